@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures from the UNMODIFIED reference (build container only).
+
+Imports ``/root/reference/lib/modeling/iodine.py`` and ``lib/utils/ari.py`` as they
+are, drives ``IODINE`` with a ``SimpleNamespace`` mirroring ``ARCH`` (lib/config is
+not importable: needs yacs and has destructive import side effects), loads weights
+from ``iodine_amd.synth.make_params`` through ``load_state_dict`` and replays a
+stored epsilon stream through ``torch.randn_like`` (the only RNG call on the path,
+lib/modeling/iodine.py:632).  Only inputs' seeds and the reference's OUTPUTS are
+written to ``tests/golden/*.npz``; no reference source is copied.
+
+Usage:  python tests/golden/gen_goldens.py [case ...]
+"""
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+
+import torch  # noqa: E402
+
+from iodine_amd import synth  # noqa: E402
+from lib.modeling.iodine import IODINE as RefIODINE  # noqa: E402  (the reference)
+from lib.utils.ari import compute_ari as ref_compute_ari, compute_mask_ari as ref_mask_ari  # noqa: E402
+
+ENCODING = ['posterior', 'grad_post', 'image', 'means', 'mask', 'mask_logits', 'mask_posterior',
+            'grad_means', 'grad_mask', 'likelihood', 'leave_one_out_likelihood', 'coordinate']
+
+# name -> (arch kwargs, B, image kind)
+ARCHS = {
+    'tiny': dict(L=8, T=2, K=3, S=16, ref=(32, 2, 32), dec=(32, 2)),
+    'dsprites': dict(L=16, S=64, ref=(32, 3, 128), dec=(32, 5)),   # configs/dsprites_noclip.yaml:26-45
+    'clevr': dict(L=64, S=128, ref=(64, 4, 256), dec=(64, 4)),     # configs/clevr6_prop.yaml:26-45
+}
+CASES = {
+    # fixture name: (arch family, K, T, B, images)
+    'tiny': ('tiny', 3, 2, 2, 'uniform'),
+    'cfg1_dsprites_k4_t3_b4': ('dsprites', 4, 3, 4, 'blobs'),
+    'cfg2_dsprites_k6_t5_b2': ('dsprites', 6, 5, 2, 'uniform'),
+    'cfg3_clevr_k7_t5_b1': ('clevr', 7, 5, 1, 'blobs'),
+    'cfg5_clevr_k11_t7_b1': ('clevr', 11, 7, 1, 'uniform'),
+}
+DEC_GAIN = 3.0
+POST_SCALE = 0.1
+SEED_W, SEED_X, SEED_E = 0, 0, 1
+
+
+def make_arch_ns(fam, K, T):
+    f = ARCHS[fam]
+    return SimpleNamespace(
+        DIM_LATENT=f['L'], ITERS=T, SLOTS=K, ENCODING=list(ENCODING), IMG_CHANNELS=3,
+        IMG_SIZE=f['S'], SIGMA=0.10, LAYERNORM=True, STOP_GRADIENT=False,
+        REF=SimpleNamespace(CONV_CHAN=f['ref'][0], CONV_LAYERS=f['ref'][1], MLP_UNITS=f['ref'][2],
+                            KERNEL_SIZE=3, STRIDE=2),
+        DEC=SimpleNamespace(CONV_CHAN=f['dec'][0], CONV_LAYERS=f['dec'][1], KERNEL_SIZE=3))
+
+
+class EpsReplay:
+    """Replace torch.randn_like by a replay of eps[i] for the i-th call."""
+    def __init__(self, eps):
+        self.eps, self.i = eps, 0
+
+    def __enter__(self):
+        self._orig = torch.randn_like
+        torch.randn_like = self
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like = self._orig
+
+    def __call__(self, t, **kw):
+        e = self.eps[self.i].to(t.dtype)
+        assert e.shape == t.shape, (e.shape, t.shape)
+        self.i += 1
+        return e
+
+
+def build_reference(fam, K, T, dtype):
+    model = RefIODINE(make_arch_ns(fam, K, T))
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    params = synth.make_params(shapes, seed=SEED_W, dec_gain=DEC_GAIN, posterior_scale=POST_SCALE)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    return model.to(dtype), shapes
+
+
+def summarize(name, t, out, n_sample=16):
+    a = t.detach().double().flatten()
+    out[name + '.sum'] = np.float64(a.sum().item())
+    out[name + '.sumsq'] = np.float64((a * a).sum().item())
+    step = max(1, a.numel() // n_sample)
+    out[name + '.sample'] = a[::step][:n_sample].numpy().copy()
+    out[name + '.shape'] = np.array(t.shape, dtype=np.int64)
+
+
+def run_case(case):
+    fam, K, T, B, kind = CASES[case]
+    S, L = ARCHS[fam]['S'], ARCHS[fam]['L']
+    if kind == 'blobs':
+        imgs, gt = synth.make_images(B, S, seed=SEED_X, kind='blobs')
+    else:
+        imgs, gt = synth.make_images(B, S, seed=SEED_X, kind='uniform'), None
+    eps = synth.make_eps(T, B, K, L, seed=SEED_E)
+    out = dict(meta_K=K, meta_T=T, meta_B=B, meta_S=S, meta_L=L, meta_kind=kind, meta_family=fam,
+               meta_dec_gain=DEC_GAIN, meta_post_scale=POST_SCALE,
+               meta_seeds=np.array([SEED_W, SEED_X, SEED_E]))
+    for tag, dtype in (('f32', torch.float32), ('f64', torch.float64)):
+        model, shapes = build_reference(fam, K, T, dtype)
+        x = torch.from_numpy(imgs).to(dtype)
+        e = torch.from_numpy(eps).to(dtype)
+
+        # ---- training step: lib/engine/train.py:60-63 (no optimizer) ----
+        model.train()
+        elbo_log = []
+        orig_elbo = model.elbo
+
+        def spy(xx, _orig=orig_elbo, _log=elbo_log, _m=model):
+            v = _orig(xx)
+            _log.append(v.detach().clone())
+            return v
+        model.elbo = spy
+        t0 = time.time()
+        with EpsReplay(e) as rp:
+            loss = model(x)
+            assert rp.i == T + 1
+        loss = loss.mean()
+        model.zero_grad()
+        loss.backward()
+        dt = time.time() - t0
+        model.elbo = orig_elbo
+        out[f'{tag}.train.loss'] = np.float64(loss.item())
+        out[f'{tag}.train.elbos'] = torch.stack(elbo_log).double().numpy().copy()
+        out[f'{tag}.train.post_mean'] = model.posterior.mean.detach().double().numpy().copy()
+        out[f'{tag}.train.post_logvar'] = model.posterior.logvar.detach().double().numpy().copy()
+        for n, prm in model.named_parameters():
+            g = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+            if case == 'tiny':
+                out[f'{tag}.train.grad.{n}'] = g.detach().double().numpy().copy()
+            else:
+                summarize(f'{tag}.train.grad.{n}', g, out)
+        print(f'  [{case}/{tag}] train loss {loss.item():.6f}  ({dt:.1f}s)')
+
+        # ---- inference step: IODINE.reconstruct (iodine.py:107-112) ----
+        model.eval()
+        elbo_log.clear()
+        model.elbo = spy
+        with EpsReplay(e) as rp:
+            pred, mask, mean = model.reconstruct(x)
+            assert rp.i == T + 1
+        model.elbo = orig_elbo
+        out[f'{tag}.recon.elbos'] = torch.stack(elbo_log).double().numpy().copy()
+        out[f'{tag}.recon.post_mean'] = model.posterior.mean.detach().double().numpy().copy()
+        out[f'{tag}.recon.post_logvar'] = model.posterior.logvar.detach().double().numpy().copy()
+        if case == 'tiny':
+            out[f'{tag}.recon.pred'] = pred.detach().double().numpy().copy()
+            out[f'{tag}.recon.mask'] = mask.detach().double().numpy().copy()
+            out[f'{tag}.recon.mean'] = mean.detach().double().numpy().copy()
+        else:
+            for nm, tt in (('pred', pred), ('mask', mask), ('mean', mean)):
+                summarize(f'{tag}.recon.{nm}', tt, out)
+        amax = torch.argmax(mask[:, :, 0], dim=1).to(torch.uint8).numpy()
+        out[f'{tag}.recon.argmax'] = amax
+        if gt is not None:
+            onehot = torch.zeros_like(mask[:, :, 0])
+            onehot.scatter_(1, torch.argmax(mask[:, :, 0], dim=1, keepdim=True), 1.0)
+            aris = [ref_mask_ari(torch.from_numpy(gt[b]), onehot[b].detach().cpu()) for b in range(B)]
+            out[f'{tag}.recon.ari'] = np.array(aris, dtype=np.float64)
+
+        # ---- per-stage tensors of the first two refinement iterations (tiny only) ----
+        if case == 'tiny' and tag == 'f32':
+            dump_stages(model, x, e, out)
+    return out
+
+
+def dump_stages(model, x, e, out):
+    """Capture the tensors the reference keeps on ``self`` after each elbo() /
+    get_input_encoding() call (iodine.py:36-52,171-216,243-343) during ``encode``."""
+    rec = []
+    orig_enc = model.get_input_encoding
+
+    def spy_enc(xx):
+        enc, lat = orig_enc(xx)
+        rec.append(dict(
+            z=model.z.detach().clone(), mean=model.mean.detach().clone(),
+            logits=model.mask_logits.detach().clone(), mask=model.mask.detach().clone(),
+            g_mean=model.mean.grad.detach().clone(), g_mask=model.mask.grad.detach().clone(),
+            g_pm=model.posterior.mean.grad.detach().clone(),
+            g_plv=model.posterior.logvar.grad.detach().clone(),
+            post_mean=model.posterior.mean.detach().clone(),
+            post_logvar=model.posterior.logvar.detach().clone(),
+            enc=enc.clone(), latent=lat.clone()))
+        return enc, lat
+    orig_ref = model.refine.forward
+
+    def spy_ref(inp, lat, hidden=(None, None)):
+        dm, dl, hc = orig_ref(inp, lat, hidden)
+        rec[-1].update(d_mean=dm.detach().clone(), d_logvar=dl.detach().clone(),
+                       h1=hc[0].detach().clone(), c1=hc[1].detach().clone())
+        return dm, dl, hc
+    model.get_input_encoding = spy_enc
+    model.refine.forward = spy_ref
+    with EpsReplay(e):
+        model.encode(x)
+    model.get_input_encoding = orig_enc
+    model.refine.forward = orig_ref
+    for i, r in enumerate(rec):
+        for k, v in r.items():
+            out[f'stage{i}.{k}'] = v.numpy()
+
+
+def ari_known_answer():
+    table = np.array([[3, 0, 1], [1, 2, 1], [0, 2, 2]])       # lib/utils/ari.py:56-63
+    extra = []
+    rng = np.random.RandomState(0)
+    for _ in range(8):
+        t = rng.randint(0, 50, size=(rng.randint(2, 6), rng.randint(2, 8)))
+        extra.append((t, ref_compute_ari(t)))
+    out = {'known.table': table, 'known.ari': np.float64(ref_compute_ari(table))}
+    for i, (t, v) in enumerate(extra):
+        out[f'rand{i}.table'] = t
+        out[f'rand{i}.ari'] = np.float64(v)
+    out['perfect.table'] = np.diag([5, 7, 9])
+    out['perfect.ari'] = np.float64(ref_compute_ari(np.diag([5, 7, 9])))
+    return out
+
+
+def main():
+    torch.set_num_threads(8)
+    want = sys.argv[1:] or (list(CASES) + ['ari'])
+    for case in want:
+        t0 = time.time()
+        out = ari_known_answer() if case == 'ari' else run_case(case)
+        path = os.path.join(HERE, case + '.npz')
+        np.savez_compressed(path, **out)
+        print(f'{case}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB, {time.time() - t0:.1f}s)')
+
+
+if __name__ == '__main__':
+    main()

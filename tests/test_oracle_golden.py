@@ -1,0 +1,117 @@
+"""Pin the CPU oracle against fixtures generated from the unmodified reference
+(tests/golden/gen_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ari_oracle as A
+from oracle import iodine_oracle as O
+from util import golden_setup, load_golden, rel_err, rel_l2
+
+torch.set_num_threads(8)
+
+
+def _summary(t, n_sample=16):
+    a = t.detach().double().flatten()
+    step = max(1, a.numel() // n_sample)
+    return a.sum().item(), (a * a).sum().item(), a[::step][:n_sample].numpy()
+
+
+def test_param_shapes_match_reference_state_dict():
+    g = load_golden('tiny')
+    arch, params, _, _, _ = golden_setup(g)
+    names = [k[len('f32.train.grad.'):] for k in g.files if k.startswith('f32.train.grad.')]
+    assert names == list(O.param_shapes(arch).keys())       # named_parameters order
+    for n in names:
+        assert tuple(g['f32.train.grad.' + n].shape) == tuple(params[n].shape)
+    # 1,109,956 / 240,036 parameters (probed on the reference)
+    assert sum(int(np.prod(s)) for s in O.param_shapes(O.clevr_arch()).values()) == 1109956
+    assert sum(int(np.prod(s)) for s in O.param_shapes(O.dsprites_arch(slots=4, iters=3)).values()) == 240036
+
+
+@pytest.mark.parametrize('tag,dtype,tol', [('f32', torch.float32, 2e-5), ('f64', torch.float64, 1e-11)])
+def test_tiny_full_tensors(tag, dtype, tol):
+    g = load_golden('tiny')
+    arch, params, x, eps, _ = golden_setup(g, dtype)
+    out, grads = O.train_step_grads(x, eps, params, arch)
+    assert abs(out['loss'].item() - float(g[f'{tag}.train.loss'])) <= tol * abs(float(g[f'{tag}.train.loss']))
+    assert rel_err(out['elbos'].numpy(), g[f'{tag}.train.elbos']) <= tol
+    assert rel_err(out['post_mean'].numpy(), g[f'{tag}.train.post_mean']) <= 50 * tol
+    for n, gv in grads.items():
+        ref = g[f'{tag}.train.grad.{n}']
+        assert rel_l2(gv.numpy(), ref) <= 200 * tol, n
+    rec = O.reconstruct(x, eps, params, arch)
+    assert rel_err(rec['elbos'].numpy(), g[f'{tag}.recon.elbos']) <= tol
+    for k in ('pred', 'mask', 'mean'):
+        assert rel_err(rec[k].numpy(), g[f'{tag}.recon.{k}']) <= 100 * tol, k
+    assert rel_err(rec['post_logvar'].numpy(), g[f'{tag}.recon.post_logvar']) <= 50 * tol
+
+
+def test_tiny_stage_tensors():
+    g = load_golden('tiny')
+    arch, params, x, eps, _ = golden_setup(g)
+    trace = []
+    O.reconstruct(x, eps, params, arch, trace=trace)
+    assert len(trace) == arch.iters
+    for i, st in enumerate(trace):
+        for k in ('z', 'mean', 'logits', 'mask', 'g_mean', 'g_mask', 'g_pm', 'g_plv', 'post_mean',
+                  'post_logvar', 'enc', 'latent', 'd_mean', 'd_logvar', 'h1', 'c1'):
+            ref = g[f'stage{i}.{k}']
+            assert tuple(ref.shape) == tuple(st[k].shape), (i, k)
+            assert rel_err(st[k].numpy(), ref) <= 3e-4, (i, k)
+        # per-channel check of the 17-channel encoding (order fixed by iodine.py:277-340)
+        enc, ref = st['enc'].numpy(), g[f'stage{i}.enc']
+        for c in range(17):
+            assert rel_err(enc[:, :, c], ref[:, :, c]) <= 3e-4, (i, c)
+
+
+def test_closed_form_inner_gradients_match_autograd():
+    g = load_golden('tiny')
+    arch, params, x, eps, _ = golden_setup(g, torch.float64)
+    for i in range(arch.iters):
+        mean = torch.from_numpy(g[f'stage{i}.mean']).double()
+        logits = torch.from_numpy(g[f'stage{i}.logits']).double()
+        cf = O.pixel_closed_form(x, mean, logits, arch.sigma)
+        assert rel_err(cf['g_mean'].numpy(), g[f'stage{i}.g_mean']) <= 1e-5
+        assert rel_err(cf['g_mask'].numpy(), g[f'stage{i}.g_mask']) <= 1e-5
+
+
+@pytest.mark.parametrize('case', ['cfg1_dsprites_k4_t3_b4', 'cfg2_dsprites_k6_t5_b2',
+                                  'cfg3_clevr_k7_t5_b1', 'cfg5_clevr_k11_t7_b1'])
+def test_config_scalars(case):
+    g = load_golden(case)
+    arch, params, x, eps, gt = golden_setup(g)
+    out, grads = O.train_step_grads(x, eps, params, arch)
+    ref_loss = float(g['f32.train.loss'])
+    assert abs(out['loss'].item() - ref_loss) <= 2e-5 * abs(ref_loss)
+    assert rel_err(out['elbos'].numpy(), g['f32.train.elbos']) <= 2e-5
+    # the reference's own fp32-vs-fp64 distance bounds what "equal" can mean here
+    assert abs(out['loss'].item() - float(g['f64.train.loss'])) <= 1e-4 * abs(ref_loss)
+    for n, gv in grads.items():
+        s, ss, smp = _summary(gv)
+        ref_ss = float(g[f'f32.train.grad.{n}.sumsq'])
+        assert abs(ss - ref_ss) <= 5e-3 * ref_ss + 1e-12, n
+        assert np.abs(smp - g[f'f32.train.grad.{n}.sample']).max() <= 5e-3 * np.sqrt(ref_ss / gv.numel()) + 1e-7, n
+    rec = O.reconstruct(x, eps, params, arch)
+    assert rel_err(rec['elbos'].numpy(), g['f32.recon.elbos']) <= 2e-5
+    for k in ('pred', 'mask', 'mean'):
+        s, ss, smp = _summary(rec[k])
+        assert abs(ss - float(g[f'f32.recon.{k}.sumsq'])) <= 1e-4 * float(g[f'f32.recon.{k}.sumsq']), k
+    amax = rec['mask'][:, :, 0].argmax(dim=1).numpy()
+    assert (amax == g['f32.recon.argmax']).mean() >= 0.999
+    if gt is not None:
+        onehot = A.binarize_argmax(rec['mask'].numpy())
+        aris = [A.compute_mask_ari(gt[b], onehot[b]) for b in range(len(gt))]
+        assert np.abs(np.array(aris) - g['f32.recon.ari']).max() <= 1e-3
+
+
+def test_ari_known_answers():
+    g = load_golden('ari')
+    assert abs(float(g['known.ari']) - 1.0 / 12.0) < 1e-12          # lib/utils/ari.py:56-63 prints 0.08333
+    assert abs(A.compute_ari(g['known.table']) - float(g['known.ari'])) < 1e-12
+    assert A.compute_ari(g['perfect.table']) == float(g['perfect.ari']) == 1.0
+    i = 0
+    while f'rand{i}.table' in g.files:
+        assert abs(A.compute_ari(g[f'rand{i}.table']) - float(g[f'rand{i}.ari'])) < 1e-12
+        i += 1
+    assert i >= 8
