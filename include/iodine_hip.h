@@ -1,0 +1,136 @@
+/* libiodine_hip.so -- C ABI of the MI355X-native (gfx950) IODINE refinement step.
+ *
+ * The reference (zhixuan-lin/IODINE) has no FFI: its boundary for this path is the
+ * nn.Module protocol of lib/modeling/iodine.py as used by lib/engine/train.py:58-65,
+ * lib/engine/eval.py:14-28 and lib/eval/ari_eval.py:22.  Each entry point below names the
+ * reference interface it replaces.  All pointers named *_dev / x / eps / outputs are DEVICE
+ * pointers owned by the caller (torch); `stream` is a hipStream_t (pass
+ * torch.cuda.current_stream().cuda_stream).  Nothing throws across this ABI: every call
+ * returns an int status and iodine_last_error() gives the message.
+ *
+ * Layouts at the boundary are the reference's: images (B,3,S,S) NCHW fp32 in [0,1];
+ * eps (T+1,B,K,L) standard normals, one slice per Gaussian.sample call
+ * (iodine.py:620-634); parameters in state_dict order with state_dict shapes (OIHW convs).
+ * A handle is bound to one device and is NOT re-entrant (neither is the reference module,
+ * iodine.py:36-52); use one handle per (device, stream).
+ */
+#ifndef IODINE_HIP_H
+#define IODINE_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IODINE_OK 0
+#define IODINE_ERR_INVALID 1       /* bad argument / unsupported configuration */
+#define IODINE_ERR_HIP 2           /* a HIP runtime call or kernel launch failed */
+#define IODINE_ERR_STATE 3         /* call order violated (params not set, no forward before backward ...) */
+#define IODINE_ERR_WORKSPACE 4     /* caller-provided workspace too small */
+
+#define IODINE_ABI_VERSION 1
+
+/* bit i set <=> the i-th entry of ARCH.ENCODING is enabled; order = code order of
+ * IODINE.get_input_encoding (iodine.py:253-340).  Only IODINE_ENC_FULL (every shipped
+ * config) is implemented; anything else is rejected, never silently approximated. */
+#define IODINE_ENC_POSTERIOR      (1u << 0)
+#define IODINE_ENC_GRAD_POST      (1u << 1)
+#define IODINE_ENC_IMAGE          (1u << 2)
+#define IODINE_ENC_MEANS          (1u << 3)
+#define IODINE_ENC_MASK           (1u << 4)
+#define IODINE_ENC_MASK_LOGITS    (1u << 5)
+#define IODINE_ENC_MASK_POSTERIOR (1u << 6)
+#define IODINE_ENC_GRAD_MEANS     (1u << 7)
+#define IODINE_ENC_GRAD_MASK      (1u << 8)
+#define IODINE_ENC_LIKELIHOOD     (1u << 9)
+#define IODINE_ENC_LEAVE_ONE_OUT  (1u << 10)
+#define IODINE_ENC_COORDINATE     (1u << 11)
+#define IODINE_ENC_FULL           0xFFFu
+
+/* Mirror of the ARCH.* node read by IODINE.__init__ (iodine.py:8-32; defaults lib/config/defaults.py:35-100). */
+typedef struct iodine_config {
+    int dim_latent;        /* ARCH.DIM_LATENT  */
+    int iters;             /* ARCH.ITERS       */
+    int slots;             /* ARCH.SLOTS       */
+    int img_size;          /* ARCH.IMG_SIZE    (multiple of 16) */
+    int img_channels;      /* ARCH.IMG_CHANNELS (3) */
+    double sigma;          /* ARCH.SIGMA       */
+    int layernorm;         /* ARCH.LAYERNORM   */
+    int stop_gradient;     /* ARCH.STOP_GRADIENT (stored, unused: iodine.py:21 has no caller) */
+    unsigned encoding;     /* ARCH.ENCODING as IODINE_ENC_* bits */
+    int ref_conv_chan;     /* ARCH.REF.CONV_CHAN   (32 or 64) */
+    int ref_conv_layers;   /* ARCH.REF.CONV_LAYERS */
+    int ref_mlp_units;     /* ARCH.REF.MLP_UNITS   */
+    int ref_kernel_size;   /* ARCH.REF.KERNEL_SIZE (3) */
+    int ref_stride;        /* ARCH.REF.STRIDE      (2) */
+    int dec_conv_chan;     /* ARCH.DEC.CONV_CHAN   (32 or 64) */
+    int dec_conv_layers;   /* ARCH.DEC.CONV_LAYERS (>= 2) */
+    int dec_kernel_size;   /* ARCH.DEC.KERNEL_SIZE (3) */
+} iodine_config;
+
+typedef struct iodine_handle iodine_handle;
+
+int iodine_abi_version(void);
+
+/* IODINE(ARCH) -- iodine.py:8-52.  Builds the parameter table and the packed-weight buffers on the
+ * current HIP device.  On failure *out is NULL and iodine_last_error(NULL) holds the reason. */
+int iodine_create(const iodine_config* cfg, iodine_handle** out);
+void iodine_destroy(iodine_handle* h);
+const char* iodine_last_error(const iodine_handle* h);
+
+/* model.named_parameters() / state_dict() surface (lib/solver/build.py:10-14, lib/utils/checkpoint.py:43,68). */
+int iodine_num_params(const iodine_handle* h);
+int iodine_param_info(const iodine_handle* h, int index, const char** name, int* ndim, long long dims[4]);
+
+/* load_state_dict / "parameters changed" notification: repacks every weight into the kernels' layouts
+ * (NHWC/MFMA quads, border-class sums and coordinate map of the broadcast layer, transposed head weights).
+ * dev_ptrs[i] is the i-th parameter (state_dict order, reference shapes, contiguous fp32). */
+int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev_ptrs, int n);
+
+/* Workspace: mode 0 = inference (reconstruct/decode), 1 = training.  If no workspace is installed the
+ * library allocates one itself on first use (never inside the refinement loop). */
+size_t iodine_workspace_bytes(const iodine_handle* h, int batch, int mode);
+int iodine_set_workspace(iodine_handle* h, void* dev_ptr, size_t bytes);
+
+/* pred, mask, mean = model.reconstruct(x) -- iodine.py:107-112 (encode :73-105 + decode :59-71).
+ * Outputs (any may be NULL): pred (B,3,S,S), mask (B,K,1,S,S), mean (B,K,3,S,S) NCHW; z (B,K,L) = the final
+ * sample; post_mean / post_logvar (B,K,L) = lambda after T updates; elbo_iter (T,3) = {ELBO, KL, LL} of each
+ * elbo() call, batch means exactly as iodine.py:193,220,223. */
+int iodine_reconstruct(iodine_handle* h, void* stream, int batch, const float* x, const float* eps,
+                       float* pred, float* mask, float* mean, float* z, float* post_mean, float* post_logvar,
+                       float* elbo_iter);
+
+/* pred, mask, mean = model.decode(z) -- iodine.py:59-71. */
+int iodine_decode(iodine_handle* h, void* stream, int batch, const float* z, float* pred, float* mask, float* mean);
+
+/* loss = model(x) -- IODINE.forward, iodine.py:115-158.  loss (1) and elbo_iter (T+1,3) are device outputs.
+ * Keeps what iodine_train_backward needs in the workspace (the autograd graph of the reference). */
+int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float* x, const float* eps,
+                         float* loss, float* elbo_iter);
+
+/* loss.backward() -- lib/engine/train.py:63.  Accumulates grad_scale * d loss / d param INTO param_grads[i]
+ * (+=, like autograd's .grad accumulation; zero_grad is the caller's job, train.py:62). */
+int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, float* const* param_grads, int n);
+
+/* Debug / test hooks: key "stop_after_iters" (run only the first v refinement iterations in reconstruct). */
+int iodine_set_option(iodine_handle* h, const char* key, double value);
+/* Copy an internal buffer of the last call (name as listed in DESIGN.md "workspace") to dst (device). */
+int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter, float* dst, size_t max_floats,
+                      size_t* n_floats);
+
+/* ---- operator-level entry points (used by tests/ to check each kernel against the oracle) ------------- */
+/* torch.linspace(-1, 1, n) in fp32, bit-exact restatement of ATen's CPU kernel (iodine.py:334-335,526-527). HOST. */
+void iodine_linspace_host(int n, float* out);
+/* 3x3 conv, NHWC activations, OIHW weights; mode 0: stride-1 LDS-tiled (epi 0 bias+ELU, 1 multiply by ELU'(aux),
+ * 2 none; transpose_flip=1 computes the data-gradient conv), mode 1: strided gather kernel (bias+ELU). */
+int iodine_op_conv3x3(void* stream, int mode, const float* in_nhwc, const float* w_oihw, const float* bias,
+                      const float* aux, float* out_nhwc, int n, int ih, int iw, int w_o, int w_i, int cin_pad,
+                      int cout, int stride, int epi, int transpose_flip);
+int iodine_op_dec_out(void* stream, const float* in_nhwc, const float* w_oihw, const float* bias, float* out_nhwc4,
+                      int n, int s, int c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IODINE_HIP_H */

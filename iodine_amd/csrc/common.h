@@ -1,0 +1,77 @@
+// Shared device helpers and launcher declarations for libiodine_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define IOD_DEVINL __device__ __forceinline__
+
+// ELU with alpha = 1 (torch.nn.functional.elu): x > 0 ? x : expm1(x)
+IOD_DEVINL float elu1(float v) { return v > 0.f ? v : expm1f(v); }
+// derivative of ELU expressed through its OUTPUT a = ELU(x): a > 0 ? 1 : a + 1
+IOD_DEVINL float elu1_grad_from_out(float a) { return a > 0.f ? 1.f : a + 1.f; }
+IOD_DEVINL float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+// ---- packed conv-weight geometry (shared by host packer and kernels) ------------------
+// A 3x3 conv with CIN (padded) input channels is cut into chunks of CC channels.  Inside a
+// chunk the reduction index is organised in "quads" q = tap * (CC/4) + cig: 4 consecutive
+// input channels (cig*4 .. +3) at filter tap `tap` (= dy*3+dx).  Quads are consumed in
+// pairs by v_mfma_f32_32x32x2_f32: lanes 0-31 feed quad 2g, lanes 32-63 quad 2g+1, element
+// s of the quad at MFMA step s.  wpk[chunk][q][co] is a float4 over the quad's 4 channels.
+__host__ __device__ constexpr int conv_cc(int cin) { return cin == 20 ? 20 : (cin >= 16 ? 16 : cin); }
+__host__ __device__ constexpr int conv_nq(int cin) { return 9 * (conv_cc(cin) / 4); }
+__host__ __device__ constexpr int conv_nqp(int cin) { return (conv_nq(cin) + 1) & ~1; }
+__host__ __device__ constexpr int conv_nchunk(int cin) { return cin / conv_cc(cin); }
+// float4 elements in a packed weight tensor
+__host__ __device__ constexpr size_t conv_wpk_elems(int cin, int cout) {
+    return (size_t)conv_nchunk(cin) * conv_nqp(cin) * cout;
+}
+
+enum ConvEpilogue { EPI_BIAS_ELU = 0, EPI_MUL_ELUGRAD = 1, EPI_NONE = 2 };
+
+// ---- launchers (each returns hipError_t from the launch) -------------------------------
+hipError_t launch_pack_conv_weights(hipStream_t st, const float* src_oihw, int O, int I, int cin_pad,
+                                    int cout, int transpose_flip, float* dst);
+hipError_t launch_conv3x3_tile(hipStream_t st, const float* in, const float* wpk, const float* bias,
+                               const float* aux, float* out, int N, int S, int cin, int cout, int epi);
+hipError_t launch_conv3x3_gather(hipStream_t st, const float* in, const float* wpk, const float* bias,
+                                 float* out, int N, int IH, int IW, int cin, int cout, int stride);
+hipError_t launch_dec_out(hipStream_t st, const float* in, const float* wk, const float* bias, float* out,
+                          int N, int S, int C);
+
+// kernels_pixel.hip
+int pixel_blocks_per_image(int P);
+hipError_t launch_pixel_pass1(hipStream_t st, const float* x4, const float* dec, float* g, double* part, int B,
+                              int K, int P, float sigma);
+hipError_t launch_pixel_finalize(hipStream_t st, const double* part, int B, int K, int P, int use_ln,
+                                 float* lnstat, float* ll_img);
+hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec, const float* lnstat,
+                              const float* lin, float* enc, int B, int K, int S, float sigma);
+hipError_t launch_final_out(hipStream_t st, const float* dec, float* pred, float* mask, float* mean, int B, int K,
+                            int P);
+// kernels_misc.hip
+hipError_t launch_x_to_nhwc4(hipStream_t st, const float* x, float* x4, int B, int P);
+hipError_t launch_posterior_init(hipStream_t st, const float* im, const float* ilv, float* pm, float* plv, float* h,
+                                 float* c, int N, int L, int H);
+hipError_t launch_dec_l0_prepare(hipStream_t st, const float* w, const float* bias, const float* lin, int C, int L,
+                                 int S, float* wcls, float* wclsT, float* cmap);
+hipError_t launch_dec_v(hipStream_t st, const float* pm, const float* plv, const float* eps, const float* z_in,
+                        const float* wcls, float* z_out, float* V, int N, int L, int C);
+hipError_t launch_dec_l0(hipStream_t st, const float* V, const float* cmap, float* out, int N, int S, int C);
+hipError_t launch_l0_reduce(hipStream_t st, const float* dpre, float* rows, float* Rc, int N, int S, int C);
+hipError_t launch_dz_latent(hipStream_t st, const float* Rc, const float* wclsT, const float* pm, const float* plv,
+                            const float* eps, int N, int L, int C, int use_ln, float* g_pm, float* g_plv, float* latent);
+hipError_t launch_elbo(hipStream_t st, const float* pm, const float* plv, const float* ll_img, int B, int K, int L,
+                       float* img_terms, float* scal);
+hipError_t launch_refine_head(hipStream_t st, const float* feat, int N, int PL, int C, int H, int L,
+                              const float* mlp_wT, const float* mlp_b, const float* wihT, const float* whhT,
+                              const float* lstm_b, const float* wmT, const float* bm, const float* wvT, const float* bv,
+                              const float* latent, const float* h_prev, const float* c_prev, float* h_out, float* c_out,
+                              float* pm, float* plv, float* sv_pooled, float* sv_u, float* sv_gates, float* d_mean,
+                              float* d_logvar);
+hipError_t launch_transpose(hipStream_t st, const float* src, float* dst, int R, int Cc);
+hipError_t launch_add2(hipStream_t st, const float* a, const float* b, float* o, int n);
+hipError_t launch_pack_dec_out(hipStream_t st, const float* w, float* wk, int C);

@@ -1,0 +1,627 @@
+// Host side of libiodine_hip.so: handle, parameter repacking, workspace planning and the
+// T-step refinement loop (kernel launch sequence).  See include/iodine_hip.h for the ABI and the
+// reference call sites each entry point replaces.
+#include "../../include/iodine_hip.h"
+#include "common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_create_error;
+
+struct ParamInfo {
+    std::string name;
+    int ndim;
+    long long dims[4];
+    size_t numel() const { size_t n = 1; for (int i = 0; i < ndim; ++i) n *= (size_t)dims[i]; return n; }
+};
+
+// bump allocator over a (possibly NULL = size query) base pointer
+struct Arena {
+    char* base;
+    size_t off = 0;
+    explicit Arena(void* b) : base((char*)b) {}
+    template <typename T> T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+struct Buffers {               // workspace carve-up for one batch size / mode
+    int B = 0, mode = -1;
+    size_t bytes = 0;
+    float *x4, *V, *dec_out, *g, *lnstat, *ll_img, *img_terms, *scal, *rows, *Rc, *pm, *plv;
+    double* part;
+    std::vector<float*> act;                   // decoder activations a[0..Dd-1]   (N,P,Cd)
+    float* dpre[2];                            // ping-pong gradient wrt pre-activations
+    // per-iteration buffers: index i (training keeps all T(+1) copies, inference aliases them)
+    std::vector<float*> z, g_pm, g_plv, latent, enc, pooled, u, gates, h, c;
+    std::vector<std::vector<float*>> ract;     // [iter][layer] refinement activations
+};
+
+}  // namespace
+
+struct iodine_handle {
+    iodine_config cfg;
+    std::string err;
+    int L, T, K, S, P, Cd, Dd, Cr, Dr, H;
+    std::vector<ParamInfo> params;
+    bool params_set = false;
+    int stop_after = -1;
+
+    // parameter-derived device buffers (owned)
+    float* lin = nullptr;                       // linspace(-1,1,S)
+    float *wcls = nullptr, *wclsT = nullptr, *cmap = nullptr;
+    std::vector<float*> dec_wf, dec_wb, dec_b;  // packed fwd / dgrad weights + bias copies for layers 1..Dd-1
+    float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr;
+    std::vector<float*> ref_w, ref_b;
+    float *mlp_wT = nullptr, *mlp_b = nullptr, *wihT = nullptr, *whhT = nullptr, *lstm_b = nullptr;
+    float *wmT = nullptr, *bm = nullptr, *wvT = nullptr, *bv = nullptr, *init_mean = nullptr, *init_logvar = nullptr;
+    std::vector<void*> owned;
+
+    // workspace
+    void* ws_user = nullptr; size_t ws_user_bytes = 0;
+    void* ws_own = nullptr; size_t ws_own_bytes = 0;
+    Buffers buf;
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return (h)->fail(IODINE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+hipError_t dev_alloc(iodine_handle* h, T** p, size_t n)
+{
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess) { *p = (T*)q; h->owned.push_back(q); }
+    return e;
+}
+
+void build_param_table(iodine_handle* h)
+{
+    // names / shapes of the reference module tree in named_parameters() order
+    // (iodine.py:26-33, 412-423, 446-464, 543-557, 570-584, 596-604)
+    auto add = [&](const std::string& n, std::initializer_list<long long> d) {
+        ParamInfo p; p.name = n; p.ndim = (int)d.size(); int i = 0;
+        for (long long v : d) p.dims[i++] = v;
+        for (; i < 4; ++i) p.dims[i] = 1;
+        h->params.push_back(p);
+    };
+    const iodine_config& c = h->cfg;
+    int cin = 17;
+    for (int i = 0; i < c.ref_conv_layers; ++i) {
+        add("refine.mlc.layers." + std::to_string(i) + ".weight", {c.ref_conv_chan, cin, 3, 3});
+        add("refine.mlc.layers." + std::to_string(i) + ".bias", {c.ref_conv_chan});
+        cin = c.ref_conv_chan;
+    }
+    const long long H = c.ref_mlp_units, L = c.dim_latent;
+    add("refine.mlp.layers.0.weight", {H, c.ref_conv_chan});
+    add("refine.mlp.layers.0.bias", {H});
+    add("refine.lstm.weight_ih", {4 * H, H + 4 * L});
+    add("refine.lstm.weight_hh", {4 * H, H});
+    add("refine.lstm.bias_ih", {4 * H});
+    add("refine.lstm.bias_hh", {4 * H});
+    add("refine.mean_update.weight", {L, H});
+    add("refine.mean_update.bias", {L});
+    add("refine.logvar_update.weight", {L, H});
+    add("refine.logvar_update.bias", {L});
+    cin = c.dim_latent + 2;
+    for (int i = 0; i < c.dec_conv_layers; ++i) {
+        add("decoder.mlc.layers." + std::to_string(i) + ".weight", {c.dec_conv_chan, cin, 3, 3});
+        add("decoder.mlc.layers." + std::to_string(i) + ".bias", {c.dec_conv_chan});
+        cin = c.dec_conv_chan;
+    }
+    add("decoder.conv.weight", {4, c.dec_conv_chan, 3, 3});
+    add("decoder.conv.bias", {4});
+    add("posterior.init_mean", {L});
+    add("posterior.init_logvar", {L});
+}
+
+int param_index(const iodine_handle* h, const std::string& name)
+{
+    for (size_t i = 0; i < h->params.size(); ++i)
+        if (h->params[i].name == name) return (int)i;
+    return -1;
+}
+
+std::string validate(const iodine_config& c)
+{
+    char m[256];
+    if (c.encoding != IODINE_ENC_FULL) return "only the full 12-entry ARCH.ENCODING list (17 input channels) is implemented";
+    if (c.img_channels != 3) return "ARCH.IMG_CHANNELS must be 3";
+    if (c.dec_kernel_size != 3 || c.ref_kernel_size != 3) return "only KERNEL_SIZE 3 is implemented (all BASELINE configs)";
+    if (c.ref_stride != 2) return "only REF.STRIDE 2 is implemented";
+    if (c.img_size < 16 || c.img_size % 16 != 0) return "ARCH.IMG_SIZE must be a positive multiple of 16";
+    if (c.dec_conv_chan != 32 && c.dec_conv_chan != 64) return "DEC.CONV_CHAN must be 32 or 64";
+    if (c.ref_conv_chan != 32 && c.ref_conv_chan != 64) return "REF.CONV_CHAN must be 32 or 64";
+    if (c.dec_conv_layers < 2) return "DEC.CONV_LAYERS must be >= 2";
+    if (c.ref_conv_layers < 1 || (c.img_size >> c.ref_conv_layers) < 1) return "REF.CONV_LAYERS out of range for IMG_SIZE";
+    if (c.slots < 1 || c.slots > 12) return "ARCH.SLOTS must be in 1..12";
+    if (c.iters < 1) return "ARCH.ITERS must be >= 1";
+    if (c.dim_latent < 2 || c.dim_latent > 256) return "ARCH.DIM_LATENT must be in 2..256";
+    if (c.ref_mlp_units < 1 || c.ref_mlp_units > 1024) return "REF.MLP_UNITS must be in 1..1024";
+    if (!(c.sigma > 0)) { snprintf(m, sizeof m, "ARCH.SIGMA must be > 0 (got %g)", c.sigma); return m; }
+    return "";
+}
+
+// spatial size of refinement layer l's OUTPUT (3x3, pad 1, stride 2): floor((s + 2 - 3)/2) + 1
+int ref_out_size(int s) { return (s - 1) / 2 + 1; }
+
+void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
+{
+    const int N = B * h->K, P = h->P, L = h->L, Cd = h->Cd, Cr = h->Cr, H = h->H, T = h->T;
+    b.B = B; b.mode = mode;
+    b.x4 = a.take<float>((size_t)B * P * 4);
+    b.V = a.take<float>((size_t)N * 9 * Cd);
+    b.dec_out = a.take<float>((size_t)N * P * 4);
+    b.g = a.take<float>((size_t)N * P * 4);
+    b.part = a.take<double>((size_t)B * pixel_blocks_per_image(P) * (6 * h->K + 3));
+    b.lnstat = a.take<float>((size_t)N * 8);
+    b.ll_img = a.take<float>((size_t)B);
+    b.img_terms = a.take<float>((size_t)(T + 1) * B * 2);
+    b.scal = a.take<float>((size_t)(T + 1) * 3 + 4);
+    b.rows = a.take<float>((size_t)N * h->S * 3 * Cd);
+    b.Rc = a.take<float>((size_t)N * 9 * Cd);
+    b.pm = a.take<float>((size_t)N * L);
+    b.plv = a.take<float>((size_t)N * L);
+    b.act.resize(h->Dd);
+    for (int l = 0; l < h->Dd; ++l) b.act[l] = a.take<float>((size_t)N * P * Cd);
+    b.dpre[0] = a.take<float>((size_t)N * P * Cd);
+    b.dpre[1] = a.take<float>((size_t)N * P * Cd);
+    const int ncopy = mode == 1 ? T + 1 : 1;
+    auto per_iter = [&](std::vector<float*>& v, size_t n, int copies) {
+        v.resize(T + 1);
+        for (int i = 0; i <= T; ++i) v[i] = (i < copies) ? a.take<float>(n) : v[0];
+    };
+    per_iter(b.z, (size_t)N * L, ncopy);
+    per_iter(b.g_pm, (size_t)N * L, ncopy);
+    per_iter(b.g_plv, (size_t)N * L, ncopy);
+    per_iter(b.latent, (size_t)N * 4 * L, ncopy);
+    per_iter(b.enc, (size_t)N * P * 20, mode == 1 ? T : 1);
+    per_iter(b.pooled, (size_t)N * Cr, ncopy);
+    per_iter(b.u, (size_t)N * H, ncopy);
+    per_iter(b.gates, (size_t)N * 4 * H, ncopy);
+    // LSTM state: h[i], c[i] = state BEFORE iteration i; inference ping-pongs two copies
+    b.h.resize(T + 2); b.c.resize(T + 2);
+    if (mode == 1) {
+        for (int i = 0; i <= T + 1; ++i) { b.h[i] = a.take<float>((size_t)N * H); b.c[i] = a.take<float>((size_t)N * H); }
+    } else {
+        float* hh[2] = {a.take<float>((size_t)N * H), a.take<float>((size_t)N * H)};
+        float* cc[2] = {a.take<float>((size_t)N * H), a.take<float>((size_t)N * H)};
+        for (int i = 0; i <= T + 1; ++i) { b.h[i] = hh[i & 1]; b.c[i] = cc[i & 1]; }
+    }
+    b.ract.assign(T + 1, std::vector<float*>(h->Dr));
+    for (int i = 0; i <= T; ++i) {
+        int s = h->S;
+        for (int l = 0; l < h->Dr; ++l) {
+            s = ref_out_size(s);
+            b.ract[i][l] = (i == 0 || (mode == 1 && i < T)) ? a.take<float>((size_t)N * s * s * Cr) : b.ract[0][l];
+        }
+    }
+    b.bytes = (a.off + 255) & ~(size_t)255;
+}
+
+int ensure_workspace(iodine_handle* h, int B, int mode)
+{
+    if (h->buf.B == B && h->buf.mode == mode && h->buf.bytes > 0) return IODINE_OK;
+    Arena q(nullptr); Buffers tmp; plan(h, B, mode, q, tmp);
+    void* base = nullptr;
+    if (h->ws_user) {
+        if (h->ws_user_bytes < tmp.bytes) {
+            char m[160];
+            snprintf(m, sizeof m, "workspace too small: need %zu bytes for batch %d mode %d, have %zu", tmp.bytes, B,
+                     mode, h->ws_user_bytes);
+            return h->fail(IODINE_ERR_WORKSPACE, m);
+        }
+        base = h->ws_user;
+    } else {
+        if (h->ws_own_bytes < tmp.bytes) {
+            if (h->ws_own) { HIPCHK(h, hipFree(h->ws_own)); h->ws_own = nullptr; h->ws_own_bytes = 0; }
+            HIPCHK(h, hipMalloc(&h->ws_own, tmp.bytes));
+            h->ws_own_bytes = tmp.bytes;
+        }
+        base = h->ws_own;
+    }
+    Arena a(base);
+    plan(h, B, mode, a, h->buf);
+    return IODINE_OK;
+}
+
+// one decoder forward pass from z (already in buf.V via dec_v) -> dec_out
+int decoder_forward(iodine_handle* h, hipStream_t st, int N)
+{
+    Buffers& b = h->buf;
+    HIPCHK(h, launch_dec_l0(st, b.V, h->cmap, b.act[0], N, h->S, h->Cd));
+    for (int l = 1; l < h->Dd; ++l)
+        HIPCHK(h, launch_conv3x3_tile(st, b.act[l - 1], h->dec_wf[l], h->dec_b[l], nullptr, b.act[l], N, h->S, h->Cd,
+                                      h->Cd, EPI_BIAS_ELU));
+    HIPCHK(h, launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, b.dec_out, N, h->S, h->Cd));
+    return IODINE_OK;
+}
+
+// gradient of B*ELBO wrt the decoder input z through the whole decoder (replaces the autograd traversal of
+// (B*elbo).backward(), iodine.py:90,137).  Leaves d(pre-activation) of layer 0 in the returned buffer.
+int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0)
+{
+    Buffers& b = h->buf;
+    int cur = 0;
+    HIPCHK(h, launch_conv3x3_tile(st, b.g, h->dec_out_wb, nullptr, b.act[h->Dd - 1], b.dpre[cur], N, h->S, 4, h->Cd,
+                                  EPI_MUL_ELUGRAD));
+    for (int l = h->Dd - 1; l >= 1; --l) {
+        HIPCHK(h, launch_conv3x3_tile(st, b.dpre[cur], h->dec_wb[l], nullptr, b.act[l - 1], b.dpre[cur ^ 1], N, h->S,
+                                      h->Cd, h->Cd, EPI_MUL_ELUGRAD));
+        cur ^= 1;
+    }
+    *dpre0 = b.dpre[cur];
+    return IODINE_OK;
+}
+
+// elbo() + inner backward + get_input_encoding for iteration i (iodine.py:85-93 / 133-142)
+int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps_i, int i, bool need_grads)
+{
+    Buffers& b = h->buf;
+    const int N = B * h->K;
+    HIPCHK(h, launch_dec_v(st, b.pm, b.plv, eps_i, nullptr, h->wcls, b.z[i], b.V, N, h->L, h->Cd));
+    int rc = decoder_forward(h, st, N);
+    if (rc) return rc;
+    HIPCHK(h, launch_pixel_pass1(st, b.x4, b.dec_out, b.g, b.part, B, h->K, h->P, (float)h->cfg.sigma));
+    HIPCHK(h, launch_pixel_finalize(st, b.part, B, h->K, h->P, h->cfg.layernorm, b.lnstat, b.ll_img));
+    HIPCHK(h, launch_elbo(st, b.pm, b.plv, b.ll_img, B, h->K, h->L, b.img_terms + (size_t)i * B * 2, b.scal + 3 * i));
+    if (!need_grads) return IODINE_OK;
+    float* dpre0 = nullptr;
+    rc = decoder_backward_data(h, st, N, &dpre0);
+    if (rc) return rc;
+    HIPCHK(h, launch_l0_reduce(st, dpre0, b.rows, b.Rc, N, h->S, h->Cd));
+    HIPCHK(h, launch_dz_latent(st, b.Rc, h->wclsT, b.pm, b.plv, eps_i, N, h->L, h->Cd, h->cfg.layernorm, b.g_pm[i],
+                               b.g_plv[i], b.latent[i]));
+    return IODINE_OK;
+}
+
+// refine() + posterior.update() for iteration i (iodine.py:95-100 / 144-145)
+int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
+{
+    Buffers& b = h->buf;
+    const int N = B * h->K;
+    HIPCHK(h, launch_pixel_pass2(st, b.x4, b.dec_out, b.lnstat, h->lin, b.enc[i], B, h->K, h->S, (float)h->cfg.sigma));
+    int s = h->S;
+    const float* in = b.enc[i];
+    for (int l = 0; l < h->Dr; ++l) {
+        HIPCHK(h, launch_conv3x3_gather(st, in, h->ref_w[l], h->ref_b[l], b.ract[i][l], N, s, s, l == 0 ? 20 : h->Cr,
+                                        h->Cr, 2));
+        in = b.ract[i][l];
+        s = ref_out_size(s);
+    }
+    HIPCHK(h, launch_refine_head(st, in, N, s * s, h->Cr, h->H, h->L, h->mlp_wT, h->mlp_b, h->wihT, h->whhT, h->lstm_b,
+                                 h->wmT, h->bm, h->wvT, h->bv, b.latent[i], b.h[i], b.c[i], b.h[i + 1], b.c[i + 1], b.pm,
+                                 b.plv, save ? b.pooled[i] : nullptr, save ? b.u[i] : nullptr,
+                                 save ? b.gates[i] : nullptr, nullptr, nullptr));
+    return IODINE_OK;
+}
+
+int check_ready(iodine_handle* h, int batch)
+{
+    if (!h) return IODINE_ERR_INVALID;
+    if (!h->params_set) return h->fail(IODINE_ERR_STATE, "iodine_set_params has not been called");
+    if (batch < 1) return h->fail(IODINE_ERR_INVALID, "batch must be >= 1");
+    return IODINE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int iodine_abi_version(void) { return IODINE_ABI_VERSION; }
+
+const char* iodine_last_error(const iodine_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int iodine_create(const iodine_config* cfg, iodine_handle** out)
+{
+    if (out) *out = nullptr;
+    if (!cfg || !out) { g_create_error = "null argument"; return IODINE_ERR_INVALID; }
+    const std::string why = validate(*cfg);
+    if (!why.empty()) { g_create_error = why; return IODINE_ERR_INVALID; }
+    iodine_handle* h = new iodine_handle();
+    h->cfg = *cfg;
+    h->L = cfg->dim_latent; h->T = cfg->iters; h->K = cfg->slots; h->S = cfg->img_size; h->P = h->S * h->S;
+    h->Cd = cfg->dec_conv_chan; h->Dd = cfg->dec_conv_layers; h->Cr = cfg->ref_conv_chan; h->Dr = cfg->ref_conv_layers;
+    h->H = cfg->ref_mlp_units;
+    build_param_table(h);
+
+    auto bail = [&](hipError_t e, const char* what) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(e);
+        iodine_destroy(h);
+        return IODINE_ERR_HIP;
+    };
+#define ALLOC(ptr, n) do { hipError_t e_ = dev_alloc(h, &(ptr), (n)); if (e_ != hipSuccess) return bail(e_, "hipMalloc " #ptr); } while (0)
+    const int L = h->L, Cd = h->Cd, Cr = h->Cr, H = h->H;
+    ALLOC(h->lin, (size_t)h->S);
+    ALLOC(h->wcls, (size_t)9 * L * Cd);
+    ALLOC(h->wclsT, (size_t)9 * L * Cd);
+    ALLOC(h->cmap, (size_t)h->P * Cd);
+    h->dec_wf.assign(h->Dd, nullptr); h->dec_wb.assign(h->Dd, nullptr); h->dec_b.assign(h->Dd, nullptr);
+    for (int l = 1; l < h->Dd; ++l) {
+        ALLOC(h->dec_wf[l], conv_wpk_elems(Cd, Cd) * 4);
+        ALLOC(h->dec_wb[l], conv_wpk_elems(Cd, Cd) * 4);
+        ALLOC(h->dec_b[l], (size_t)Cd);
+    }
+    ALLOC(h->dec_out_w, (size_t)9 * Cd * 4);
+    ALLOC(h->dec_out_b, (size_t)4);
+    ALLOC(h->dec_out_wb, conv_wpk_elems(4, Cd) * 4);
+    h->ref_w.assign(h->Dr, nullptr); h->ref_b.assign(h->Dr, nullptr);
+    for (int l = 0; l < h->Dr; ++l) {
+        ALLOC(h->ref_w[l], conv_wpk_elems(l == 0 ? 20 : Cr, Cr) * 4);
+        ALLOC(h->ref_b[l], (size_t)Cr);
+    }
+    ALLOC(h->mlp_wT, (size_t)Cr * H); ALLOC(h->mlp_b, (size_t)H);
+    ALLOC(h->wihT, (size_t)(H + 4 * L) * 4 * H); ALLOC(h->whhT, (size_t)H * 4 * H); ALLOC(h->lstm_b, (size_t)4 * H);
+    ALLOC(h->wmT, (size_t)H * L); ALLOC(h->bm, (size_t)L); ALLOC(h->wvT, (size_t)H * L); ALLOC(h->bv, (size_t)L);
+    ALLOC(h->init_mean, (size_t)L); ALLOC(h->init_logvar, (size_t)L);
+#undef ALLOC
+    std::vector<float> lin(h->S);
+    iodine_linspace_host(h->S, lin.data());
+    hipError_t e = hipMemcpy(h->lin, lin.data(), sizeof(float) * h->S, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(e, "hipMemcpy linspace");
+    *out = h;
+    return IODINE_OK;
+}
+
+void iodine_destroy(iodine_handle* h)
+{
+    if (!h) return;
+    for (void* p : h->owned) (void)hipFree(p);
+    if (h->ws_own) (void)hipFree(h->ws_own);
+    delete h;
+}
+
+int iodine_num_params(const iodine_handle* h) { return h ? (int)h->params.size() : 0; }
+
+int iodine_param_info(const iodine_handle* h, int index, const char** name, int* ndim, long long dims[4])
+{
+    if (!h || index < 0 || index >= (int)h->params.size()) return IODINE_ERR_INVALID;
+    const ParamInfo& p = h->params[index];
+    if (name) *name = p.name.c_str();
+    if (ndim) *ndim = p.ndim;
+    if (dims) for (int i = 0; i < 4; ++i) dims[i] = p.dims[i];
+    return IODINE_OK;
+}
+
+int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, int n)
+{
+    if (!h) return IODINE_ERR_INVALID;
+    if (n != (int)h->params.size() || !dev) return h->fail(IODINE_ERR_INVALID, "iodine_set_params: wrong parameter count");
+    for (int i = 0; i < n; ++i)
+        if (!dev[i]) return h->fail(IODINE_ERR_INVALID, "iodine_set_params: null pointer for " + h->params[i].name);
+    hipStream_t st = (hipStream_t)stream;
+    auto P = [&](const std::string& name) { return dev[param_index(h, name)]; };
+    const int L = h->L, Cd = h->Cd, Cr = h->Cr, H = h->H;
+    // decoder
+    HIPCHK(h, launch_dec_l0_prepare(st, P("decoder.mlc.layers.0.weight"), P("decoder.mlc.layers.0.bias"), h->lin, Cd, L,
+                                    h->S, h->wcls, h->wclsT, h->cmap));
+    for (int l = 1; l < h->Dd; ++l) {
+        const float* w = P("decoder.mlc.layers." + std::to_string(l) + ".weight");
+        HIPCHK(h, launch_pack_conv_weights(st, w, Cd, Cd, Cd, Cd, 0, h->dec_wf[l]));
+        HIPCHK(h, launch_pack_conv_weights(st, w, Cd, Cd, Cd, Cd, 1, h->dec_wb[l]));
+        HIPCHK(h, hipMemcpyAsync(h->dec_b[l], P("decoder.mlc.layers." + std::to_string(l) + ".bias"), sizeof(float) * Cd,
+                                 hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(h, launch_pack_dec_out(st, P("decoder.conv.weight"), h->dec_out_w, Cd));
+    HIPCHK(h, hipMemcpyAsync(h->dec_out_b, P("decoder.conv.bias"), sizeof(float) * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, launch_pack_conv_weights(st, P("decoder.conv.weight"), 4, Cd, 4, Cd, 1, h->dec_out_wb));
+    // refinement conv stack
+    for (int l = 0; l < h->Dr; ++l) {
+        const float* w = P("refine.mlc.layers." + std::to_string(l) + ".weight");
+        HIPCHK(h, launch_pack_conv_weights(st, w, Cr, l == 0 ? 17 : Cr, l == 0 ? 20 : Cr, Cr, 0, h->ref_w[l]));
+        HIPCHK(h, hipMemcpyAsync(h->ref_b[l], P("refine.mlc.layers." + std::to_string(l) + ".bias"), sizeof(float) * Cr,
+                                 hipMemcpyDeviceToDevice, st));
+    }
+    // head
+    HIPCHK(h, launch_transpose(st, P("refine.mlp.layers.0.weight"), h->mlp_wT, H, Cr));
+    HIPCHK(h, hipMemcpyAsync(h->mlp_b, P("refine.mlp.layers.0.bias"), sizeof(float) * H, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, launch_transpose(st, P("refine.lstm.weight_ih"), h->wihT, 4 * H, H + 4 * L));
+    HIPCHK(h, launch_transpose(st, P("refine.lstm.weight_hh"), h->whhT, 4 * H, H));
+    HIPCHK(h, launch_add2(st, P("refine.lstm.bias_ih"), P("refine.lstm.bias_hh"), h->lstm_b, 4 * H));
+    HIPCHK(h, launch_transpose(st, P("refine.mean_update.weight"), h->wmT, L, H));
+    HIPCHK(h, launch_transpose(st, P("refine.logvar_update.weight"), h->wvT, L, H));
+    HIPCHK(h, hipMemcpyAsync(h->bm, P("refine.mean_update.bias"), sizeof(float) * L, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->bv, P("refine.logvar_update.bias"), sizeof(float) * L, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->init_mean, P("posterior.init_mean"), sizeof(float) * L, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->init_logvar, P("posterior.init_logvar"), sizeof(float) * L, hipMemcpyDeviceToDevice, st));
+    h->params_set = true;
+    return IODINE_OK;
+}
+
+size_t iodine_workspace_bytes(const iodine_handle* h, int batch, int mode)
+{
+    if (!h || batch < 1) return 0;
+    Arena q(nullptr); Buffers tmp; plan(h, batch, mode, q, tmp);
+    return tmp.bytes;
+}
+
+int iodine_set_workspace(iodine_handle* h, void* dev_ptr, size_t bytes)
+{
+    if (!h) return IODINE_ERR_INVALID;
+    if (((uintptr_t)dev_ptr & 255) != 0) return h->fail(IODINE_ERR_INVALID, "workspace must be 256-byte aligned");
+    h->ws_user = dev_ptr; h->ws_user_bytes = dev_ptr ? bytes : 0;
+    h->buf = Buffers();
+    return IODINE_OK;
+}
+
+int iodine_set_option(iodine_handle* h, const char* key, double value)
+{
+    if (!h || !key) return IODINE_ERR_INVALID;
+    if (!strcmp(key, "stop_after_iters")) { h->stop_after = (int)value; return IODINE_OK; }
+    return h->fail(IODINE_ERR_INVALID, std::string("unknown option ") + key);
+}
+
+int iodine_reconstruct(iodine_handle* h, void* stream, int batch, const float* x, const float* eps, float* pred,
+                       float* mask, float* mean, float* z, float* post_mean, float* post_logvar, float* elbo_iter)
+{
+    int rc = check_ready(h, batch);
+    if (rc) return rc;
+    if (!x || !eps) return h->fail(IODINE_ERR_INVALID, "iodine_reconstruct: x and eps are required");
+    rc = ensure_workspace(h, batch, 0);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    Buffers& b = h->buf;
+    const int B = batch, N = B * h->K, T = h->T;
+    const size_t eps_stride = (size_t)N * h->L;
+    HIPCHK(h, launch_x_to_nhwc4(st, x, b.x4, B, h->P));
+    HIPCHK(h, launch_posterior_init(st, h->init_mean, h->init_logvar, b.pm, b.plv, b.h[0], b.c[0], N, h->L, h->H));
+    const bool partial = h->stop_after >= 0 && h->stop_after <= T;     // debug: stop before the final sample/decode
+    const int n_it = partial ? h->stop_after : T;
+    for (int i = 0; i < n_it; ++i) {
+        rc = elbo_and_gradients(h, st, B, eps + (size_t)i * eps_stride, i, true);
+        if (rc) return rc;
+        rc = refine_step(h, st, B, i, false);
+        if (rc) return rc;
+    }
+    if (!partial) {
+        // z = posterior.sample(); decode(z)   (iodine.py:103,110)
+        HIPCHK(h, launch_dec_v(st, b.pm, b.plv, eps + (size_t)T * eps_stride, nullptr, h->wcls, b.z[T], b.V, N, h->L, h->Cd));
+        rc = decoder_forward(h, st, N);
+        if (rc) return rc;
+        HIPCHK(h, launch_final_out(st, b.dec_out, pred, mask, mean, B, h->K, h->P));
+        if (z) HIPCHK(h, hipMemcpyAsync(z, b.z[T], sizeof(float) * eps_stride, hipMemcpyDeviceToDevice, st));
+    }
+    if (post_mean) HIPCHK(h, hipMemcpyAsync(post_mean, b.pm, sizeof(float) * eps_stride, hipMemcpyDeviceToDevice, st));
+    if (post_logvar) HIPCHK(h, hipMemcpyAsync(post_logvar, b.plv, sizeof(float) * eps_stride, hipMemcpyDeviceToDevice, st));
+    if (elbo_iter) HIPCHK(h, hipMemcpyAsync(elbo_iter, b.scal, sizeof(float) * 3 * n_it, hipMemcpyDeviceToDevice, st));
+    return IODINE_OK;
+}
+
+int iodine_decode(iodine_handle* h, void* stream, int batch, const float* z, float* pred, float* mask, float* mean)
+{
+    int rc = check_ready(h, batch);
+    if (rc) return rc;
+    if (!z) return h->fail(IODINE_ERR_INVALID, "iodine_decode: z is required");
+    rc = ensure_workspace(h, batch, 0);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    Buffers& b = h->buf;
+    const int N = batch * h->K;
+    HIPCHK(h, launch_dec_v(st, nullptr, nullptr, nullptr, z, h->wcls, nullptr, b.V, N, h->L, h->Cd));
+    rc = decoder_forward(h, st, N);
+    if (rc) return rc;
+    HIPCHK(h, launch_final_out(st, b.dec_out, pred, mask, mean, batch, h->K, h->P));
+    return IODINE_OK;
+}
+
+int iodine_train_forward(iodine_handle* h, void*, int, const float*, const float*, float*, float*)
+{
+    if (!h) return IODINE_ERR_INVALID;
+    return h->fail(IODINE_ERR_STATE, "iodine_train_forward: not implemented in this build");
+}
+
+int iodine_train_backward(iodine_handle* h, void*, float, float* const*, int)
+{
+    if (!h) return IODINE_ERR_INVALID;
+    return h->fail(IODINE_ERR_STATE, "iodine_train_backward: not implemented in this build");
+}
+
+int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter, float* dst, size_t max_floats,
+                      size_t* n_floats)
+{
+    if (!h || !name) return IODINE_ERR_INVALID;
+    if (h->buf.bytes == 0) return h->fail(IODINE_ERR_STATE, "iodine_debug_copy: no workspace yet");
+    Buffers& b = h->buf;
+    const size_t N = (size_t)b.B * h->K, P = h->P, L = h->L;
+    if (iter < 0 || iter > h->T) return h->fail(IODINE_ERR_INVALID, "iodine_debug_copy: bad iteration index");
+    const std::string s(name);
+    const float* src = nullptr; size_t n = 0;
+    if (s == "z") { src = b.z[iter]; n = N * L; }
+    else if (s == "dec_out") { src = b.dec_out; n = N * P * 4; }
+    else if (s == "g") { src = b.g; n = N * P * 4; }
+    else if (s == "enc") { src = b.enc[iter]; n = N * P * 20; }
+    else if (s == "latent") { src = b.latent[iter]; n = N * 4 * L; }
+    else if (s == "g_pm") { src = b.g_pm[iter]; n = N * L; }
+    else if (s == "g_plv") { src = b.g_plv[iter]; n = N * L; }
+    else if (s == "lnstat") { src = b.lnstat; n = N * 8; }
+    else if (s == "Rc") { src = b.Rc; n = N * 9 * h->Cd; }
+    else if (s == "V") { src = b.V; n = N * 9 * h->Cd; }
+    else if (s == "h") { src = b.h[iter + 1]; n = N * h->H; }
+    else if (s == "c") { src = b.c[iter + 1]; n = N * h->H; }
+    else if (s == "pm") { src = b.pm; n = N * L; }
+    else if (s == "plv") { src = b.plv; n = N * L; }
+    else if (s == "scal") { src = b.scal; n = (size_t)(h->T + 1) * 3; }
+    else if (s == "img_terms") { src = b.img_terms; n = (size_t)(h->T + 1) * b.B * 2; }
+    else if (s.rfind("act", 0) == 0) {
+        const int l = atoi(s.c_str() + 3);
+        if (l < 0 || l >= h->Dd) return h->fail(IODINE_ERR_INVALID, "bad decoder layer");
+        src = b.act[l]; n = N * P * h->Cd;
+    } else if (s.rfind("ract", 0) == 0) {
+        const int l = atoi(s.c_str() + 4);
+        if (l < 0 || l >= h->Dr) return h->fail(IODINE_ERR_INVALID, "bad refinement layer");
+        int sz = h->S; for (int j = 0; j <= l; ++j) sz = ref_out_size(sz);
+        src = b.ract[iter][l]; n = N * sz * sz * h->Cr;
+    } else return h->fail(IODINE_ERR_INVALID, "iodine_debug_copy: unknown buffer " + s);
+    if (n_floats) *n_floats = n;
+    if (dst) {
+        if (n > max_floats) return h->fail(IODINE_ERR_INVALID, "iodine_debug_copy: destination too small");
+        HIPCHK(h, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return IODINE_OK;
+}
+
+void iodine_linspace_host(int n, float* out)
+{
+    // ATen's CPU linspace for float: step = (end - start) / (n - 1); first half counts up from start,
+    // second half counts down from end (symmetric), all in fp32.
+    const float start = -1.f, end = 1.f;
+    if (n == 1) { out[0] = start; return; }
+    const float step = (end - start) / (float)(n - 1);
+    const int halfway = n / 2;
+    for (int i = 0; i < n; ++i)
+        out[i] = i < halfway ? start + step * (float)i : end - step * (float)(n - i - 1);
+}
+
+// ---- operator-level test entry points ---------------------------------------------------------
+static std::string g_op_error;
+
+int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, const float* bias, const float* aux,
+                      float* out, int n, int ih, int iw, int w_o, int w_i, int cin_pad, int cout, int stride, int epi,
+                      int tflip)
+{
+    hipStream_t st = (hipStream_t)stream;
+    float* wpk = nullptr;
+    if (hipMalloc((void**)&wpk, conv_wpk_elems(cin_pad, cout) * 16) != hipSuccess) return IODINE_ERR_HIP;
+    hipError_t e = launch_pack_conv_weights(st, w, w_o, w_i, cin_pad, cout, tflip, wpk);
+    if (e == hipSuccess) {
+        if (mode == 0) e = (ih == iw && stride == 1) ? launch_conv3x3_tile(st, in, wpk, bias, aux, out, n, ih, cin_pad, cout, epi)
+                                                     : hipErrorInvalidValue;
+        else e = launch_conv3x3_gather(st, in, wpk, bias, out, n, ih, iw, cin_pad, cout, stride);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(wpk);
+    if (e != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3: ") + hipGetErrorString(e); return IODINE_ERR_HIP; }
+    return IODINE_OK;
+}
+
+int iodine_op_dec_out(void* stream, const float* in, const float* w, const float* bias, float* out, int n, int s, int c)
+{
+    hipStream_t st = (hipStream_t)stream;
+    float* wk = nullptr;
+    if (hipMalloc((void**)&wk, (size_t)9 * c * 4 * sizeof(float)) != hipSuccess) return IODINE_ERR_HIP;
+    hipError_t e = launch_pack_dec_out(st, w, wk, c);
+    if (e == hipSuccess) e = launch_dec_out(st, in, wk, bias, out, n, s, c);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(wk);
+    if (e != hipSuccess) { g_create_error = std::string("iodine_op_dec_out: ") + hipGetErrorString(e); return IODINE_ERR_HIP; }
+    return IODINE_OK;
+}
+
+}  // extern "C"

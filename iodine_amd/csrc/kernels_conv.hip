@@ -1,0 +1,346 @@
+// 3x3 convolution kernels for the IODINE decoder / refinement stacks on gfx950.
+//
+// Replaces the reference's nn.Conv2d call sites (lib/modeling/iodine.py:422,435,583,592 and
+// their autograd backward) with fp32 MFMA implicit-GEMM kernels over NHWC activations:
+//   M = output pixels, N = output channels, K = 9 taps x input channels.
+// v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain, so results differ from the CPU path only
+// by summation order.
+#include "common.h"
+
+// =========================================================================================
+// weight packer: OIHW (or its dgrad transform) -> wpk[chunk][quad][co] float4
+// =========================================================================================
+__global__ void pack_conv_weights_kernel(const float* __restrict__ src, int O, int I, int cin_pad,
+                                         int cout, int tflip, float* __restrict__ dst)
+{
+    const int cc = conv_cc(cin_pad), qpt = cc / 4, nq = 9 * qpt, nqp = (nq + 1) & ~1;
+    const size_t total = (size_t)(cin_pad / cc) * nqp * cout * 4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 3;
+        size_t r = idx >> 2;
+        const int co = r % cout; r /= cout;
+        const int q = r % nqp;
+        const int chunk = r / nqp;
+        const int tap = q / qpt, cig = q % qpt;
+        const int ci = chunk * cc + cig * 4 + e;
+        float v = 0.f;
+        if (q < nq) {
+            if (!tflip) {                       // forward: conv-in = I axis, conv-out = O axis
+                if (ci < I && co < O) v = src[((size_t)co * I + ci) * 9 + tap];
+            } else {                            // dgrad: conv-in = O axis, conv-out = I axis, taps flipped
+                if (ci < O && co < I) v = src[((size_t)ci * I + co) * 9 + (8 - tap)];
+            }
+        }
+        dst[idx] = v;
+    }
+}
+
+hipError_t launch_pack_conv_weights(hipStream_t st, const float* src, int O, int I, int cin_pad, int cout,
+                                    int tflip, float* dst)
+{
+    const size_t total = conv_wpk_elems(cin_pad, cout) * 4;
+    const int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(pack_conv_weights_kernel, dim3(blocks), dim3(256), 0, st, src, O, I, cin_pad, cout,
+                       tflip, dst);
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// LDS-tiled stride-1 3x3 conv, pad 1 (decoder layers, and their dgrad with transformed weights)
+//   block = 256 threads (4 waves), output tile 16x16 pixels x COUT channels
+//   wave w owns tile rows 4w..4w+3: two 32-pixel MFMA row-blocks (2 rows x 16 cols each)
+//   per channel chunk: stage (18x18 halo) x CC input channels + the chunk's packed weights in LDS
+// =========================================================================================
+template <int CIN, int COUT, int EPI>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_tile_kernel(const float* __restrict__ in, const float4* __restrict__ wpk,
+                         const float* __restrict__ bias, const float* __restrict__ aux,
+                         float* __restrict__ out, int S, int tiles)
+{
+    constexpr int CC = conv_cc(CIN);
+    constexpr int NCHUNK = CIN / CC;
+    constexpr int QPT = CC / 4;
+    constexpr int NQ = 9 * QPT;
+    constexpr int NQP = (NQ + 1) & ~1;
+    constexpr int NPAIR = NQP / 2;
+    constexpr int CP = (CC == 4) ? 4 : CC + 4;       // LDS pixel stride in floats (bank spread)
+    constexpr int NT = COUT / 32;
+    constexpr int HALO = 18;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;
+    float4* s_w = reinterpret_cast<float4*>(smem + HALO * HALO * CP);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, li = lane & 31;
+    const int prow = li >> 4, pcol = li & 15;
+
+    int bid = blockIdx.x;
+    const int tx = bid % tiles; bid /= tiles;
+    const int ty = bid % tiles;
+    const int n = bid / tiles;
+    const int y0 = ty * 16 - 1, x0 = tx * 16 - 1;
+    const float* in_n = in + (size_t)n * S * S * CIN;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+        if (chunk > 0) __syncthreads();
+        // ---- stage the input halo tile for this channel chunk ----
+        for (int idx = tid; idx < HALO * HALO * QPT; idx += 256) {
+            const int px = idx / QPT, cq = idx % QPT;
+            const int hy = px / HALO, hx = px % HALO;
+            const int gy = y0 + hy, gx = x0 + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < S && gx >= 0 && gx < S)
+                v = *reinterpret_cast<const float4*>(in_n + ((size_t)gy * S + gx) * CIN + chunk * CC + cq * 4);
+            *reinterpret_cast<float4*>(s_in + px * CP + cq * 4) = v;
+        }
+        // ---- stage this chunk's packed weights ----
+        const float4* wsrc = wpk + (size_t)chunk * NQP * COUT;
+        for (int idx = tid; idx < NQP * COUT; idx += 256) s_w[idx] = wsrc[idx];
+        __syncthreads();
+
+#pragma unroll
+        for (int g = 0; g < NPAIR; ++g) {
+            const int q = 2 * g + half;
+            const int qa = q < NQ ? q : NQ - 1;          // padded quad: weights are zero, read any valid pixel
+            const int tap = qa / QPT, cig = qa % QPT;
+            const int dy = tap / 3, dx = tap % 3;
+            float4 a[2], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int hy = 4 * wv + 2 * mt + prow + dy, hx = pcol + dx;
+                a[mt] = *reinterpret_cast<const float4*>(s_in + (hy * HALO + hx) * CP + cig * 4);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = s_w[q * COUT + nt * 32 + li];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue: D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel) ----
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = nt * 32 + li;
+            float bv = 0.f;
+            if (EPI == EPI_BIAS_ELU) bv = bias[co];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;        // 0..31 inside the row-block
+                const int gy = ty * 16 + 4 * wv + 2 * mt + (m >> 4);
+                const int gx = tx * 16 + (m & 15);
+                const size_t o = (((size_t)n * S + gy) * S + gx) * COUT + co;
+                float v = acc[mt][nt][r];
+                if (EPI == EPI_BIAS_ELU) v = elu1(v + bv);
+                else if (EPI == EPI_MUL_ELUGRAD) v *= elu1_grad_from_out(aux[o]);
+                out[o] = v;
+            }
+        }
+}
+
+template <int CIN, int COUT, int EPI>
+static hipError_t launch_tile_inst(hipStream_t st, const float* in, const float* wpk, const float* bias,
+                                   const float* aux, float* out, int N, int S)
+{
+    constexpr int CC = conv_cc(CIN);
+    constexpr int CP = (CC == 4) ? 4 : CC + 4;
+    constexpr size_t lds = (size_t)(18 * 18 * CP) * 4 + (size_t)conv_nqp(CIN) * COUT * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_tile_kernel<CIN, COUT, EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles = S / 16;
+    hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, COUT, EPI>), dim3(N * tiles * tiles), dim3(256), lds, st, in,
+                       reinterpret_cast<const float4*>(wpk), bias, aux, out, S, tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_tile(hipStream_t st, const float* in, const float* wpk, const float* bias,
+                               const float* aux, float* out, int N, int S, int cin, int cout, int epi)
+{
+    if (S % 16 != 0) return hipErrorInvalidValue;
+#define TILE_CASE(CI, CO, EP) \
+    if (cin == CI && cout == CO && epi == EP) return launch_tile_inst<CI, CO, EP>(st, in, wpk, bias, aux, out, N, S);
+    TILE_CASE(64, 64, EPI_BIAS_ELU) TILE_CASE(64, 64, EPI_MUL_ELUGRAD)
+    TILE_CASE(32, 32, EPI_BIAS_ELU) TILE_CASE(32, 32, EPI_MUL_ELUGRAD)
+    TILE_CASE(4, 64, EPI_MUL_ELUGRAD) TILE_CASE(4, 32, EPI_MUL_ELUGRAD)
+#undef TILE_CASE
+    return hipErrorInvalidValue;
+}
+
+// =========================================================================================
+// gather-style 3x3 conv with stride (refinement network, lib/modeling/iodine.py:459,480,583):
+//   M = linear output pixel index over the whole slot batch, A operand gathered straight from
+//   global memory (L1/L2 absorb the 9/stride^2 re-reads), weights chunk-staged in LDS.
+//   block = 256 threads, 4 waves x 32 output pixels; epilogue bias + ELU.
+// =========================================================================================
+template <int CIN, int COUT, int STRIDE>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_gather_kernel(const float* __restrict__ in, const float4* __restrict__ wpk,
+                           const float* __restrict__ bias, float* __restrict__ out,
+                           int M, int IH, int IW, int OH, int OW)
+{
+    constexpr int CC = conv_cc(CIN);
+    constexpr int NCHUNK = CIN / CC;
+    constexpr int QPT = CC / 4;
+    constexpr int NQ = 9 * QPT;
+    constexpr int NQP = (NQ + 1) & ~1;
+    constexpr int NPAIR = NQP / 2;
+    constexpr int NT = COUT / 32;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4* s_w = reinterpret_cast<float4*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, li = lane & 31;
+    const int m = blockIdx.x * 128 + wv * 32 + li;
+    const bool mvalid = m < M;
+    int t = mvalid ? m : 0;
+    const int ox = t % OW; t /= OW;
+    const int oy = t % OH;
+    const int n = t / OH;
+    const float* in_n = in + (size_t)n * IH * IW * CIN;
+    const int iy0 = oy * STRIDE - 1, ix0 = ox * STRIDE - 1;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+        if (chunk > 0) __syncthreads();
+        const float4* wsrc = wpk + (size_t)chunk * NQP * COUT;
+        for (int idx = tid; idx < NQP * COUT; idx += 256) s_w[idx] = wsrc[idx];
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < NPAIR; ++g) {
+            const int q = 2 * g + half;
+            const int qa = q < NQ ? q : NQ - 1;
+            const int tap = qa / QPT, cig = qa % QPT;
+            const int iy = iy0 + tap / 3, ix = ix0 + tap % 3;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mvalid && q < NQ && iy >= 0 && iy < IH && ix >= 0 && ix < IW)
+                a = *reinterpret_cast<const float4*>(in_n + ((size_t)iy * IW + ix) * CIN + chunk * CC + cig * 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 b = s_w[q * COUT + nt * 32 + li];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 32 + li;
+        const float bv = bias[co];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mm = blockIdx.x * 128 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (mm < M) out[(size_t)mm * COUT + co] = elu1(acc[nt][r] + bv);
+        }
+    }
+}
+
+template <int CIN, int COUT, int STRIDE>
+static hipError_t launch_gather_inst(hipStream_t st, const float* in, const float* wpk, const float* bias,
+                                     float* out, int N, int IH, int IW)
+{
+    constexpr size_t lds = (size_t)conv_nqp(CIN) * COUT * 16;
+    const int OH = (IH + 2 - 3) / STRIDE + 1, OW = (IW + 2 - 3) / STRIDE + 1;
+    const int M = N * OH * OW;
+    hipLaunchKernelGGL((conv3x3_gather_kernel<CIN, COUT, STRIDE>), dim3((M + 127) / 128), dim3(256), lds, st, in,
+                       reinterpret_cast<const float4*>(wpk), bias, out, M, IH, IW, OH, OW);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_gather(hipStream_t st, const float* in, const float* wpk, const float* bias,
+                                 float* out, int N, int IH, int IW, int cin, int cout, int stride)
+{
+#define G_CASE(CI, CO, SD) \
+    if (cin == CI && cout == CO && stride == SD) return launch_gather_inst<CI, CO, SD>(st, in, wpk, bias, out, N, IH, IW);
+    G_CASE(20, 64, 2) G_CASE(64, 64, 2) G_CASE(20, 32, 2) G_CASE(32, 32, 2)
+#undef G_CASE
+    return hipErrorInvalidValue;
+}
+
+// =========================================================================================
+// decoder output conv C -> 4 (rgb pre-sigmoid x3, mask logit), lib/modeling/iodine.py:422,435.
+// N=4 would waste 7/8 of a 32-wide MFMA tile, so this one is a VALU kernel: one thread per
+// output pixel, weights wave-uniform from LDS (broadcast reads), input straight from L1/L2.
+//   wk layout: [tap][ci][4]
+// =========================================================================================
+template <int C>
+__global__ __launch_bounds__(256)
+void dec_out_kernel(const float* __restrict__ in, const float4* __restrict__ wk, const float* __restrict__ bias,
+                    float4* __restrict__ out, int S, int tiles)
+{
+    __shared__ float4 s_w[9 * C];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 9 * C; i += 256) s_w[i] = wk[i];
+    __syncthreads();
+    int bid = blockIdx.x;
+    const int tx = bid % tiles; bid /= tiles;
+    const int ty = bid % tiles;
+    const int n = bid / tiles;
+    const int y = ty * 16 + (tid >> 4), x = tx * 16 + (tid & 15);
+    const float* in_n = in + (size_t)n * S * S * C;
+    float4 acc = make_float4(bias[0], bias[1], bias[2], bias[3]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+        if (iy < 0 || iy >= S || ix < 0 || ix >= S) continue;
+        const float4* p = reinterpret_cast<const float4*>(in_n + ((size_t)iy * S + ix) * C);
+#pragma unroll 4
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+            const float4 v = p[c4];
+            const float4 w0 = s_w[tap * C + c4 * 4 + 0], w1 = s_w[tap * C + c4 * 4 + 1];
+            const float4 w2 = s_w[tap * C + c4 * 4 + 2], w3 = s_w[tap * C + c4 * 4 + 3];
+            acc.x = fmaf(v.x, w0.x, acc.x); acc.y = fmaf(v.x, w0.y, acc.y); acc.z = fmaf(v.x, w0.z, acc.z); acc.w = fmaf(v.x, w0.w, acc.w);
+            acc.x = fmaf(v.y, w1.x, acc.x); acc.y = fmaf(v.y, w1.y, acc.y); acc.z = fmaf(v.y, w1.z, acc.z); acc.w = fmaf(v.y, w1.w, acc.w);
+            acc.x = fmaf(v.z, w2.x, acc.x); acc.y = fmaf(v.z, w2.y, acc.y); acc.z = fmaf(v.z, w2.z, acc.z); acc.w = fmaf(v.z, w2.w, acc.w);
+            acc.x = fmaf(v.w, w3.x, acc.x); acc.y = fmaf(v.w, w3.y, acc.y); acc.z = fmaf(v.w, w3.z, acc.z); acc.w = fmaf(v.w, w3.w, acc.w);
+        }
+    }
+    out[((size_t)n * S + y) * S + x] = acc;
+}
+
+hipError_t launch_dec_out(hipStream_t st, const float* in, const float* wk, const float* bias, float* out,
+                          int N, int S, int C)
+{
+    if (S % 16 != 0) return hipErrorInvalidValue;
+    const int tiles = S / 16;
+    if (C == 64)
+        hipLaunchKernelGGL((dec_out_kernel<64>), dim3(N * tiles * tiles), dim3(256), 0, st, in,
+                           reinterpret_cast<const float4*>(wk), bias, reinterpret_cast<float4*>(out), S, tiles);
+    else if (C == 32)
+        hipLaunchKernelGGL((dec_out_kernel<32>), dim3(N * tiles * tiles), dim3(256), 0, st, in,
+                           reinterpret_cast<const float4*>(wk), bias, reinterpret_cast<float4*>(out), S, tiles);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}

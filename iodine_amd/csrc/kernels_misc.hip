@@ -1,0 +1,479 @@
+// Small kernels around the conv stacks: spatial-broadcast first decoder layer and its backward
+// reductions, posterior sampling / KL / ELBO, latent layer-norm, refinement head (avg-pool, MLP,
+// LSTM cell, posterior update).  All are HBM- or latency-bound; none is GEMM-shaped enough for MFMA
+// at the slot-batch sizes involved (N = B*K rows).
+#include "common.h"
+
+// -----------------------------------------------------------------------------------------------
+// layout conversion: images NCHW (B,3,P) -> (B,P) float4 {r,g,b,0}
+// -----------------------------------------------------------------------------------------------
+__global__ void x_to_nhwc4_kernel(const float* __restrict__ x, float4* __restrict__ x4, int B, int P)
+{
+    const size_t total = (size_t)B * P;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / P, p = i % P;
+        const float* xb = x + b * 3 * P;
+        x4[i] = make_float4(xb[p], xb[P + p], xb[2 * (size_t)P + p], 0.f);
+    }
+}
+
+hipError_t launch_x_to_nhwc4(hipStream_t st, const float* x, float* x4, int B, int P)
+{
+    const int blocks = (int)std::min<size_t>(((size_t)B * P + 255) / 256, 4096);
+    hipLaunchKernelGGL(x_to_nhwc4_kernel, dim3(blocks), dim3(256), 0, st, x, (float4*)x4, B, P);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------
+// Gaussian.init_unit (lib/modeling/iodine.py:607-618): lambda = learned init, LSTM state = 0
+// -----------------------------------------------------------------------------------------------
+__global__ void posterior_init_kernel(const float* __restrict__ init_mean, const float* __restrict__ init_logvar,
+                                      float* __restrict__ pm, float* __restrict__ plv, float* __restrict__ h,
+                                      float* __restrict__ c, int N, int L, int H)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * L) { pm[i] = init_mean[i % L]; plv[i] = init_logvar[i % L]; }
+    if (i < N * H) { h[i] = 0.f; c[i] = 0.f; }
+}
+
+hipError_t launch_posterior_init(hipStream_t st, const float* im, const float* ilv, float* pm, float* plv, float* h,
+                                 float* c, int N, int L, int H)
+{
+    const int tot = N * (L > H ? L : H);
+    hipLaunchKernelGGL(posterior_init_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, im, ilv, pm, plv, h, c, N, L, H);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------
+// Decoder layer 0 (SpatialBroadcast + first conv, iodine.py:512-540,583,592) without materialising
+// the (N, L+2, S, S) broadcast: z is spatially constant, so
+//     a0[n,p,co] = ELU( V[n, cls(p), co] + Cmap[p, co] ),  V = z . Wcls  (9 border classes),
+//     Wcls[cls][ci][co] = sum over the taps that stay inside the image for that class of W[co][ci][tap]
+//     Cmap[p][co] = bias[co] + conv(coordinate planes)[p][co]   (depends on the weights only).
+// -----------------------------------------------------------------------------------------------
+IOD_DEVINL bool tap_valid_for_class(int cls3, int d) { return !((cls3 == 0 && d == 0) || (cls3 == 2 && d == 2)); }
+
+__global__ void dec_l0_prepare_kernel(const float* __restrict__ w /*[C][L+2][3][3]*/, const float* __restrict__ bias,
+                                      const float* __restrict__ lin, int C, int L, int S,
+                                      float* __restrict__ wcls /*[9][L][C]*/, float* __restrict__ wclsT /*[9][C][L]*/,
+                                      float* __restrict__ cmap /*[P][C]*/)
+{
+    const int I = L + 2;
+    const size_t n_w = (size_t)9 * L * C, n_c = (size_t)S * S * C;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_w + n_c;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        if (idx < n_w) {
+            const int co = idx % C, ci = (idx / C) % L, cls = idx / ((size_t)C * L);
+            const int rc = cls / 3, cc = cls % 3;
+            float s = 0.f;
+            for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx)
+                    if (tap_valid_for_class(rc, dy) && tap_valid_for_class(cc, dx))
+                        s += w[((size_t)co * I + ci) * 9 + dy * 3 + dx];
+            wcls[idx] = s;
+            wclsT[((size_t)cls * C + co) * L + ci] = s;
+        } else {
+            const size_t j = idx - n_w;
+            const int co = j % C, p = j / C;
+            const int y = p / S, x = p % S;
+            float s = bias[co];
+            for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int yy = y + dy - 1, xx = x + dx - 1;
+                    if (yy < 0 || yy >= S || xx < 0 || xx >= S) continue;
+                    s += lin[xx] * w[((size_t)co * I + L) * 9 + dy * 3 + dx];        // channel L   = x coordinate
+                    s += lin[yy] * w[((size_t)co * I + L + 1) * 9 + dy * 3 + dx];    // channel L+1 = y coordinate
+                }
+            cmap[j] = s;
+        }
+    }
+}
+
+hipError_t launch_dec_l0_prepare(hipStream_t st, const float* w, const float* bias, const float* lin, int C, int L,
+                                 int S, float* wcls, float* wclsT, float* cmap)
+{
+    hipLaunchKernelGGL(dec_l0_prepare_kernel, dim3(1024), dim3(256), 0, st, w, bias, lin, C, L, S, wcls, wclsT, cmap);
+    return hipGetLastError();
+}
+
+// z = mean + exp(logvar/2) * eps (Gaussian.sample, iodine.py:620-634), then V = z . Wcls.  One block per slot.
+__global__ __launch_bounds__(256)
+void dec_v_kernel(const float* __restrict__ pm, const float* __restrict__ plv, const float* __restrict__ eps,
+                  const float* __restrict__ z_in, const float* __restrict__ wcls, float* __restrict__ z_out,
+                  float* __restrict__ V, int L, int C)
+{
+    extern __shared__ float s_z[];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int l = tid; l < L; l += 256) {
+        float z;
+        if (z_in) z = z_in[(size_t)n * L + l];
+        else z = pm[(size_t)n * L + l] + expf(0.5f * plv[(size_t)n * L + l]) * eps[(size_t)n * L + l];
+        s_z[l] = z;
+        if (z_out) z_out[(size_t)n * L + l] = z;
+    }
+    __syncthreads();
+    for (int o = tid; o < 9 * C; o += 256) {
+        const int cls = o / C, co = o % C;
+        const float* w = wcls + (size_t)cls * L * C + co;
+        float s = 0.f;
+        for (int ci = 0; ci < L; ++ci) s = fmaf(s_z[ci], w[(size_t)ci * C], s);
+        V[(size_t)n * 9 * C + o] = s;
+    }
+}
+
+hipError_t launch_dec_v(hipStream_t st, const float* pm, const float* plv, const float* eps, const float* z_in,
+                        const float* wcls, float* z_out, float* V, int N, int L, int C)
+{
+    hipLaunchKernelGGL(dec_v_kernel, dim3(N), dim3(256), L * sizeof(float), st, pm, plv, eps, z_in, wcls, z_out, V, L, C);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256)
+void dec_l0_kernel(const float4* __restrict__ V, const float4* __restrict__ cmap, float4* __restrict__ out,
+                   int S, int C4, size_t total)
+{
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = idx % C4;
+        const size_t r = idx / C4;
+        const int p = r % ((size_t)S * S);
+        const size_t n = r / ((size_t)S * S);
+        const int y = p / S, x = p % S;
+        const int cls = (y == 0 ? 0 : (y == S - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x == S - 1 ? 2 : 1));
+        const float4 v = V[(n * 9 + cls) * C4 + c4];
+        const float4 m = cmap[(size_t)p * C4 + c4];
+        out[idx] = make_float4(elu1(v.x + m.x), elu1(v.y + m.y), elu1(v.z + m.z), elu1(v.w + m.w));
+    }
+}
+
+hipError_t launch_dec_l0(hipStream_t st, const float* V, const float* cmap, float* out, int N, int S, int C)
+{
+    const size_t total = (size_t)N * S * S * (C / 4);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(dec_l0_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)V, (const float4*)cmap,
+                       (float4*)out, S, C / 4, total);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------
+// Backward of decoder layer 0 wrt z: class sums of dpre0 over pixels.
+//   stage 1: one block per (n, row): left / interior / right column sums   -> rows[n][y][3][C]
+//   stage 2: one block per n: top / middle / bottom over rows              -> Rc[n][9][C]
+// -----------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256)
+void l0_reduce_rows_kernel(const float4* __restrict__ dpre, float4* __restrict__ rows, int S)
+{
+    constexpr int C4 = C / 4, PL = 256 / C4;            // float4 lanes per pixel, pixel lanes
+    const int y = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int c4 = tid % C4, pl = tid / C4;
+    const float4* src = dpre + ((size_t)n * S + y) * S * C4;
+    float4 mid = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int x = 1 + pl; x < S - 1; x += PL) {
+        const float4 v = src[(size_t)x * C4 + c4];
+        mid.x += v.x; mid.y += v.y; mid.z += v.z; mid.w += v.w;
+    }
+    __shared__ float4 s_red[256];
+    s_red[tid] = mid;
+    __syncthreads();
+    for (int s = PL / 2; s > 0; s >>= 1) {
+        if (pl < s) {
+            float4 a = s_red[tid], b = s_red[tid + s * C4];
+            s_red[tid] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        }
+        __syncthreads();
+    }
+    if (tid < C4) {
+        float4* o = rows + ((size_t)n * S + y) * 3 * C4;
+        o[0 * C4 + tid] = src[tid];                              // x = 0
+        o[1 * C4 + tid] = s_red[tid];                            // 1 .. S-2
+        o[2 * C4 + tid] = src[(size_t)(S - 1) * C4 + tid];       // x = S-1
+    }
+}
+
+__global__ void l0_reduce_cls_kernel(const float* __restrict__ rows, float* __restrict__ Rc, int S, int C)
+{
+    const int n = blockIdx.x;
+    for (int t = threadIdx.x; t < 3 * C; t += blockDim.x) {      // t = cc*C + co
+        const float* src = rows + (size_t)n * S * 3 * C + t;
+        float mid = 0.f;
+        for (int y = 1; y < S - 1; ++y) mid += src[(size_t)y * 3 * C];
+        float* o = Rc + (size_t)n * 9 * C;
+        const int cc = t / C, co = t % C;
+        o[(0 * 3 + cc) * C + co] = src[0];
+        o[(1 * 3 + cc) * C + co] = mid;
+        o[(2 * 3 + cc) * C + co] = src[(size_t)(S - 1) * 3 * C];
+    }
+}
+
+hipError_t launch_l0_reduce(hipStream_t st, const float* dpre, float* rows, float* Rc, int N, int S, int C)
+{
+    if (C == 64)
+        hipLaunchKernelGGL((l0_reduce_rows_kernel<64>), dim3(S, N), dim3(256), 0, st, (const float4*)dpre, (float4*)rows, S);
+    else if (C == 32)
+        hipLaunchKernelGGL((l0_reduce_rows_kernel<32>), dim3(S, N), dim3(256), 0, st, (const float4*)dpre, (float4*)rows, S);
+    else
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(l0_reduce_cls_kernel, dim3(N), dim3(192), 0, st, rows, Rc, S, C);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------
+// dz = Rc . Wcls^T, posterior gradients and the refinement "latent" vector
+//   g_mean   = dz - mean
+//   g_logvar = dz * 0.5 * exp(logvar/2) * eps - 0.5 * (exp(logvar) - 1)
+//   latent   = [mean | logvar | LN(g_mean) | LN(g_logvar)]   (iodine.py:253-275; 3-D layernorm :382-384,394)
+// One block (L threads rounded up to a wave multiple) per slot.
+// -----------------------------------------------------------------------------------------------
+IOD_DEVINL float block_sum_f(float v, float* s_buf, int tid, int nthreads)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) s_buf[tid >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (nthreads + 63) / 64; ++w) t += s_buf[w];
+    return t;
+}
+
+__global__ void dz_latent_kernel(const float* __restrict__ Rc, const float* __restrict__ wclsT /*[9][C][L]*/,
+                                 const float* __restrict__ pm, const float* __restrict__ plv,
+                                 const float* __restrict__ eps, int L, int C, int use_ln,
+                                 float* __restrict__ g_pm, float* __restrict__ g_plv, float* __restrict__ latent)
+{
+    extern __shared__ float s_rc[];                     // 9*C
+    __shared__ float s_buf[8];
+    const int n = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    for (int i = tid; i < 9 * C; i += nth) s_rc[i] = Rc[(size_t)n * 9 * C + i];
+    __syncthreads();
+    const bool act = tid < L;
+    float gm = 0.f, gl = 0.f, mu = 0.f, lv = 0.f;
+    if (act) {
+        float dz = 0.f;
+        for (int j = 0; j < 9 * C; ++j) dz = fmaf(s_rc[j], wclsT[(size_t)j * L + tid], dz);
+        mu = pm[(size_t)n * L + tid]; lv = plv[(size_t)n * L + tid];
+        const float e = eps[(size_t)n * L + tid];
+        gm = dz - mu;
+        gl = dz * 0.5f * expf(0.5f * lv) * e - 0.5f * (expf(lv) - 1.f);
+        g_pm[(size_t)n * L + tid] = gm;
+        g_plv[(size_t)n * L + tid] = gl;
+    }
+    float nm = gm, nl = gl;
+    if (use_ln) {
+        const float m1 = block_sum_f(act ? gm : 0.f, s_buf, tid, nth) / L;
+        const float m2 = block_sum_f(act ? gl : 0.f, s_buf, tid, nth) / L;
+        const float d1 = act ? gm - m1 : 0.f, d2 = act ? gl - m2 : 0.f;
+        const float v1 = block_sum_f(d1 * d1, s_buf, tid, nth) / (L - 1);      // torch.std: unbiased
+        const float v2 = block_sum_f(d2 * d2, s_buf, tid, nth) / (L - 1);
+        nm = d1 / (sqrtf(v1) + 1e-5f);
+        nl = d2 / (sqrtf(v2) + 1e-5f);
+    }
+    if (act) {
+        float* o = latent + (size_t)n * 4 * L;
+        o[tid] = mu; o[L + tid] = lv; o[2 * L + tid] = nm; o[3 * L + tid] = nl;
+    }
+}
+
+hipError_t launch_dz_latent(hipStream_t st, const float* Rc, const float* wclsT, const float* pm, const float* plv,
+                            const float* eps, int N, int L, int C, int use_ln, float* g_pm, float* g_plv, float* latent)
+{
+    const int nth = ((L + 63) / 64) * 64;
+    hipLaunchKernelGGL(dz_latent_kernel, dim3(N), dim3(nth), 9 * C * sizeof(float), st, Rc, wclsT, pm, plv, eps, L, C,
+                       use_ln, g_pm, g_plv, latent);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------
+// KL against N(0,1) (iodine.py:653-659,191-193) + ELBO assembly.  One block per image; a second
+// single-block kernel forms the batch means in fixed order.
+//   img_terms[b] = {ll_b, kl_b};  scal = {elbo, kl, ll} (means over the B local images)
+// -----------------------------------------------------------------------------------------------
+__global__ void kl_image_kernel(const float* __restrict__ pm, const float* __restrict__ plv,
+                                const float* __restrict__ ll_img, int KL_, float* __restrict__ img_terms)
+{
+    __shared__ float s_buf[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float s = 0.f;
+    for (int i = tid; i < KL_; i += blockDim.x) {
+        const float mu = pm[(size_t)b * KL_ + i], lv = plv[(size_t)b * KL_ + i];
+        s += 0.5f * (expf(lv) + mu * mu - 1.f - lv);
+    }
+    const float kl = block_sum_f(s, s_buf, tid, blockDim.x);
+    if (tid == 0) { img_terms[2 * b] = ll_img[b]; img_terms[2 * b + 1] = kl; }
+}
+
+__global__ void elbo_mean_kernel(const float* __restrict__ img_terms, int B, float* __restrict__ scal)
+{
+    if (threadIdx.x == 0) {
+        double ll = 0.0, kl = 0.0;
+        for (int b = 0; b < B; ++b) { ll += img_terms[2 * b]; kl += img_terms[2 * b + 1]; }
+        ll /= B; kl /= B;
+        scal[0] = (float)(ll - kl); scal[1] = (float)kl; scal[2] = (float)ll;
+    }
+}
+
+hipError_t launch_elbo(hipStream_t st, const float* pm, const float* plv, const float* ll_img, int B, int K, int L,
+                       float* img_terms, float* scal)
+{
+    hipLaunchKernelGGL(kl_image_kernel, dim3(B), dim3(256), 0, st, pm, plv, ll_img, K * L, img_terms);
+    hipLaunchKernelGGL(elbo_mean_kernel, dim3(1), dim3(64), 0, st, img_terms, B, scal);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------
+// Refinement head (RefinementNetwork.forward after the conv stack, iodine.py:481-503):
+//   avg-pool -> Linear(C->H) -> ELU(ELU(.)) -> [u | latent] -> LSTMCell -> updates read from the CELL state c1
+//   (the reference's `(c, h) = lstm(...)` names h1 "c" and c1 "h") -> lambda += delta (iodine.py:642-643).
+// One block per slot; weights pre-transposed to [in][out] so lane j streams column j coalesced.
+//   saved (training): pooled[n][C], u[n][H], gates[n][4H] (post-activation i,f,g,o), c_prev copy not needed
+//   (state buffers are per-iteration in training mode).
+// -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, int C, int H, int L,
+                        const float* __restrict__ mlp_wT /*[C][H]*/, const float* __restrict__ mlp_b,
+                        const float* __restrict__ wihT /*[H+4L][4H]*/, const float* __restrict__ whhT /*[H][4H]*/,
+                        const float* __restrict__ lstm_b /*[4H] = b_ih + b_hh*/,
+                        const float* __restrict__ wmT /*[H][L]*/, const float* __restrict__ bm,
+                        const float* __restrict__ wvT /*[H][L]*/, const float* __restrict__ bv,
+                        const float* __restrict__ latent /*[N][4L]*/,
+                        const float* __restrict__ h_prev, const float* __restrict__ c_prev,
+                        float* __restrict__ h_out, float* __restrict__ c_out,
+                        float* __restrict__ pm, float* __restrict__ plv,
+                        float* __restrict__ sv_pooled, float* __restrict__ sv_u, float* __restrict__ sv_gates,
+                        float* __restrict__ d_mean_out, float* __restrict__ d_logvar_out)
+{
+    extern __shared__ float sm[];
+    float* s_pool = sm;                 // C
+    float* s_x = s_pool + C;            // H + 4L
+    float* s_h = s_x + H + 4 * L;       // H   (h_prev)
+    float* s_c = s_h + H;               // H   (c1)
+    float* s_red = s_c + H;             // 256
+    const int n = blockIdx.x, tid = threadIdx.x;
+
+    // global average pool over the PL pixels of the last conv layer (F.adaptive_avg_pool2d, iodine.py:481)
+    {
+        const int c = tid % C, g = tid / C, G = 256 / C;
+        float s = 0.f;
+        for (int p = g; p < PL; p += G) s += feat[((size_t)n * PL + p) * C + c];
+        s_red[tid] = s;
+        __syncthreads();
+        if (tid < C) {
+            float t = 0.f;
+            for (int j = 0; j < G; ++j) t += s_red[j * C + tid];
+            t /= (float)PL;
+            s_pool[tid] = t;
+            if (sv_pooled) sv_pooled[(size_t)n * C + tid] = t;
+        }
+        __syncthreads();
+    }
+    // MLP + double ELU
+    for (int j = tid; j < H; j += 256) {
+        float s = mlp_b[j];
+        for (int c = 0; c < C; ++c) s = fmaf(s_pool[c], mlp_wT[(size_t)c * H + j], s);
+        const float u = elu1(elu1(s));
+        s_x[j] = u;
+        if (sv_u) sv_u[(size_t)n * H + j] = u;
+        s_h[j] = h_prev[(size_t)n * H + j];
+    }
+    for (int j = tid; j < 4 * L; j += 256) s_x[H + j] = latent[(size_t)n * 4 * L + j];
+    __syncthreads();
+    // LSTM cell, gate order i, f, g, o (torch.nn.LSTMCell)
+    const int IN = H + 4 * L, H4 = 4 * H;
+    for (int j = tid; j < H; j += 256) {
+        float gi = lstm_b[j], gf = lstm_b[H + j], gg = lstm_b[2 * H + j], go = lstm_b[3 * H + j];
+        for (int i = 0; i < IN; ++i) {
+            const float xv = s_x[i];
+            const float* w = wihT + (size_t)i * H4 + j;
+            gi = fmaf(xv, w[0], gi); gf = fmaf(xv, w[H], gf); gg = fmaf(xv, w[2 * H], gg); go = fmaf(xv, w[3 * H], go);
+        }
+        for (int i = 0; i < H; ++i) {
+            const float hv = s_h[i];
+            const float* w = whhT + (size_t)i * H4 + j;
+            gi = fmaf(hv, w[0], gi); gf = fmaf(hv, w[H], gf); gg = fmaf(hv, w[2 * H], gg); go = fmaf(hv, w[3 * H], go);
+        }
+        gi = sigmoidf_(gi); gf = sigmoidf_(gf); gg = tanhf(gg); go = sigmoidf_(go);
+        const float c1 = gf * c_prev[(size_t)n * H + j] + gi * gg;
+        const float h1 = go * tanhf(c1);
+        s_c[j] = c1;
+        c_out[(size_t)n * H + j] = c1;
+        h_out[(size_t)n * H + j] = h1;
+        if (sv_gates) {
+            float* gs = sv_gates + (size_t)n * H4;
+            gs[j] = gi; gs[H + j] = gf; gs[2 * H + j] = gg; gs[3 * H + j] = go;
+        }
+    }
+    __syncthreads();
+    // posterior update from the cell state
+    for (int t = tid; t < 2 * L; t += 256) {
+        const int l = t % L;
+        const bool is_lv = t >= L;
+        const float* w = (is_lv ? wvT : wmT) + l;
+        float s = is_lv ? bv[l] : bm[l];
+        for (int j = 0; j < H; ++j) s = fmaf(s_c[j], w[(size_t)j * L], s);
+        float* dst = (is_lv ? plv : pm) + (size_t)n * L + l;
+        *dst = *dst + s;
+        float* dd = is_lv ? d_logvar_out : d_mean_out;
+        if (dd) dd[(size_t)n * L + l] = s;
+    }
+}
+
+hipError_t launch_refine_head(hipStream_t st, const float* feat, int N, int PL, int C, int H, int L,
+                              const float* mlp_wT, const float* mlp_b, const float* wihT, const float* whhT,
+                              const float* lstm_b, const float* wmT, const float* bm, const float* wvT, const float* bv,
+                              const float* latent, const float* h_prev, const float* c_prev, float* h_out, float* c_out,
+                              float* pm, float* plv, float* sv_pooled, float* sv_u, float* sv_gates, float* d_mean,
+                              float* d_logvar)
+{
+    if (256 % C != 0) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(C + (H + 4 * L) + H + H + 256) * sizeof(float);
+    hipLaunchKernelGGL(refine_head_kernel, dim3(N), dim3(256), lds, st, feat, PL, C, H, L, mlp_wT, mlp_b, wihT, whhT,
+                       lstm_b, wmT, bm, wvT, bv, latent, h_prev, c_prev, h_out, c_out, pm, plv, sv_pooled, sv_u,
+                       sv_gates, d_mean, d_logvar);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------
+// small utilities: transpose [R][Cc] -> [Cc][R], vector add
+// -----------------------------------------------------------------------------------------------
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc)
+{
+    const size_t total = (size_t)R * Cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = i / Cc, c = i % Cc;
+        dst[(size_t)c * R + r] = src[i];
+    }
+}
+
+hipError_t launch_transpose(hipStream_t st, const float* src, float* dst, int R, int Cc)
+{
+    const int blocks = (int)std::min<size_t>(((size_t)R * Cc + 255) / 256, 2048);
+    hipLaunchKernelGGL(transpose_kernel, dim3(blocks), dim3(256), 0, st, src, dst, R, Cc);
+    return hipGetLastError();
+}
+
+__global__ void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+
+hipError_t launch_add2(hipStream_t st, const float* a, const float* b, float* o, int n)
+{
+    hipLaunchKernelGGL(add2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, o, n);
+    return hipGetLastError();
+}
+
+// decoder output conv weights OIHW [4][C][3][3] -> [tap][ci][4]
+__global__ void pack_dec_out_kernel(const float* __restrict__ w, float* __restrict__ wk, int C)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9 * C * 4) return;
+    const int co = i & 3, ci = (i >> 2) % C, tap = (i >> 2) / C;
+    wk[i] = w[((size_t)co * C + ci) * 9 + tap];
+}
+
+hipError_t launch_pack_dec_out(hipStream_t st, const float* w, float* wk, int C)
+{
+    hipLaunchKernelGGL(pack_dec_out_kernel, dim3((9 * C * 4 + 255) / 256), dim3(256), 0, st, w, wk, C);
+    return hipGetLastError();
+}

@@ -1,0 +1,310 @@
+// Per-pixel mixture kernels: mask softmax, Gaussian log-likelihood, log-mixture, the closed-form
+// inner gradients and the 17-channel refinement input with its layer-norm statistics.
+//
+// Reference call sites (lib/modeling/iodine.py):
+//   elbo():               softmax :185, gaussian_log_likelihood :210,661-666, logsumexp :213-216, .mean(0).sum() :220
+//   (B*elbo).backward():  mean.grad / mask.grad :90,137,181,187  -> closed forms
+//   get_input_encoding(): channel order :277-340, 5-D layernorm :385-394
+// One thread owns one pixel and keeps all K slots of it in registers (the K-softmax, the
+// log-mixture and the leave-one-out term couple the slots at every pixel).  HBM-bound.
+#include "common.h"
+
+#define PIX_BLOCK 256
+
+template <int K>
+struct PixelTerms {
+    float mu[K][3];       // sigmoid(rgb)
+    float m[K];           // mask = softmax_k(logit)
+    float logit[K];
+    float g1[K][3];       // d(B*ELBO)/d mean
+    float g2[K];          // d(B*ELBO)/d mask
+    float pk[K];          // exp(sum_c l_kc)  (un-stabilised, as the reference)
+    float ll_sum;         // sum_c logsumexp_k(log(m_k + 1e-12) + l_kc)
+    float like;           // exp(ll_sum)
+    float mix;            // sum_k m_k * pk_k
+};
+
+template <int K>
+IOD_DEVINL void pixel_terms(const float4 xv, const float4* __restrict__ dec, size_t slot_stride, size_t p,
+                            float inv2s2, float invs2, float lconst, PixelTerms<K>& t)
+{
+    const float xs[3] = {xv.x, xv.y, xv.z};
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float4 d = dec[(size_t)k * slot_stride + p];
+        t.mu[k][0] = sigmoidf_(d.x); t.mu[k][1] = sigmoidf_(d.y); t.mu[k][2] = sigmoidf_(d.z);
+        t.logit[k] = d.w;
+        mx = fmaxf(mx, d.w);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { t.m[k] = expf(t.logit[k] - mx); den += t.m[k]; }
+    const float rden = 1.f / den;
+    float lm[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { t.m[k] *= rden; lm[k] = logf(t.m[k] + 1e-12f); t.g2[k] = 0.f; }
+    float lsum[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) lsum[k] = 0.f;
+    t.ll_sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float a[K];
+        float amax = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float d = xs[c] - t.mu[k][c];
+            const float l = -(d * d) * inv2s2 + lconst;
+            lsum[k] += l;
+            a[k] = lm[k] + l;
+            amax = fmaxf(amax, a[k]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { a[k] = expf(a[k] - amax); s += a[k]; }
+        t.ll_sum += amax + logf(s);
+        const float rs = 1.f / s;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float r = a[k] * rs;                         // responsibility of slot k for channel c
+            t.g1[k][c] = r * (xs[c] - t.mu[k][c]) * invs2;
+            t.g2[k] += r / (t.m[k] + 1e-12f);
+        }
+    }
+    t.like = expf(t.ll_sum);
+    t.mix = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { t.pk[k] = expf(lsum[k]); t.mix += t.m[k] * t.pk[k]; }
+}
+
+IOD_DEVINL double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ---- pass 1: ELBO log-likelihood partials, gradient wrt decoder output, layer-norm partial sums ----
+// part layout per (b, block): [0] ll, [1] like.s1, [2] like.s2, then per k: g1.s1, g1.s2, g2.s1, g2.s2, loo.s1, loo.s2
+template <int K>
+__global__ __launch_bounds__(PIX_BLOCK)
+void pixel_pass1_kernel(const float4* __restrict__ x4, const float4* __restrict__ dec, float4* __restrict__ g,
+                        double* __restrict__ part, int P, int ppb, float inv2s2, float invs2, float lconst)
+{
+    constexpr int NST = 6 * K + 3;
+    const int nblk = gridDim.x, b = blockIdx.y, blk = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float4* dec_b = dec + (size_t)b * K * P;
+    float4* g_b = g + (size_t)b * K * P;
+
+    float st[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) st[i] = 0.f;
+
+    const int pend = min(P, (blk + 1) * ppb);
+    for (int p = blk * ppb + tid; p < pend; p += PIX_BLOCK) {
+        PixelTerms<K> t;
+        pixel_terms<K>(x4[(size_t)b * P + p], dec_b, (size_t)P, (size_t)p, inv2s2, invs2, lconst, t);
+        float tg = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) tg += t.m[k] * t.g2[k];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float4 o;
+            o.x = t.g1[k][0] * t.mu[k][0] * (1.f - t.mu[k][0]);
+            o.y = t.g1[k][1] * t.mu[k][1] * (1.f - t.mu[k][1]);
+            o.z = t.g1[k][2] * t.mu[k][2] * (1.f - t.mu[k][2]);
+            o.w = t.m[k] * (t.g2[k] - tg);
+            g_b[(size_t)k * P + p] = o;
+            const float loo = (t.mix - t.m[k] * t.pk[k]) / (1.f - t.m[k] + 1e-5f);
+            st[3 + 6 * k + 0] += t.g1[k][0] + t.g1[k][1] + t.g1[k][2];
+            st[3 + 6 * k + 1] += t.g1[k][0] * t.g1[k][0] + t.g1[k][1] * t.g1[k][1] + t.g1[k][2] * t.g1[k][2];
+            st[3 + 6 * k + 2] += t.g2[k];
+            st[3 + 6 * k + 3] += t.g2[k] * t.g2[k];
+            st[3 + 6 * k + 4] += loo;
+            st[3 + 6 * k + 5] += loo * loo;
+        }
+        st[0] += t.ll_sum;
+        st[1] += t.like;
+        st[2] += t.like * t.like;
+    }
+
+    __shared__ double s_red[PIX_BLOCK / 64][NST];
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const double v = wave_sum_d((double)st[i]);
+        if (lane == 0) s_red[wv][i] = v;
+    }
+    __syncthreads();
+    if (tid < NST) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < PIX_BLOCK / 64; ++w) v += s_red[w][tid];
+        part[((size_t)b * nblk + blk) * NST + tid] = v;
+    }
+}
+
+// ---- finalize: fixed-order sum of block partials -> per-image LL, per-slot LN (mean, 1/(std+1e-5)) ----
+// lnstat[n][8] = {g1.mean, g1.inv, g2.mean, g2.inv, loo.mean, loo.inv, like.mean, like.inv}
+__global__ void pixel_finalize_kernel(const double* __restrict__ part, int nblk, int K, int P, int use_ln,
+                                      float* __restrict__ lnstat, float* __restrict__ ll_img)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int NST = 6 * K + 3;
+    __shared__ double s_sum[6 * 16 + 3];
+    if (tid < NST) {
+        double v = 0.0;
+        for (int i = 0; i < nblk; ++i) v += part[((size_t)b * nblk + i) * NST + tid];
+        s_sum[tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) ll_img[b] = (float)s_sum[0];
+    if (tid < K) {
+        float* o = lnstat + ((size_t)b * K + tid) * 8;
+        const double cnt[4] = {3.0 * P, (double)P, (double)P, (double)P};
+        const double s1[4] = {s_sum[3 + 6 * tid + 0], s_sum[3 + 6 * tid + 2], s_sum[3 + 6 * tid + 4], s_sum[1]};
+        const double s2[4] = {s_sum[3 + 6 * tid + 1], s_sum[3 + 6 * tid + 3], s_sum[3 + 6 * tid + 5], s_sum[2]};
+        for (int j = 0; j < 4; ++j) {
+            const double mean = s1[j] / cnt[j];
+            double var = s2[j] / cnt[j] - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float sd = (float)sqrt(var);
+            o[2 * j + 0] = use_ln ? (float)mean : 0.f;
+            o[2 * j + 1] = use_ln ? 1.f / (sd + 1e-5f) : 1.f;
+        }
+    }
+}
+
+// ---- pass 2: write the refinement input, NHWC with 20 channels (17 + 3 zero pad) -----------------
+template <int K>
+__global__ __launch_bounds__(PIX_BLOCK)
+void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict__ dec,
+                        const float* __restrict__ lnstat, const float* __restrict__ lin, float* __restrict__ enc,
+                        int P, int S, int ppb, float inv2s2, float invs2, float lconst)
+{
+    const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const float4* dec_b = dec + (size_t)b * K * P;
+    __shared__ float s_ln[K * 8];
+    for (int i = tid; i < K * 8; i += PIX_BLOCK) s_ln[i] = lnstat[(size_t)b * K * 8 + i];
+    __syncthreads();
+    const int pend = min(P, (blk + 1) * ppb);
+    for (int p = blk * ppb + tid; p < pend; p += PIX_BLOCK) {
+        PixelTerms<K> t;
+        const float4 xv = x4[(size_t)b * P + p];
+        pixel_terms<K>(xv, dec_b, (size_t)P, (size_t)p, inv2s2, invs2, lconst, t);
+        float psum = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) psum += t.pk[k];
+        const float cx = lin[p % S], cy = lin[p / S];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float* ln = s_ln + k * 8;
+            const float loo = (t.mix - t.m[k] * t.pk[k]) / (1.f - t.m[k] + 1e-5f);
+            float4* o = reinterpret_cast<float4*>(enc + (((size_t)b * K + k) * P + p) * 20);
+            o[0] = make_float4(xv.x, xv.y, xv.z, t.mu[k][0]);
+            o[1] = make_float4(t.mu[k][1], t.mu[k][2], t.m[k], t.logit[k]);
+            o[2] = make_float4(t.pk[k] / psum, (t.g1[k][0] - ln[0]) * ln[1], (t.g1[k][1] - ln[0]) * ln[1],
+                               (t.g1[k][2] - ln[0]) * ln[1]);
+            o[3] = make_float4((t.g2[k] - ln[2]) * ln[3], (t.like - ln[6]) * ln[7], (loo - ln[4]) * ln[5], cx);
+            o[4] = make_float4(cy, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+// ---- final decode outputs (IODINE.decode, lib/modeling/iodine.py:59-71): NCHW pred / mask / mean ----
+template <int K>
+__global__ __launch_bounds__(PIX_BLOCK)
+void final_out_kernel(const float4* __restrict__ dec, float* __restrict__ pred, float* __restrict__ mask,
+                      float* __restrict__ mean, int P)
+{
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * PIX_BLOCK + threadIdx.x;
+    if (p >= P) return;
+    const float4* dec_b = dec + (size_t)b * K * P;
+    float4 d[K];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { d[k] = dec_b[(size_t)k * P + p]; mx = fmaxf(mx, d[k].w); }
+    float m[K], den = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { m[k] = expf(d[k].w - mx); den += m[k]; }
+    const float rden = 1.f / den;
+    float pr[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        m[k] *= rden;
+        const float mu[3] = {sigmoidf_(d[k].x), sigmoidf_(d[k].y), sigmoidf_(d[k].z)};
+        const size_t n = (size_t)b * K + k;
+        if (mask) mask[n * P + p] = m[k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (mean) mean[(n * 3 + c) * P + p] = mu[c];
+            pr[c] += m[k] * mu[c];
+        }
+    }
+    if (pred)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pred[((size_t)b * 3 + c) * P + p] = pr[c];
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+#define FOR_EACH_K(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+
+int pixel_blocks_per_image(int P) { return (P + 2 * PIX_BLOCK - 1) / (2 * PIX_BLOCK); }   // 2 pixels / thread
+
+hipError_t launch_pixel_pass1(hipStream_t st, const float* x4, const float* dec, float* g, double* part, int B,
+                              int K, int P, float sigma)
+{
+    const int nblk = pixel_blocks_per_image(P), ppb = (P + nblk - 1) / nblk;
+    const float inv2s2 = 1.f / (2.f * sigma * sigma), invs2 = 1.f / (sigma * sigma);
+    const float lconst = (float)(-log((double)sigma) - 0.5 * log(2.0 * M_PI));
+    switch (K) {
+#define CASE(KK) case KK: hipLaunchKernelGGL((pixel_pass1_kernel<KK>), dim3(nblk, B), dim3(PIX_BLOCK), 0, st, \
+        (const float4*)x4, (const float4*)dec, (float4*)g, part, P, ppb, inv2s2, invs2, lconst); break;
+        FOR_EACH_K(CASE)
+#undef CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_pixel_finalize(hipStream_t st, const double* part, int B, int K, int P, int use_ln,
+                                 float* lnstat, float* ll_img)
+{
+    hipLaunchKernelGGL(pixel_finalize_kernel, dim3(B), dim3(128), 0, st, part, pixel_blocks_per_image(P), K, P,
+                       use_ln, lnstat, ll_img);
+    return hipGetLastError();
+}
+
+hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec, const float* lnstat,
+                              const float* lin, float* enc, int B, int K, int S, float sigma)
+{
+    const int P = S * S;
+    const int nblk = pixel_blocks_per_image(P), ppb = (P + nblk - 1) / nblk;
+    const float inv2s2 = 1.f / (2.f * sigma * sigma), invs2 = 1.f / (sigma * sigma);
+    const float lconst = (float)(-log((double)sigma) - 0.5 * log(2.0 * M_PI));
+    switch (K) {
+#define CASE(KK) case KK: hipLaunchKernelGGL((pixel_pass2_kernel<KK>), dim3(nblk, B), dim3(PIX_BLOCK), 0, st, \
+        (const float4*)x4, (const float4*)dec, lnstat, lin, enc, P, S, ppb, inv2s2, invs2, lconst); break;
+        FOR_EACH_K(CASE)
+#undef CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_final_out(hipStream_t st, const float* dec, float* pred, float* mask, float* mean, int B, int K,
+                            int P)
+{
+    const dim3 grid((P + PIX_BLOCK - 1) / PIX_BLOCK, B);
+    switch (K) {
+#define CASE(KK) case KK: hipLaunchKernelGGL((final_out_kernel<KK>), grid, dim3(PIX_BLOCK), 0, st, \
+        (const float4*)dec, pred, mask, mean, P); break;
+        FOR_EACH_K(CASE)
+#undef CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,379 @@
+"""``IODINE(ARCH)``: the reference's module surface over libiodine_hip.so.
+
+Mirrors ``lib/modeling/iodine.py`` of zhixuan-lin/IODINE for the callers of the hot path:
+``loss = model(x)`` (lib/engine/train.py:60), ``model.reconstruct(image)``
+(lib/eval/ari_eval.py:22), ``encode`` / ``decode`` (iodine.py:59-112), the
+``named_parameters()`` / ``state_dict()`` names (lib/solver/build.py:10-14,
+lib/utils/checkpoint.py:43,68), ``model.sigma`` (train.py:97) and the ``logger`` side
+channel keys (iodine.py:156-157,226-239).  All arithmetic runs in hand-written gfx950
+kernels behind the C ABI of include/iodine_hip.h; PyTorch only owns the tensors, the
+stream and the autograd hook-up.  There is no CPU or eager fallback: tensors must live on
+a ROCm device and the shared library must be built.
+
+Extensions over the reference: every entry point takes an optional ``eps`` tensor of shape
+(T+1, B, K, L) replacing the ``torch.randn_like`` draws of ``Gaussian.sample``
+(iodine.py:632) in call order, so that results can be compared with the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class Logger:
+    """Same role as lib/utils/vis_logger.py:30-50: a dict of the latest values."""
+
+    def __init__(self):
+        self.things = dict()
+
+    def __getitem__(self, key):
+        return self.things[key]
+
+    def __contains__(self, key):
+        return key in self.things
+
+    def update(self, **kw):
+        self.things.update(kw)
+
+
+logger = Logger()
+
+
+def _arch_get(arch, name, default=None):
+    return getattr(arch, name, default)
+
+
+class _MultiLayerConv(nn.Module):
+    """Parameter container with the reference's names (iodine.py:570-584); never called."""
+
+    def __init__(self, dim_in, dim_out, n_layers, kernel_size, stride=1):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        for _ in range(n_layers):
+            self.layers.append(nn.Conv2d(dim_in, dim_out, kernel_size, stride=stride, padding=kernel_size // 2))
+            dim_in = dim_out
+
+
+class _MLP(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.layers = nn.ModuleList([nn.Linear(dim_in, dim_out)])       # iodine.py:553-557
+
+
+class _Refine(nn.Module):
+    def __init__(self, dim_in, dim_conv, dim_hidden, dim_out, n_layers, kernel_size, stride):
+        super().__init__()                                              # iodine.py:450-464
+        self.mlc = _MultiLayerConv(dim_in, dim_conv, n_layers, kernel_size, stride)
+        self.mlp = _MLP(dim_conv, dim_hidden)
+        self.lstm = nn.LSTMCell(dim_hidden + 4 * dim_out, dim_hidden)
+        self.mean_update = nn.Linear(dim_hidden, dim_out)
+        self.logvar_update = nn.Linear(dim_hidden, dim_out)
+
+
+class _Decoder(nn.Module):
+    def __init__(self, dim_in, dim_hidden, n_layers, kernel_size):
+        super().__init__()                                              # iodine.py:416-423
+        self.mlc = _MultiLayerConv(dim_in + 2, dim_hidden, n_layers, kernel_size)
+        self.conv = nn.Conv2d(dim_hidden, 4, kernel_size, stride=1, padding=kernel_size // 2)
+
+
+class _Posterior(nn.Module):
+    def __init__(self, dim_latent):
+        super().__init__()                                              # iodine.py:596-604
+        self.init_mean = nn.Parameter(torch.zeros(dim_latent))
+        self.init_logvar = nn.Parameter(torch.zeros(dim_latent))
+        self.mean = None
+        self.logvar = None
+
+
+class _TrainStep(torch.autograd.Function):
+    """``loss = model(x)`` / ``loss.backward()`` through iodine_train_forward / iodine_train_backward."""
+
+    @staticmethod
+    def forward(ctx, module, x, eps, *params):
+        loss, elbo_iter = module._train_forward(x, eps)
+        ctx.module = module
+        ctx.n = len(params)
+        ctx.mark_non_differentiable(elbo_iter)
+        return loss, elbo_iter
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_elbo):
+        grads = ctx.module._train_backward(grad_loss)
+        return (None, None, None, *grads)
+
+
+class IODINE(nn.Module):
+    def __init__(self, ARCH):
+        super().__init__()
+        # same attribute reads as iodine.py:8-21
+        self.dim_latent = ARCH.DIM_LATENT
+        self.n_iters = ARCH.ITERS
+        self.K = ARCH.SLOTS
+        self.encodings = list(ARCH.ENCODING)
+        self.img_channels = ARCH.IMG_CHANNELS
+        self.img_size = ARCH.IMG_SIZE
+        self.sigma = ARCH.SIGMA
+        self.use_layernorm = ARCH.LAYERNORM
+        self.use_stop_gradient = _arch_get(ARCH, 'STOP_GRADIENT', False)
+
+        input_size, lambda_size = self.get_input_size()
+        ref, dec = ARCH.REF, ARCH.DEC
+        self.refine = _Refine(input_size, ref.CONV_CHAN, ref.MLP_UNITS, ARCH.DIM_LATENT, ref.CONV_LAYERS,
+                              ref.KERNEL_SIZE, _arch_get(ref, 'STRIDE', 2))
+        self.decoder = _Decoder(ARCH.DIM_LATENT, dec.CONV_CHAN, dec.CONV_LAYERS, dec.KERNEL_SIZE)
+        self.posterior = _Posterior(self.dim_latent)
+
+        self._cfg = _lib.Config(
+            dim_latent=ARCH.DIM_LATENT, iters=ARCH.ITERS, slots=ARCH.SLOTS, img_size=ARCH.IMG_SIZE,
+            img_channels=ARCH.IMG_CHANNELS, sigma=float(ARCH.SIGMA), layernorm=int(bool(ARCH.LAYERNORM)),
+            stop_gradient=int(bool(self.use_stop_gradient)), encoding=_lib.encoding_bits(self.encodings),
+            ref_conv_chan=ref.CONV_CHAN, ref_conv_layers=ref.CONV_LAYERS, ref_mlp_units=ref.MLP_UNITS,
+            ref_kernel_size=ref.KERNEL_SIZE, ref_stride=_arch_get(ref, 'STRIDE', 2),
+            dec_conv_chan=dec.CONV_CHAN, dec_conv_layers=dec.CONV_LAYERS, dec_kernel_size=dec.KERNEL_SIZE)
+
+        # per-call state the reference keeps on self (iodine.py:36-52)
+        self.lstm_hidden = None
+        self.z = None
+        self.mean = None
+        self.mask_logits = None
+        self.mask = None
+        self.elbo_terms = None          # (n_elbo_calls, 3) = {ELBO, KL, LL} of the last call
+
+        self._handle = None
+        self._handle_device = None
+        self._param_versions = None
+        self._workspace = None
+        self._ws_key = None
+        self.generator: Optional[torch.Generator] = None
+        self._options: Dict[str, float] = {}
+
+    # ---- bookkeeping identical to the reference -------------------------------------------------
+    def get_input_size(self):
+        """iodine.py:345-374."""
+        size, latent = 0, 0
+        e, c = self.encodings, self.img_channels
+        if 'grad_post' in e: latent += 2 * self.dim_latent
+        if 'posterior' in e: latent += 2 * self.dim_latent
+        for name, n in (('image', c), ('means', c), ('mask', 1), ('mask_logits', 1), ('mask_posterior', 1),
+                        ('grad_means', c), ('grad_mask', 1), ('likelihood', 1), ('leave_one_out_likelihood', 1),
+                        ('coordinate', 2)):
+            if name in e:
+                size += n
+        return size, latent
+
+    # ---- library plumbing ---------------------------------------------------------------------
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.lib().iodine_destroy(self._handle)
+        except Exception:
+            pass
+
+    def _ordered_params(self):
+        return [p for _, p in self.named_parameters()]
+
+    def _ensure_handle(self, device: torch.device):
+        if device.type != 'cuda':
+            raise RuntimeError('iodine_amd.IODINE runs only on a ROCm device (gfx950); got tensors on '
+                               f'{device}. There is no CPU fallback - move the module and inputs with .to("cuda").')
+        L = _lib.lib()
+        if self._handle is not None and self._handle_device != device:
+            L.iodine_destroy(self._handle)
+            self._handle, self._param_versions, self._workspace, self._ws_key = None, None, None, None
+        if self._handle is None:
+            with torch.cuda.device(device):
+                h = C.c_void_p()
+                _lib.check(L.iodine_create(C.byref(self._cfg), C.byref(h)), None, 'iodine_create')
+            self._handle, self._handle_device = h, device
+            for k, v in self._options.items():
+                _lib.check(L.iodine_set_option(h, k.encode(), v), h)
+            names = []
+            for i in range(L.iodine_num_params(h)):
+                nm, nd, dims = C.c_char_p(), C.c_int(), (C.c_longlong * 4)()
+                _lib.check(L.iodine_param_info(h, i, C.byref(nm), C.byref(nd), dims), h)
+                names.append((nm.value.decode(), tuple(dims[:nd.value])))
+            mine = [(n, tuple(p.shape)) for n, p in self.named_parameters()]
+            if names != mine:
+                raise RuntimeError(f'parameter table mismatch between module and library:\n{names}\n{mine}')
+        return self._handle
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _sync_params(self, device):
+        h = self._ensure_handle(device)
+        params = self._ordered_params()
+        for p in params:
+            if p.device != device or p.dtype != torch.float32:
+                raise RuntimeError('all parameters must be float32 on the same ROCm device as the input')
+        versions = tuple((p.data_ptr(), p._version) for p in params)
+        if versions != self._param_versions:
+            keep = [p.detach().contiguous() for p in params]
+            arr = (C.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
+            _lib.check(_lib.lib().iodine_set_params(h, self._stream(), arr, len(keep)), h, 'iodine_set_params')
+            self._param_versions = versions
+        return h
+
+    def _ensure_workspace(self, h, B, mode, device):
+        key = (B, mode, device)
+        if self._ws_key == key:
+            return
+        need = _lib.lib().iodine_workspace_bytes(h, B, mode)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+        _lib.check(_lib.lib().iodine_set_workspace(h, C.c_void_p(self._workspace.data_ptr()),
+                                                   self._workspace.numel()), h, 'iodine_set_workspace')
+        self._ws_key = key
+
+    def _check_x(self, x):
+        if x.dim() != 4 or x.shape[1] != self.img_channels or x.shape[2] != self.img_size or x.shape[3] != self.img_size:
+            raise RuntimeError(f'expected images of shape (B, {self.img_channels}, {self.img_size}, {self.img_size}), '
+                               f'got {tuple(x.shape)}')
+        return x.detach().to(torch.float32).contiguous()
+
+    def _eps(self, eps, B, device):
+        shape = (self.n_iters + 1, B, self.K, self.dim_latent)
+        if eps is None:
+            return torch.randn(shape, device=device, dtype=torch.float32, generator=self.generator)
+        if tuple(eps.shape) != shape:
+            raise RuntimeError(f'eps must have shape {shape}, got {tuple(eps.shape)}')
+        return eps.detach().to(device=device, dtype=torch.float32).contiguous()
+
+    def debug_buffer(self, name: str, iteration: int = 0) -> torch.Tensor:
+        """Copy of an internal workspace buffer of the last call (tests only)."""
+        h = self._handle
+        n = C.c_size_t()
+        L = _lib.lib()
+        _lib.check(L.iodine_debug_copy(h, self._stream(), name.encode(), iteration, None, 0, C.byref(n)), h)
+        out = torch.empty(n.value, dtype=torch.float32, device=self._handle_device)
+        _lib.check(L.iodine_debug_copy(h, self._stream(), name.encode(), iteration, C.c_void_p(out.data_ptr()),
+                                       n.value, C.byref(n)), h)
+        return out
+
+    def set_option(self, key: str, value: float):
+        """Debug/test options of the library (e.g. ``stop_after_iters``); applied to the live handle."""
+        self._options[key] = float(value)
+        if self._handle is not None:
+            _lib.check(_lib.lib().iodine_set_option(self._handle, key.encode(), float(value)), self._handle)
+
+    # ---- inference: iodine.py:59-112 ------------------------------------------------------------
+    @torch.no_grad()
+    def _reconstruct(self, x, eps, want_images=True):
+        x = self._check_x(x)
+        dev, B = x.device, x.shape[0]
+        h = self._sync_params(dev)
+        self._ensure_workspace(h, B, 0, dev)
+        eps = self._eps(eps, B, dev)
+        K, L, S, T = self.K, self.dim_latent, self.img_size, self.n_iters
+        f = dict(device=dev, dtype=torch.float32)
+        pred = torch.empty((B, 3, S, S), **f) if want_images else None
+        mask = torch.empty((B, K, 1, S, S), **f) if want_images else None
+        mean = torch.empty((B, K, 3, S, S), **f) if want_images else None
+        z = torch.empty((B, K, L), **f)
+        pm, plv = torch.empty((B, K, L), **f), torch.empty((B, K, L), **f)
+        elbo = torch.empty((T, 3), **f)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().iodine_reconstruct(h, self._stream(), B, _lib.ptr(x), _lib.ptr(eps), _lib.ptr(pred),
+                                                     _lib.ptr(mask), _lib.ptr(mean), _lib.ptr(z), _lib.ptr(pm),
+                                                     _lib.ptr(plv), _lib.ptr(elbo)), h, 'iodine_reconstruct')
+        self.z, self.posterior.mean, self.posterior.logvar, self.elbo_terms = z, pm, plv, elbo
+        if want_images:
+            self.mean, self.mask = mean, mask
+            self._publish(x, pred, mask, mean, elbo[-1])
+        return pred, mask, mean, z
+
+    def encode(self, x, eps=None):
+        """z (B, K, L) after T refinement iterations.  iodine.py:73-105."""
+        return self._reconstruct(x, eps, want_images=False)[3]
+
+    def reconstruct(self, x, eps=None):
+        """pred (B,3,S,S), mask (B,K,1,S,S), mean (B,K,3,S,S).  iodine.py:107-112."""
+        pred, mask, mean, _ = self._reconstruct(x, eps)
+        return pred, mask, mean
+
+    @torch.no_grad()
+    def decode(self, z):
+        """iodine.py:59-71."""
+        z = z.detach().to(torch.float32).contiguous()
+        dev, B = z.device, z.shape[0]
+        h = self._sync_params(dev)
+        self._ensure_workspace(h, B, 0, dev)
+        K, S = self.K, self.img_size
+        f = dict(device=dev, dtype=torch.float32)
+        pred, mask, mean = torch.empty((B, 3, S, S), **f), torch.empty((B, K, 1, S, S), **f), torch.empty((B, K, 3, S, S), **f)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().iodine_decode(h, self._stream(), B, _lib.ptr(z), _lib.ptr(pred), _lib.ptr(mask),
+                                                _lib.ptr(mean)), h, 'iodine_decode')
+        return pred, mask, mean
+
+    # ---- training: iodine.py:115-158 + lib/engine/train.py:60-63 -------------------------------------
+    def forward(self, x, eps=None):
+        """-sum_i (i+1)/(T+1) ELBO_i, differentiable wrt every parameter."""
+        x = self._check_x(x)
+        eps = self._eps(eps, x.shape[0], x.device)
+        loss, elbo_iter = _TrainStep.apply(self, x, eps, *self._ordered_params())
+        self.elbo_terms = elbo_iter
+        logger.update(init_mean=self.posterior.init_mean.detach().mean(),
+                      init_logvar=self.posterior.init_logvar.detach().mean())          # iodine.py:156-157
+        logger.update(kl=elbo_iter[-1, 1], likelihood=elbo_iter[-1, 2])
+        return loss
+
+    def _train_forward(self, x, eps):
+        dev, B = x.device, x.shape[0]
+        h = self._sync_params(dev)
+        self._ensure_workspace(h, B, 1, dev)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        elbo_iter = torch.empty((self.n_iters + 1, 3), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().iodine_train_forward(h, self._stream(), B, _lib.ptr(x), _lib.ptr(eps), _lib.ptr(loss),
+                                                       _lib.ptr(elbo_iter)), h, 'iodine_train_forward')
+        return loss, elbo_iter
+
+    def _train_backward(self, grad_loss):
+        h, dev = self._handle, self._handle_device
+        params = self._ordered_params()
+        sizes = [p.numel() for p in params]
+        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        views, off = [], 0
+        for p, n in zip(params, sizes):
+            views.append(flat[off:off + n].view_as(p))
+            off += n
+        arr = (C.c_void_p * len(views))(*[v.data_ptr() for v in views])
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().iodine_train_backward(h, self._stream(), 1.0, arr, len(views)), h, 'iodine_train_backward')
+        flat.mul_(grad_loss.to(torch.float32))
+        return views
+
+    # ---- logger side channel (iodine.py:226-239) ----------------------------------------------------
+    def _publish(self, x, pred, mask, mean, terms):
+        logger.update(image=x[0], pred=pred[0], kl=terms[1], likelihood=terms[2])
+        logger.update(**{f'mask_{i}': mask[0, i, 0] for i in range(self.K)})
+        logger.update(**{f'pred_{i}': mean[0, i] for i in range(self.K)})
+
+
+def arch_namespace(dim_latent, iters, slots, img_size, ref, dec, sigma=0.10, layernorm=True,
+                   encoding=_lib.ENC_ORDER):
+    """Build an ``ARCH``-shaped namespace (the yacs node of lib/config/defaults.py:35-100) from plain
+    values; ref = (CONV_CHAN, CONV_LAYERS, MLP_UNITS), dec = (CONV_CHAN, CONV_LAYERS)."""
+    from types import SimpleNamespace as NS
+    return NS(DIM_LATENT=dim_latent, ITERS=iters, SLOTS=slots, ENCODING=list(encoding), IMG_CHANNELS=3,
+              IMG_SIZE=img_size, SIGMA=sigma, LAYERNORM=layernorm, STOP_GRADIENT=False,
+              REF=NS(CONV_CHAN=ref[0], CONV_LAYERS=ref[1], MLP_UNITS=ref[2], KERNEL_SIZE=3, STRIDE=2),
+              DEC=NS(CONV_CHAN=dec[0], CONV_LAYERS=dec[1], KERNEL_SIZE=3))
+
+
+def clevr6_arch(slots=7, iters=5):
+    """configs/clevr6_prop.yaml:26-45."""
+    return arch_namespace(64, iters, slots, 128, (64, 4, 256), (64, 4))
+
+
+def dsprites_arch(slots=6, iters=5):
+    """configs/dsprites_noclip.yaml:26-45."""
+    return arch_namespace(16, iters, slots, 64, (32, 3, 128), (32, 5))

@@ -1,0 +1,82 @@
+"""CPU-side checks of the C-ABI library and host logic (no GPU, no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from iodine_amd import _lib, synth
+from oracle import iodine_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    header = open(os.path.join(ROOT, 'include', 'iodine_hip.h')).read()
+    declared = set(re.findall(r'\b(iodine_[a-z0-9_]+)\s*\(', header))
+    declared -= {'iodine_handle', 'iodine_config'}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.iodine_abi_version() == 1
+
+
+def test_config_struct_matches_header_field_order():
+    header = open(os.path.join(ROOT, 'include', 'iodine_hip.h')).read()
+    body = header[header.index('typedef struct iodine_config {'):header.index('} iodine_config;')]
+    fields = re.findall(r'^\s*(?:int|double|unsigned)\s+([a-z_]+);', body, flags=re.M)
+    assert fields == [f[0] for f in _lib.Config._fields_]
+
+
+def test_create_rejects_unsupported_configs_with_message():
+    L = _lib.lib()
+    cfg = _lib.Config(dim_latent=16, iters=3, slots=4, img_size=64, img_channels=3, sigma=0.1, layernorm=1,
+                      stop_gradient=0, encoding=_lib.ENC_FULL & ~(1 << 11), ref_conv_chan=32, ref_conv_layers=3,
+                      ref_mlp_units=128, ref_kernel_size=3, ref_stride=2, dec_conv_chan=32, dec_conv_layers=5,
+                      dec_kernel_size=3)
+    h = C.c_void_p()
+    assert L.iodine_create(C.byref(cfg), C.byref(h)) == 1 and not h.value
+    assert b'ENCODING' in L.iodine_last_error(None)
+    cfg.encoding = _lib.ENC_FULL
+    cfg.dec_kernel_size = 5                       # configs/test.yaml uses 5: rejected, not approximated
+    assert L.iodine_create(C.byref(cfg), C.byref(h)) == 1
+    assert b'KERNEL_SIZE' in L.iodine_last_error(None)
+
+
+def test_linspace_matches_torch():
+    L = _lib.lib()
+    for n in (16, 64, 128):
+        out = (C.c_float * n)()
+        L.iodine_linspace_host(n, out)
+        ref = torch.linspace(-1, 1, n).numpy()
+        got = np.frombuffer(out, dtype=np.float32)
+        assert np.abs(got - ref).max() <= 1.2e-7         # <= 1 ulp (ATen's vectorised path rounds differently)
+        assert got[0] == -1.0 and got[-1] == 1.0
+
+
+def test_module_surface_matches_reference_names():
+    from util import golden_setup, hip_arch, load_golden
+    from iodine_amd import IODINE
+    g = load_golden('tiny')
+    arch, params, _, _, _ = golden_setup(g)
+    m = IODINE(hip_arch(arch))
+    assert [(k, tuple(v.shape)) for k, v in m.named_parameters()] == [(k, tuple(v.shape)) for k, v in params.items()]
+    assert m.get_input_size() == (17, 4 * arch.dim_latent)
+    assert m.sigma == arch.sigma and m.K == arch.slots and m.n_iters == arch.iters
+    with pytest.raises(RuntimeError, match='ROCm device'):
+        m.reconstruct(torch.zeros(1, 3, arch.img_size, arch.img_size))
+
+
+def test_synth_is_deterministic_and_shard_invariant():
+    e1 = synth.make_eps(2, 4, 3, 8, seed=1)
+    e2 = synth.make_eps(2, 4, 3, 8, seed=1)
+    assert np.array_equal(e1, e2)
+    assert abs(float(e1.mean())) < 0.2 and 0.8 < float(e1.std()) < 1.2
+    a = synth.make_images(4, 16, seed=0)
+    b = synth.make_images(2, 16, seed=0, first_index=2)
+    assert np.array_equal(a[2:], b)
+    imgs, masks = synth.make_images(2, 32, seed=0, kind='blobs')
+    assert imgs.min() >= 0 and imgs.max() <= 1 and len(masks) == 2 and masks[0].shape[1:] == (32, 32)

@@ -1,0 +1,87 @@
+"""Kernel-level parity: each conv kernel of libiodine_hip.so against PyTorch-CPU fp32 convs
+(the ATen arithmetic the reference runs, lib/modeling/iodine.py:422,435,583,592)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from iodine_amd import _lib
+from util import nchw, nhwc, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _conv_op(mode, x_nhwc, w, bias, aux, n, ih, iw, w_o, w_i, cin_pad, cout, stride, epi, tflip, out_shape):
+    L = _lib.lib()
+    out = torch.full(out_shape, float('nan'), device=DEV)
+    args = [t.to(DEV).contiguous() if t is not None else None for t in (x_nhwc, w, bias, aux)]
+    rc = L.iodine_op_conv3x3(None, mode, _lib.ptr(args[0]), _lib.ptr(args[1]), _lib.ptr(args[2]), _lib.ptr(args[3]),
+                             _lib.ptr(out), n, ih, iw, w_o, w_i, cin_pad, cout, stride, epi, tflip)
+    _lib.check(rc, None, 'iodine_op_conv3x3')
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+@pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 2), (64, 128, 1), (32, 64, 2)])
+def test_conv_tile_forward_bias_elu(C_, S, N):
+    x = _rand(N, C_, S, S, seed=1)
+    w = _rand(C_, C_, 3, 3, seed=2, scale=3.0 / (C_ * 9) ** 0.5)
+    b = _rand(C_, seed=3, scale=0.5)
+    ref = nhwc(F.elu(F.conv2d(x, w, b, padding=1)))
+    got = _conv_op(0, nhwc(x), w, b, None, N, S, S, C_, C_, C_, C_, 1, 0, 0, ref.shape)
+    assert rel_err(got, ref) < 2e-6, rel_err(got, ref)
+
+
+@pytest.mark.parametrize('C_,S,N', [(64, 32, 2), (32, 16, 3), (64, 128, 1)])
+def test_conv_tile_dgrad_times_elu_grad(C_, S, N):
+    g = _rand(N, C_, S, S, seed=4)
+    w = _rand(C_, C_, 3, 3, seed=5, scale=3.0 / (C_ * 9) ** 0.5)
+    a = F.elu(_rand(N, C_, S, S, seed=6, scale=2.0))              # saved ELU output of the layer below
+    ref = F.conv_transpose2d(g, w, padding=1) * torch.where(a > 0, torch.ones_like(a), a + 1)
+    got = _conv_op(0, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 1, 1, nhwc(ref).shape)
+    assert rel_err(got, nhwc(ref)) < 2e-6, rel_err(got, nhwc(ref))
+
+
+@pytest.mark.parametrize('C_,S,N', [(64, 32, 2), (32, 16, 3)])
+def test_conv_tile_output_layer_dgrad(C_, S, N):
+    """data gradient of the C->4 output conv: a conv with 4 input channels (K = 36)"""
+    g = _rand(N, 4, S, S, seed=7)
+    w = _rand(4, C_, 3, 3, seed=8, scale=0.2)
+    a = F.elu(_rand(N, C_, S, S, seed=9, scale=2.0))
+    ref = F.conv_transpose2d(g, w, padding=1) * torch.where(a > 0, torch.ones_like(a), a + 1)
+    got = _conv_op(0, nhwc(g), w, None, nhwc(a), N, S, S, 4, C_, 4, C_, 1, 1, 1, nhwc(ref).shape)
+    assert rel_err(got, nhwc(ref)) < 2e-6, rel_err(got, nhwc(ref))
+
+
+@pytest.mark.parametrize('cin,cpad,cout,S,N', [(17, 20, 64, 32, 3), (64, 64, 64, 16, 5), (17, 20, 32, 16, 2),
+                                                (32, 32, 32, 8, 7), (64, 64, 64, 128, 1), (32, 32, 32, 4, 3)])
+def test_conv_gather_stride2(cin, cpad, cout, S, N):
+    x = _rand(N, cin, S, S, seed=10)
+    w = _rand(cout, cin, 3, 3, seed=11, scale=3.0 / (cin * 9) ** 0.5)
+    b = _rand(cout, seed=12, scale=0.5)
+    ref = nhwc(F.elu(F.conv2d(x, w, b, stride=2, padding=1)))
+    xp = torch.full((N, S, S, cpad), 7.0)                      # pad channels hold garbage: weights there must be zero
+    xp[..., :cin] = nhwc(x)
+    got = _conv_op(1, xp, w, b, None, N, S, S, cout, cin, cpad, cout, 2, 0, 0, ref.shape)
+    assert rel_err(got, ref) < 2e-6, rel_err(got, ref)
+
+
+@pytest.mark.parametrize('C_,S,N', [(64, 32, 2), (32, 16, 3), (64, 128, 1)])
+def test_dec_out_conv(C_, S, N):
+    x = _rand(N, C_, S, S, seed=13)
+    w = _rand(4, C_, 3, 3, seed=14, scale=0.1)
+    b = _rand(4, seed=15)
+    ref = nhwc(F.conv2d(x, w, b, padding=1))
+    out = torch.full(ref.shape, float('nan'), device=DEV)
+    L = _lib.lib()
+    xs, ws, bs = nhwc(x).to(DEV), w.to(DEV), b.to(DEV)
+    _lib.check(L.iodine_op_dec_out(None, _lib.ptr(xs), _lib.ptr(ws), _lib.ptr(bs), _lib.ptr(out), N, S, C_))
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < 2e-6

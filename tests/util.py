@@ -50,3 +50,30 @@ def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64).ravel()
     b = np.asarray(b, dtype=np.float64).ravel()
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+# ---- HIP-side helpers (GPU tests) -------------------------------------------------------------
+def hip_arch(arch):
+    """oracle Arch -> ARCH-shaped namespace for iodine_amd.IODINE."""
+    from iodine_amd.model import arch_namespace
+    return arch_namespace(arch.dim_latent, arch.iters, arch.slots, arch.img_size,
+                          (arch.ref_chan, arch.ref_layers, arch.ref_mlp), (arch.dec_chan, arch.dec_layers),
+                          sigma=arch.sigma, layernorm=arch.layernorm)
+
+
+def make_hip_model(arch, params, device='cuda:0'):
+    from iodine_amd import IODINE
+    m = IODINE(hip_arch(arch))
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(params.keys()), 'state_dict names differ from the reference'
+    m.load_state_dict({k: v.to(torch.float32) for k, v in params.items()})
+    return m.to(device)
+
+
+def nhwc(t):
+    """(N,C,H,W) -> (N,H,W,C) contiguous"""
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
