@@ -113,8 +113,13 @@ int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float*
  * (+=, like autograd's .grad accumulation; zero_grad is the caller's job, train.py:62). */
 int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, float* const* param_grads, int n);
 
-/* Debug / test hooks: key "stop_after_iters" (run only the first v refinement iterations in reconstruct). */
+/* Options: "stop_after_iters" (debug: run only the first v refinement iterations of reconstruct, no final decode),
+ * "profile" (1: bracket every kernel launch with HIP events on the launch stream). */
 int iodine_set_option(iodine_handle* h, const char* key, double value);
+/* Sum of event-measured durations (ms) and number of launches of one kernel category since the last reset:
+ * "conv_tile_fwd", "conv_tile_dgrad", "conv_tile_wgrad", "dec_out", "dec_out_dgrad", "dec_l0", "l0_reduce",
+ * "pixel_pass1", "pixel_pass2", "refine_conv", "refine_head".  Synchronises on the recorded events. */
+int iodine_profile_read(iodine_handle* h, const char* category, double* total_ms, long long* launches, int reset);
 /* Copy an internal buffer of the last call (name as listed in DESIGN.md "workspace") to dst (device). */
 int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter, float* dst, size_t max_floats,
                       size_t* n_floats);

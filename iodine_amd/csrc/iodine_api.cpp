@@ -48,9 +48,19 @@ struct Buffers {               // workspace carve-up for one batch size / mode
 
 }  // namespace
 
+// HIP-event profiler: when enabled every launch of a category is bracketed by two events on the
+// launch stream; totals are read back (after a sync) with iodine_profile_read.
+struct ProfCat { std::string name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; };
+
 struct iodine_handle {
     iodine_config cfg;
     std::string err;
+    bool profile = false;
+    std::vector<ProfCat> prof;
+    ProfCat* prof_cat(const char* name) {
+        for (auto& c : prof) if (c.name == name) return &c;
+        prof.push_back(ProfCat()); prof.back().name = name; return &prof.back();
+    }
     int L, T, K, S, P, Cd, Dd, Cr, Dr, H;
     std::vector<ParamInfo> params;
     bool params_set = false;
@@ -81,6 +91,25 @@ namespace {
         hipError_t e_ = (expr);                                                                  \
         if (e_ != hipSuccess)                                                                    \
             return (h)->fail(IODINE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// bracket one launch expression with profiler events (no-op unless profiling is on)
+#define PROF(h, st, cat, expr)                                                       \
+    do {                                                                             \
+        hipEvent_t e0_ = nullptr, e1_ = nullptr;                                     \
+        if ((h)->profile) {                                                          \
+            ProfCat* pc_ = (h)->prof_cat(cat);                                       \
+            if (pc_->used == pc_->ev.size()) {                                       \
+                hipEvent_t a_, b_;                                                   \
+                HIPCHK(h, hipEventCreate(&a_)); HIPCHK(h, hipEventCreate(&b_));      \
+                pc_->ev.push_back({a_, b_});                                         \
+            }                                                                        \
+            e0_ = pc_->ev[pc_->used].first; e1_ = pc_->ev[pc_->used].second;         \
+            pc_->used++;                                                             \
+            HIPCHK(h, hipEventRecord(e0_, st));                                      \
+        }                                                                            \
+        HIPCHK(h, expr);                                                             \
+        if (e1_) HIPCHK(h, hipEventRecord(e1_, st));                                 \
     } while (0)
 
 template <typename T>
@@ -246,11 +275,11 @@ int ensure_workspace(iodine_handle* h, int B, int mode)
 int decoder_forward(iodine_handle* h, hipStream_t st, int N)
 {
     Buffers& b = h->buf;
-    HIPCHK(h, launch_dec_l0(st, b.V, h->cmap, b.act[0], N, h->S, h->Cd));
+    PROF(h, st, "dec_l0", launch_dec_l0(st, b.V, h->cmap, b.act[0], N, h->S, h->Cd));
     for (int l = 1; l < h->Dd; ++l)
-        HIPCHK(h, launch_conv3x3_tile(st, b.act[l - 1], h->dec_wf[l], h->dec_b[l], nullptr, b.act[l], N, h->S, h->Cd,
-                                      h->Cd, EPI_BIAS_ELU));
-    HIPCHK(h, launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, b.dec_out, N, h->S, h->Cd));
+        PROF(h, st, "conv_tile_fwd", launch_conv3x3_tile(st, b.act[l - 1], h->dec_wf[l], h->dec_b[l], nullptr, b.act[l],
+                                                         N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
+    PROF(h, st, "dec_out", launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, b.dec_out, N, h->S, h->Cd));
     return IODINE_OK;
 }
 
@@ -260,11 +289,11 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
 {
     Buffers& b = h->buf;
     int cur = 0;
-    HIPCHK(h, launch_conv3x3_tile(st, b.g, h->dec_out_wb, nullptr, b.act[h->Dd - 1], b.dpre[cur], N, h->S, 4, h->Cd,
-                                  EPI_MUL_ELUGRAD));
+    PROF(h, st, "dec_out_dgrad", launch_conv3x3_tile(st, b.g, h->dec_out_wb, nullptr, b.act[h->Dd - 1], b.dpre[cur], N,
+                                                     h->S, 4, h->Cd, EPI_MUL_ELUGRAD));
     for (int l = h->Dd - 1; l >= 1; --l) {
-        HIPCHK(h, launch_conv3x3_tile(st, b.dpre[cur], h->dec_wb[l], nullptr, b.act[l - 1], b.dpre[cur ^ 1], N, h->S,
-                                      h->Cd, h->Cd, EPI_MUL_ELUGRAD));
+        PROF(h, st, "conv_tile_dgrad", launch_conv3x3_tile(st, b.dpre[cur], h->dec_wb[l], nullptr, b.act[l - 1],
+                                                           b.dpre[cur ^ 1], N, h->S, h->Cd, h->Cd, EPI_MUL_ELUGRAD));
         cur ^= 1;
     }
     *dpre0 = b.dpre[cur];
@@ -279,14 +308,14 @@ int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps
     HIPCHK(h, launch_dec_v(st, b.pm, b.plv, eps_i, nullptr, h->wcls, b.z[i], b.V, N, h->L, h->Cd));
     int rc = decoder_forward(h, st, N);
     if (rc) return rc;
-    HIPCHK(h, launch_pixel_pass1(st, b.x4, b.dec_out, b.g, b.part, B, h->K, h->P, (float)h->cfg.sigma));
+    PROF(h, st, "pixel_pass1", launch_pixel_pass1(st, b.x4, b.dec_out, b.g, b.part, B, h->K, h->P, (float)h->cfg.sigma));
     HIPCHK(h, launch_pixel_finalize(st, b.part, B, h->K, h->P, h->cfg.layernorm, b.lnstat, b.ll_img));
     HIPCHK(h, launch_elbo(st, b.pm, b.plv, b.ll_img, B, h->K, h->L, b.img_terms + (size_t)i * B * 2, b.scal + 3 * i));
     if (!need_grads) return IODINE_OK;
     float* dpre0 = nullptr;
     rc = decoder_backward_data(h, st, N, &dpre0);
     if (rc) return rc;
-    HIPCHK(h, launch_l0_reduce(st, dpre0, b.rows, b.Rc, N, h->S, h->Cd));
+    PROF(h, st, "l0_reduce", launch_l0_reduce(st, dpre0, b.rows, b.Rc, N, h->S, h->Cd));
     HIPCHK(h, launch_dz_latent(st, b.Rc, h->wclsT, b.pm, b.plv, eps_i, N, h->L, h->Cd, h->cfg.layernorm, b.g_pm[i],
                                b.g_plv[i], b.latent[i]));
     return IODINE_OK;
@@ -297,16 +326,17 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
 {
     Buffers& b = h->buf;
     const int N = B * h->K;
-    HIPCHK(h, launch_pixel_pass2(st, b.x4, b.dec_out, b.lnstat, h->lin, b.enc[i], B, h->K, h->S, (float)h->cfg.sigma));
+    PROF(h, st, "pixel_pass2", launch_pixel_pass2(st, b.x4, b.dec_out, b.lnstat, h->lin, b.enc[i], B, h->K, h->S,
+                                                  (float)h->cfg.sigma));
     int s = h->S;
     const float* in = b.enc[i];
     for (int l = 0; l < h->Dr; ++l) {
-        HIPCHK(h, launch_conv3x3_gather(st, in, h->ref_w[l], h->ref_b[l], b.ract[i][l], N, s, s, l == 0 ? 20 : h->Cr,
-                                        h->Cr, 2));
+        PROF(h, st, "refine_conv", launch_conv3x3_gather(st, in, h->ref_w[l], h->ref_b[l], b.ract[i][l], N, s, s,
+                                                         l == 0 ? 20 : h->Cr, h->Cr, 2));
         in = b.ract[i][l];
         s = ref_out_size(s);
     }
-    HIPCHK(h, launch_refine_head(st, in, N, s * s, h->Cr, h->H, h->L, h->mlp_wT, h->mlp_b, h->wihT, h->whhT, h->lstm_b,
+    PROF(h, st, "refine_head", launch_refine_head(st, in, N, s * s, h->Cr, h->H, h->L, h->mlp_wT, h->mlp_b, h->wihT, h->whhT, h->lstm_b,
                                  h->wmT, h->bm, h->wvT, h->bv, b.latent[i], b.h[i], b.c[i], b.h[i + 1], b.c[i + 1], b.pm,
                                  b.plv, save ? b.pooled[i] : nullptr, save ? b.u[i] : nullptr,
                                  save ? b.gates[i] : nullptr, nullptr, nullptr));
@@ -384,6 +414,7 @@ void iodine_destroy(iodine_handle* h)
 {
     if (!h) return;
     for (void* p : h->owned) (void)hipFree(p);
+    for (auto& c : h->prof) for (auto& e : c.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->ws_own) (void)hipFree(h->ws_own);
     delete h;
 }
@@ -465,6 +496,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
 {
     if (!h || !key) return IODINE_ERR_INVALID;
     if (!strcmp(key, "stop_after_iters")) { h->stop_after = (int)value; return IODINE_OK; }
+    if (!strcmp(key, "profile")) { h->profile = value != 0; return IODINE_OK; }
     return h->fail(IODINE_ERR_INVALID, std::string("unknown option ") + key);
 }
 
@@ -574,6 +606,25 @@ int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter
         if (n > max_floats) return h->fail(IODINE_ERR_INVALID, "iodine_debug_copy: destination too small");
         HIPCHK(h, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
+    return IODINE_OK;
+}
+
+int iodine_profile_read(iodine_handle* h, const char* category, double* total_ms, long long* launches, int reset)
+{
+    if (!h || !category) return IODINE_ERR_INVALID;
+    double tot = 0.0; long long cnt = 0;
+    for (auto& c : h->prof) {
+        if (c.name != category) continue;
+        for (size_t i = 0; i < c.used; ++i) {
+            HIPCHK(h, hipEventSynchronize(c.ev[i].second));
+            float ms = 0.f;
+            HIPCHK(h, hipEventElapsedTime(&ms, c.ev[i].first, c.ev[i].second));
+            tot += ms; ++cnt;
+        }
+        if (reset) c.used = 0;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = cnt;
     return IODINE_OK;
 }
 

@@ -263,6 +263,13 @@ class IODINE(nn.Module):
         if self._handle is not None:
             _lib.check(_lib.lib().iodine_set_option(self._handle, key.encode(), float(value)), self._handle)
 
+    def profile_read(self, category: str, reset: bool = True):
+        """(total_ms, launches) of one kernel category measured with HIP events (set_option('profile', 1))."""
+        tot, cnt = C.c_double(), C.c_longlong()
+        _lib.check(_lib.lib().iodine_profile_read(self._handle, category.encode(), C.byref(tot), C.byref(cnt),
+                                                  int(reset)), self._handle)
+        return tot.value, cnt.value
+
     # ---- inference: iodine.py:59-112 ------------------------------------------------------------
     @torch.no_grad()
     def _reconstruct(self, x, eps, want_images=True):
