@@ -70,8 +70,34 @@ hipError_t launch_refine_head(hipStream_t st, const float* feat, int N, int PL, 
                               const float* mlp_wT, const float* mlp_b, const float* wihT, const float* whhT,
                               const float* lstm_b, const float* wmT, const float* bm, const float* wvT, const float* bv,
                               const float* latent, const float* h_prev, const float* c_prev, float* h_out, float* c_out,
-                              float* pm, float* plv, float* sv_pooled, float* sv_u, float* sv_gates, float* d_mean,
-                              float* d_logvar);
+                              float* pm, float* plv, float* sv_pooled, float* sv_s, float* sv_gates, float* sv_xin,
+                              float* d_mean, float* d_logvar);
 hipError_t launch_transpose(hipStream_t st, const float* src, float* dst, int R, int Cc);
 hipError_t launch_add2(hipStream_t st, const float* a, const float* b, float* o, int n);
 hipError_t launch_pack_dec_out(hipStream_t st, const float* w, float* wk, int C);
+hipError_t launch_conv3x3_gather_dgrad(hipStream_t st, const float* d, const float* wpk, const float* aux, float* out,
+                                       int N, int big_h, int big_w, int c, int stride);
+// kernels_train.hip
+int wgrad_tile_blocks(int N, int S);
+hipError_t launch_conv3x3_wgrad_tile(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
+                                     int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts);
+hipError_t launch_conv3x3_wgrad_gather(hipStream_t st, const float* in, const float* d, float* part, int N, int IH,
+                                       int IW, int cip, int co, int stride, int* nparts, int* cipad);
+hipError_t launch_wgrad_reduce(hipStream_t st, const float* part, int nparts, int ci_pad, int co_pad, int O_real,
+                               int I_real, int I_dst, float alpha, float* dst);
+hipError_t launch_colsum(hipStream_t st, const float* src, int rows, int cols, int ld, float alpha, float* dst);
+hipError_t launch_sgemm(hipStream_t st, int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
+                        const float* B, int ldb, float beta, float* C, int ldc);
+hipError_t launch_sum_over_slots(hipStream_t st, const float* dpre, float* D, int N, int P, int C);
+hipError_t launch_l0_tap_sums(hipStream_t st, const float* Rc, float* RT, int N, int C);
+hipError_t launch_l0_scatter_z(hipStream_t st, const float* tmp, int L, int C, float alpha, float* gw);
+hipError_t launch_l0_coord_grads(hipStream_t st, const float* D, const float* lin, int S, int C, int L, float alpha,
+                                 float* gw, float* gb);
+hipError_t launch_loss(hipStream_t st, const float* scal, int n, float* loss);
+hipError_t launch_scale(hipStream_t st, const float* a, float alpha, float* o, int n);
+hipError_t launch_axpy(hipStream_t st, const float* x, float alpha, float* y, int n);
+hipError_t launch_lstm_bwd_pointwise(hipStream_t st, const float* gates, const float* c0, const float* c1,
+                                     const float* dc1_read, const float* dh1, const float* dc1_carry, float* dgates,
+                                     float* dc0, int N, int H);
+hipError_t launch_mlp_bwd_pointwise(hipStream_t st, const float* du, int ldu, const float* s, float* ds, int N, int H);
+hipError_t launch_pool_bwd(hipStream_t st, const float* dpooled, const float* act, float* dpre, int N, int PL, int C);

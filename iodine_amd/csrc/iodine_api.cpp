@@ -42,8 +42,15 @@ struct Buffers {               // workspace carve-up for one batch size / mode
     std::vector<float*> act;                   // decoder activations a[0..Dd-1]   (N,P,Cd)
     float* dpre[2];                            // ping-pong gradient wrt pre-activations
     // per-iteration buffers: index i (training keeps all T(+1) copies, inference aliases them)
-    std::vector<float*> z, g_pm, g_plv, latent, enc, pooled, u, gates, h, c;
+    std::vector<float*> z, g_pm, g_plv, latent, enc, pooled, u, gates, xin, h, c;
     std::vector<std::vector<float*>> ract;     // [iter][layer] refinement activations
+    // training only
+    float *wg_part = nullptr, *wg_part_b = nullptr, *Dsum = nullptr, *RT = nullptr, *tmp_lz = nullptr;
+    float *ddm = nullptr, *ddv = nullptr, *dc1 = nullptr, *dgates = nullptr, *dxin = nullptr, *ds = nullptr,
+          *dpooled = nullptr;
+    float* carry_h[2] = {nullptr, nullptr};
+    float* carry_c[2] = {nullptr, nullptr};
+    std::vector<float*> rdpre;                 // gradient wrt refinement pre-activations, per layer
 };
 
 }  // namespace
@@ -74,6 +81,12 @@ struct iodine_handle {
     std::vector<float*> ref_w, ref_b;
     float *mlp_wT = nullptr, *mlp_b = nullptr, *wihT = nullptr, *whhT = nullptr, *lstm_b = nullptr;
     float *wmT = nullptr, *bm = nullptr, *wvT = nullptr, *bv = nullptr, *init_mean = nullptr, *init_logvar = nullptr;
+    // training: raw copies used by the head backward GEMMs, strided-dgrad packs, gradient accumulators
+    float *raw_mlp_w = nullptr, *raw_wih = nullptr, *raw_whh = nullptr, *raw_wm = nullptr, *raw_wv = nullptr;
+    std::vector<float*> ref_wb;
+    std::vector<float*> gacc;                   // one per parameter, reference shapes
+    bool fwd_done = false;
+    int fwd_batch = 0;
     std::vector<void*> owned;
 
     // workspace
@@ -225,6 +238,7 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
     per_iter(b.pooled, (size_t)N * Cr, ncopy);
     per_iter(b.u, (size_t)N * H, ncopy);
     per_iter(b.gates, (size_t)N * 4 * H, ncopy);
+    per_iter(b.xin, (size_t)N * (H + 4 * L), ncopy);
     // LSTM state: h[i], c[i] = state BEFORE iteration i; inference ping-pongs two copies
     b.h.resize(T + 2); b.c.resize(T + 2);
     if (mode == 1) {
@@ -241,6 +255,24 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
             s = ref_out_size(s);
             b.ract[i][l] = (i == 0 || (mode == 1 && i < T)) ? a.take<float>((size_t)N * s * s * Cr) : b.ract[0][l];
         }
+    }
+    if (mode == 1) {
+        const int Cmax = Cd > Cr ? Cd : Cr;
+        const size_t part_elems = (size_t)512 * 4 * 9 * 32 * 32 > (size_t)512 * 9 * Cmax * Cmax
+                                      ? (size_t)512 * 4 * 9 * 32 * 32 : (size_t)512 * 9 * Cmax * Cmax;
+        b.wg_part = a.take<float>(part_elems);
+        b.wg_part_b = a.take<float>((size_t)512 * 64);
+        b.Dsum = a.take<float>((size_t)P * Cd);
+        b.RT = a.take<float>((size_t)N * 9 * Cd);
+        b.tmp_lz = a.take<float>((size_t)L * 9 * Cd);
+        b.ddm = a.take<float>((size_t)N * L); b.ddv = a.take<float>((size_t)N * L);
+        b.dc1 = a.take<float>((size_t)N * H); b.dgates = a.take<float>((size_t)N * 4 * H);
+        b.dxin = a.take<float>((size_t)N * H); b.ds = a.take<float>((size_t)N * H);
+        b.dpooled = a.take<float>((size_t)N * Cr);
+        for (int j = 0; j < 2; ++j) { b.carry_h[j] = a.take<float>((size_t)N * H); b.carry_c[j] = a.take<float>((size_t)N * H); }
+        b.rdpre.resize(h->Dr);
+        int s = h->S;
+        for (int l = 0; l < h->Dr; ++l) { s = ref_out_size(s); b.rdpre[l] = a.take<float>((size_t)N * s * s * Cr); }
     }
     b.bytes = (a.off + 255) & ~(size_t)255;
 }
@@ -283,25 +315,65 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N)
     return IODINE_OK;
 }
 
-// gradient of B*ELBO wrt the decoder input z through the whole decoder (replaces the autograd traversal of
-// (B*elbo).backward(), iodine.py:90,137).  Leaves d(pre-activation) of layer 0 in the returned buffer.
-int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0)
+// reduce the partial tiles of the last wgrad launch into the accumulators of (weight, bias)
+int reduce_wgrad(iodine_handle* h, hipStream_t st, int nparts, int ci_pad, int co_pad, int O_real, int I_real,
+                 int I_dst, float alpha, int wparam, int bparam, int nbias_parts)
 {
     Buffers& b = h->buf;
-    int cur = 0;
-    PROF(h, st, "dec_out_dgrad", launch_conv3x3_tile(st, b.g, h->dec_out_wb, nullptr, b.act[h->Dd - 1], b.dpre[cur], N,
-                                                     h->S, 4, h->Cd, EPI_MUL_ELUGRAD));
-    for (int l = h->Dd - 1; l >= 1; --l) {
+    HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, ci_pad, co_pad, O_real, I_real, I_dst, alpha, h->gacc[wparam]));
+    if (nbias_parts > 0) HIPCHK(h, launch_colsum(st, b.wg_part_b, nbias_parts, O_real, O_real, alpha, h->gacc[bparam]));
+    return IODINE_OK;
+}
+
+// gradient of B*ELBO wrt the decoder input z through the whole decoder (replaces the autograd traversal of
+// (B*elbo).backward(), iodine.py:90,137).  Leaves d(pre-activation) of layer 0 in the returned buffer.
+// With train_alpha != 0 the decoder weight gradients of this pass are accumulated on the way with that factor
+// (= -w_i / B): they are what the outer loss.backward() (train.py:63) would compute for this decoder pass.
+int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0, float train_alpha, int it)
+{
+    Buffers& b = h->buf;
+    const int Cd = h->Cd, Dd = h->Dd;
+    int cur = 0, nparts = 0, ncop = 0, nb = 0, rc;
+    PROF(h, st, "dec_out_dgrad", launch_conv3x3_tile(st, b.g, h->dec_out_wb, nullptr, b.act[Dd - 1], b.dpre[cur], N,
+                                                     h->S, 4, Cd, EPI_MUL_ELUGRAD));
+    if (train_alpha != 0.f) {
+        PROF(h, st, "dec_out_wgrad", launch_conv3x3_wgrad_tile(st, b.act[Dd - 1], b.g, b.wg_part, b.wg_part_b, N, h->S,
+                                                                Cd, 4, &nparts, &ncop, &nb));
+        rc = reduce_wgrad(h, st, nparts, Cd, ncop, 4, Cd, Cd, train_alpha, param_index(h, "decoder.conv.weight"),
+                          param_index(h, "decoder.conv.bias"), nb);
+        if (rc) return rc;
+    }
+    for (int l = Dd - 1; l >= 1; --l) {
+        if (train_alpha != 0.f) {
+            PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_tile(st, b.act[l - 1], b.dpre[cur], b.wg_part, b.wg_part_b,
+                                                                      N, h->S, Cd, Cd, &nparts, &ncop, &nb));
+            const std::string base = "decoder.mlc.layers." + std::to_string(l);
+            rc = reduce_wgrad(h, st, nparts, Cd, ncop, Cd, Cd, Cd, train_alpha, param_index(h, base + ".weight"),
+                              param_index(h, base + ".bias"), nb);
+            if (rc) return rc;
+        }
         PROF(h, st, "conv_tile_dgrad", launch_conv3x3_tile(st, b.dpre[cur], h->dec_wb[l], nullptr, b.act[l - 1],
-                                                           b.dpre[cur ^ 1], N, h->S, h->Cd, h->Cd, EPI_MUL_ELUGRAD));
+                                                           b.dpre[cur ^ 1], N, h->S, Cd, Cd, EPI_MUL_ELUGRAD));
         cur ^= 1;
     }
     *dpre0 = b.dpre[cur];
+    PROF(h, st, "l0_reduce", launch_l0_reduce(st, *dpre0, b.rows, b.Rc, N, h->S, Cd));
+    if (train_alpha != 0.f) {
+        // layer 0 (spatial broadcast): latent-channel weights from z and the per-tap sums, coordinate channels
+        // and bias from the slot-summed gradient map
+        const int wi = param_index(h, "decoder.mlc.layers.0.weight"), bi = param_index(h, "decoder.mlc.layers.0.bias");
+        HIPCHK(h, launch_l0_tap_sums(st, b.Rc, b.RT, N, Cd));
+        HIPCHK(h, launch_sgemm(st, 1, 0, h->L, 9 * Cd, N, 1.f, b.z[it], h->L, b.RT, 9 * Cd, 0.f, b.tmp_lz, 9 * Cd));
+        HIPCHK(h, launch_l0_scatter_z(st, b.tmp_lz, h->L, Cd, train_alpha, h->gacc[wi]));
+        PROF(h, st, "l0_slot_sum", launch_sum_over_slots(st, *dpre0, b.Dsum, N, h->P, Cd));
+        HIPCHK(h, launch_l0_coord_grads(st, b.Dsum, h->lin, h->S, Cd, h->L, train_alpha, h->gacc[wi], h->gacc[bi]));
+    }
     return IODINE_OK;
 }
 
 // elbo() + inner backward + get_input_encoding for iteration i (iodine.py:85-93 / 133-142)
-int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps_i, int i, bool need_grads)
+int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps_i, int i, bool need_grads,
+                       float train_alpha = 0.f)
 {
     Buffers& b = h->buf;
     const int N = B * h->K;
@@ -313,9 +385,8 @@ int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps
     HIPCHK(h, launch_elbo(st, b.pm, b.plv, b.ll_img, B, h->K, h->L, b.img_terms + (size_t)i * B * 2, b.scal + 3 * i));
     if (!need_grads) return IODINE_OK;
     float* dpre0 = nullptr;
-    rc = decoder_backward_data(h, st, N, &dpre0);
+    rc = decoder_backward_data(h, st, N, &dpre0, train_alpha, i);
     if (rc) return rc;
-    PROF(h, st, "l0_reduce", launch_l0_reduce(st, dpre0, b.rows, b.Rc, N, h->S, h->Cd));
     HIPCHK(h, launch_dz_latent(st, b.Rc, h->wclsT, b.pm, b.plv, eps_i, N, h->L, h->Cd, h->cfg.layernorm, b.g_pm[i],
                                b.g_plv[i], b.latent[i]));
     return IODINE_OK;
@@ -339,7 +410,7 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
     PROF(h, st, "refine_head", launch_refine_head(st, in, N, s * s, h->Cr, h->H, h->L, h->mlp_wT, h->mlp_b, h->wihT, h->whhT, h->lstm_b,
                                  h->wmT, h->bm, h->wvT, h->bv, b.latent[i], b.h[i], b.c[i], b.h[i + 1], b.c[i + 1], b.pm,
                                  b.plv, save ? b.pooled[i] : nullptr, save ? b.u[i] : nullptr,
-                                 save ? b.gates[i] : nullptr, nullptr, nullptr));
+                                 save ? b.gates[i] : nullptr, save ? b.xin[i] : nullptr, nullptr, nullptr));
     return IODINE_OK;
 }
 
@@ -401,6 +472,12 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     ALLOC(h->wihT, (size_t)(H + 4 * L) * 4 * H); ALLOC(h->whhT, (size_t)H * 4 * H); ALLOC(h->lstm_b, (size_t)4 * H);
     ALLOC(h->wmT, (size_t)H * L); ALLOC(h->bm, (size_t)L); ALLOC(h->wvT, (size_t)H * L); ALLOC(h->bv, (size_t)L);
     ALLOC(h->init_mean, (size_t)L); ALLOC(h->init_logvar, (size_t)L);
+    ALLOC(h->raw_mlp_w, (size_t)H * Cr); ALLOC(h->raw_wih, (size_t)4 * H * (H + 4 * L)); ALLOC(h->raw_whh, (size_t)4 * H * H);
+    ALLOC(h->raw_wm, (size_t)L * H); ALLOC(h->raw_wv, (size_t)L * H);
+    h->ref_wb.assign(h->Dr, nullptr);
+    for (int l = 1; l < h->Dr; ++l) ALLOC(h->ref_wb[l], conv_wpk_elems(Cr, Cr) * 4);
+    h->gacc.assign(h->params.size(), nullptr);
+    for (size_t i = 0; i < h->params.size(); ++i) ALLOC(h->gacc[i], h->params[i].numel());
 #undef ALLOC
     std::vector<float> lin(h->S);
     iodine_linspace_host(h->S, lin.data());
@@ -460,6 +537,18 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         HIPCHK(h, hipMemcpyAsync(h->ref_b[l], P("refine.mlc.layers." + std::to_string(l) + ".bias"), sizeof(float) * Cr,
                                  hipMemcpyDeviceToDevice, st));
     }
+    for (int l = 1; l < h->Dr; ++l)
+        HIPCHK(h, launch_pack_conv_weights(st, P("refine.mlc.layers." + std::to_string(l) + ".weight"), Cr, Cr, Cr, Cr, 2,
+                                           h->ref_wb[l]));
+    auto copy_raw = [&](float* dst, const std::string& name) {
+        return hipMemcpyAsync(dst, P(name), sizeof(float) * h->params[param_index(h, name)].numel(),
+                              hipMemcpyDeviceToDevice, st);
+    };
+    HIPCHK(h, copy_raw(h->raw_mlp_w, "refine.mlp.layers.0.weight"));
+    HIPCHK(h, copy_raw(h->raw_wih, "refine.lstm.weight_ih"));
+    HIPCHK(h, copy_raw(h->raw_whh, "refine.lstm.weight_hh"));
+    HIPCHK(h, copy_raw(h->raw_wm, "refine.mean_update.weight"));
+    HIPCHK(h, copy_raw(h->raw_wv, "refine.logvar_update.weight"));
     // head
     HIPCHK(h, launch_transpose(st, P("refine.mlp.layers.0.weight"), h->mlp_wT, H, Cr));
     HIPCHK(h, hipMemcpyAsync(h->mlp_b, P("refine.mlp.layers.0.bias"), sizeof(float) * H, hipMemcpyDeviceToDevice, st));
@@ -473,6 +562,7 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     HIPCHK(h, hipMemcpyAsync(h->init_mean, P("posterior.init_mean"), sizeof(float) * L, hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipMemcpyAsync(h->init_logvar, P("posterior.init_logvar"), sizeof(float) * L, hipMemcpyDeviceToDevice, st));
     h->params_set = true;
+    h->fwd_done = false;
     return IODINE_OK;
 }
 
@@ -553,16 +643,108 @@ int iodine_decode(iodine_handle* h, void* stream, int batch, const float* z, flo
     return IODINE_OK;
 }
 
-int iodine_train_forward(iodine_handle* h, void*, int, const float*, const float*, float*, float*)
+int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float* x, const float* eps, float* loss,
+                         float* elbo_iter)
 {
-    if (!h) return IODINE_ERR_INVALID;
-    return h->fail(IODINE_ERR_STATE, "iodine_train_forward: not implemented in this build");
+    int rc = check_ready(h, batch);
+    if (rc) return rc;
+    if (!x || !eps || !loss) return h->fail(IODINE_ERR_INVALID, "iodine_train_forward: x, eps and loss are required");
+    rc = ensure_workspace(h, batch, 1);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    Buffers& b = h->buf;
+    const int B = batch, N = B * h->K, T = h->T, L = h->L;
+    const size_t eps_stride = (size_t)N * L;
+    h->fwd_done = false;
+    for (size_t i = 0; i < h->params.size(); ++i)
+        HIPCHK(h, hipMemsetAsync(h->gacc[i], 0, sizeof(float) * h->params[i].numel(), st));
+    HIPCHK(h, launch_x_to_nhwc4(st, x, b.x4, B, h->P));
+    HIPCHK(h, launch_posterior_init(st, h->init_mean, h->init_logvar, b.pm, b.plv, b.h[0], b.c[0], N, L, h->H));
+    for (int i = 0; i <= T; ++i) {
+        const float alpha = -((float)(i + 1) / (float)(T + 1)) / (float)B;      // d loss / d (B * ELBO_i)
+        rc = elbo_and_gradients(h, st, B, eps + (size_t)i * eps_stride, i, true, alpha);
+        if (rc) return rc;
+        if (i == 0) {
+            // lambda_0 = init_mean / init_logvar repeated over (B, K) (iodine.py:615-616): their gradient is the
+            // column sum of d loss / d lambda_0; later lambdas are detached from it (iodine.py:642-643)
+            HIPCHK(h, launch_colsum(st, b.g_pm[0], N, L, L, alpha, h->gacc[param_index(h, "posterior.init_mean")]));
+            HIPCHK(h, launch_colsum(st, b.g_plv[0], N, L, L, alpha, h->gacc[param_index(h, "posterior.init_logvar")]));
+        }
+        if (i < T) {
+            rc = refine_step(h, st, B, i, true);
+            if (rc) return rc;
+        }
+    }
+    HIPCHK(h, launch_loss(st, b.scal, T + 1, loss));
+    if (elbo_iter) HIPCHK(h, hipMemcpyAsync(elbo_iter, b.scal, sizeof(float) * 3 * (T + 1), hipMemcpyDeviceToDevice, st));
+    h->fwd_done = true;
+    h->fwd_batch = B;
+    return IODINE_OK;
 }
 
-int iodine_train_backward(iodine_handle* h, void*, float, float* const*, int)
+int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, float* const* param_grads, int n)
 {
     if (!h) return IODINE_ERR_INVALID;
-    return h->fail(IODINE_ERR_STATE, "iodine_train_backward: not implemented in this build");
+    if (!h->fwd_done) return h->fail(IODINE_ERR_STATE, "iodine_train_backward: no iodine_train_forward to differentiate");
+    if (n != (int)h->params.size() || !param_grads) return h->fail(IODINE_ERR_INVALID, "iodine_train_backward: wrong parameter count");
+    hipStream_t st = (hipStream_t)stream;
+    Buffers& b = h->buf;
+    const int B = h->fwd_batch, N = B * h->K, T = h->T, L = h->L, H = h->H, Cr = h->Cr, IN = H + 4 * L;
+    auto G = [&](const std::string& name) { return h->gacc[param_index(h, name)]; };
+    int cf = 0;                                            // carry buffer flip
+    for (int i = T - 1; i >= 0; --i) {
+        // d loss / d delta_i = -w_{i+1}/B * d(B*ELBO_{i+1})/d lambda_{i+1}   (lambda_{i+1} = detach(lambda_i) + delta_i)
+        const float alpha = -((float)(i + 2) / (float)(T + 1)) / (float)B;
+        HIPCHK(h, launch_scale(st, b.g_pm[i + 1], alpha, b.ddm, N * L));
+        HIPCHK(h, launch_scale(st, b.g_plv[i + 1], alpha, b.ddv, N * L));
+        const float* c1 = b.c[i + 1];
+        // read-out layers act on the cell state (iodine.py:488-492)
+        HIPCHK(h, launch_sgemm(st, 1, 0, L, H, N, 1.f, b.ddm, L, c1, H, 1.f, G("refine.mean_update.weight"), H));
+        HIPCHK(h, launch_sgemm(st, 1, 0, L, H, N, 1.f, b.ddv, L, c1, H, 1.f, G("refine.logvar_update.weight"), H));
+        HIPCHK(h, launch_colsum(st, b.ddm, N, L, L, 1.f, G("refine.mean_update.bias")));
+        HIPCHK(h, launch_colsum(st, b.ddv, N, L, L, 1.f, G("refine.logvar_update.bias")));
+        HIPCHK(h, launch_sgemm(st, 0, 0, N, H, L, 1.f, b.ddm, L, h->raw_wm, H, 0.f, b.dc1, H));
+        HIPCHK(h, launch_sgemm(st, 0, 0, N, H, L, 1.f, b.ddv, L, h->raw_wv, H, 1.f, b.dc1, H));
+        const bool last = (i == T - 1);
+        HIPCHK(h, launch_lstm_bwd_pointwise(st, b.gates[i], b.c[i], c1, b.dc1, last ? nullptr : b.carry_h[cf],
+                                            last ? nullptr : b.carry_c[cf], b.dgates, b.carry_c[cf ^ 1], N, H));
+        HIPCHK(h, launch_sgemm(st, 1, 0, 4 * H, IN, N, 1.f, b.dgates, 4 * H, b.xin[i], IN, 1.f, G("refine.lstm.weight_ih"), IN));
+        HIPCHK(h, launch_sgemm(st, 1, 0, 4 * H, H, N, 1.f, b.dgates, 4 * H, b.h[i], H, 1.f, G("refine.lstm.weight_hh"), H));
+        HIPCHK(h, launch_colsum(st, b.dgates, N, 4 * H, 4 * H, 1.f, G("refine.lstm.bias_ih")));
+        HIPCHK(h, launch_colsum(st, b.dgates, N, 4 * H, 4 * H, 1.f, G("refine.lstm.bias_hh")));
+        HIPCHK(h, launch_sgemm(st, 0, 0, N, H, 4 * H, 1.f, b.dgates, 4 * H, h->raw_whh, H, 0.f, b.carry_h[cf ^ 1], H));
+        cf ^= 1;
+        // MLP (double ELU) and average pool
+        HIPCHK(h, launch_sgemm(st, 0, 0, N, H, 4 * H, 1.f, b.dgates, 4 * H, h->raw_wih, IN, 0.f, b.dxin, H));
+        HIPCHK(h, launch_mlp_bwd_pointwise(st, b.dxin, H, b.u[i], b.ds, N, H));
+        HIPCHK(h, launch_sgemm(st, 1, 0, H, Cr, N, 1.f, b.ds, H, b.pooled[i], Cr, 1.f, G("refine.mlp.layers.0.weight"), Cr));
+        HIPCHK(h, launch_colsum(st, b.ds, N, H, H, 1.f, G("refine.mlp.layers.0.bias")));
+        HIPCHK(h, launch_sgemm(st, 0, 0, N, Cr, H, 1.f, b.ds, H, h->raw_mlp_w, Cr, 0.f, b.dpooled, Cr));
+        // conv stack, last layer first
+        std::vector<int> sz(h->Dr + 1);
+        sz[0] = h->S;
+        for (int l = 0; l < h->Dr; ++l) sz[l + 1] = ref_out_size(sz[l]);
+        const int sl = sz[h->Dr];
+        HIPCHK(h, launch_pool_bwd(st, b.dpooled, b.ract[i][h->Dr - 1], b.rdpre[h->Dr - 1], N, sl * sl, Cr));
+        for (int l = h->Dr - 1; l >= 0; --l) {
+            const float* in = l == 0 ? b.enc[i] : b.ract[i][l - 1];
+            const int cip = l == 0 ? 20 : Cr, ireal = l == 0 ? 17 : Cr;
+            int nparts = 0, cipad = 0;
+            PROF(h, st, "refine_wgrad", launch_conv3x3_wgrad_gather(st, in, b.rdpre[l], b.wg_part, N, sz[l], sz[l], cip, Cr, 2,
+                                                                    &nparts, &cipad));
+            const std::string base = "refine.mlc.layers." + std::to_string(l);
+            HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, G(base + ".weight")));
+            HIPCHK(h, launch_colsum(st, b.rdpre[l], N * sz[l + 1] * sz[l + 1], Cr, Cr, 1.f, G(base + ".bias")));
+            if (l > 0)
+                PROF(h, st, "refine_dgrad", launch_conv3x3_gather_dgrad(st, b.rdpre[l], h->ref_wb[l], b.ract[i][l - 1],
+                                                                        b.rdpre[l - 1], N, sz[l], sz[l], Cr, 2));
+        }
+    }
+    for (size_t p = 0; p < h->params.size(); ++p) {
+        if (!param_grads[p]) continue;
+        HIPCHK(h, launch_axpy(st, h->gacc[p], grad_scale, param_grads[p], (int)h->params[p].numel()));
+    }
+    return IODINE_OK;
 }
 
 int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter, float* dst, size_t max_floats,

@@ -28,8 +28,10 @@ __global__ void pack_conv_weights_kernel(const float* __restrict__ src, int O, i
         if (q < nq) {
             if (!tflip) {                       // forward: conv-in = I axis, conv-out = O axis
                 if (ci < I && co < O) v = src[((size_t)co * I + ci) * 9 + tap];
-            } else {                            // dgrad: conv-in = O axis, conv-out = I axis, taps flipped
+            } else if (tflip == 1) {            // stride-1 dgrad: conv-in = O axis, conv-out = I axis, taps flipped
                 if (ci < O && co < I) v = src[((size_t)ci * I + co) * 9 + (8 - tap)];
+            } else {                            // strided (transposed-conv) dgrad: axes swapped, taps as they are
+                if (ci < O && co < I) v = src[((size_t)ci * I + co) * 9 + tap];
             }
         }
         dst[idx] = v;
@@ -195,10 +197,14 @@ hipError_t launch_conv3x3_tile(hipStream_t st, const float* in, const float* wpk
 //   global memory (L1/L2 absorb the 9/stride^2 re-reads), weights chunk-staged in LDS.
 //   block = 256 threads, 4 waves x 32 output pixels; epilogue bias + ELU.
 // =========================================================================================
-template <int CIN, int COUT, int STRIDE>
+// MODE 0: forward conv (in = layer input, out = layer output, epilogue bias + ELU).
+// MODE 1: data gradient of the same strided conv (in = d(pre-activation) of the layer, (IH, IW) its size;
+//         out = gradient wrt the layer input of size (OH, OW), epilogue multiplies by ELU'(aux)):
+//         dIn[q] = sum_tap d[(q + 1 - tap) / STRIDE] . W[:, :, tap] over the taps where the division is exact.
+template <int CIN, int COUT, int STRIDE, int MODE>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_gather_kernel(const float* __restrict__ in, const float4* __restrict__ wpk,
-                           const float* __restrict__ bias, float* __restrict__ out,
+                           const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
                            int M, int IH, int IW, int OH, int OW)
 {
     constexpr int CC = conv_cc(CIN);
@@ -221,7 +227,7 @@ void conv3x3_gather_kernel(const float* __restrict__ in, const float4* __restric
     const int oy = t % OH;
     const int n = t / OH;
     const float* in_n = in + (size_t)n * IH * IW * CIN;
-    const int iy0 = oy * STRIDE - 1, ix0 = ox * STRIDE - 1;
+    const int iy0 = MODE == 0 ? oy * STRIDE - 1 : oy + 1, ix0 = MODE == 0 ? ox * STRIDE - 1 : ox + 1;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -239,9 +245,17 @@ void conv3x3_gather_kernel(const float* __restrict__ in, const float4* __restric
             const int q = 2 * g + half;
             const int qa = q < NQ ? q : NQ - 1;
             const int tap = qa / QPT, cig = qa % QPT;
-            const int iy = iy0 + tap / 3, ix = ix0 + tap % 3;
+            int iy, ix;
+            bool ok = mvalid && q < NQ;
+            if (MODE == 0) {
+                iy = iy0 + tap / 3; ix = ix0 + tap % 3;
+            } else {
+                const int ty2 = iy0 - tap / 3, tx2 = ix0 - tap % 3;          // = STRIDE * (source index) when exact
+                ok = ok && ty2 >= 0 && tx2 >= 0 && (ty2 % STRIDE) == 0 && (tx2 % STRIDE) == 0;
+                iy = ty2 / STRIDE; ix = tx2 / STRIDE;
+            }
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mvalid && q < NQ && iy >= 0 && iy < IH && ix >= 0 && ix < IW)
+            if (ok && iy >= 0 && iy < IH && ix >= 0 && ix < IW)
                 a = *reinterpret_cast<const float4*>(in_n + ((size_t)iy * IW + ix) * CIN + chunk * CC + cig * 4);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -257,11 +271,14 @@ void conv3x3_gather_kernel(const float* __restrict__ in, const float4* __restric
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = nt * 32 + li;
-        const float bv = bias[co];
+        const float bv = MODE == 0 ? bias[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int mm = blockIdx.x * 128 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (mm < M) out[(size_t)mm * COUT + co] = elu1(acc[nt][r] + bv);
+            if (mm < M) {
+                const size_t o = (size_t)mm * COUT + co;
+                out[o] = MODE == 0 ? elu1(acc[nt][r] + bv) : acc[nt][r] * elu1_grad_from_out(aux[o]);
+            }
         }
     }
 }
@@ -273,9 +290,31 @@ static hipError_t launch_gather_inst(hipStream_t st, const float* in, const floa
     constexpr size_t lds = (size_t)conv_nqp(CIN) * COUT * 16;
     const int OH = (IH + 2 - 3) / STRIDE + 1, OW = (IW + 2 - 3) / STRIDE + 1;
     const int M = N * OH * OW;
-    hipLaunchKernelGGL((conv3x3_gather_kernel<CIN, COUT, STRIDE>), dim3((M + 127) / 128), dim3(256), lds, st, in,
-                       reinterpret_cast<const float4*>(wpk), bias, out, M, IH, IW, OH, OW);
+    hipLaunchKernelGGL((conv3x3_gather_kernel<CIN, COUT, STRIDE, 0>), dim3((M + 127) / 128), dim3(256), lds, st, in,
+                       reinterpret_cast<const float4*>(wpk), bias, nullptr, out, M, IH, IW, OH, OW);
     return hipGetLastError();
+}
+
+// data gradient of a strided conv whose INPUT was (big_h, big_w): d has the conv's output size
+template <int CIN, int COUT, int STRIDE>
+static hipError_t launch_gather_dgrad_inst(hipStream_t st, const float* d, const float* wpk, const float* aux,
+                                           float* out, int N, int big_h, int big_w)
+{
+    constexpr size_t lds = (size_t)conv_nqp(CIN) * COUT * 16;
+    const int dh = (big_h - 1) / STRIDE + 1, dw = (big_w - 1) / STRIDE + 1;
+    const int M = N * big_h * big_w;
+    hipLaunchKernelGGL((conv3x3_gather_kernel<CIN, COUT, STRIDE, 1>), dim3((M + 127) / 128), dim3(256), lds, st, d,
+                       reinterpret_cast<const float4*>(wpk), nullptr, aux, out, M, dh, dw, big_h, big_w);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_gather_dgrad(hipStream_t st, const float* d, const float* wpk, const float* aux, float* out,
+                                       int N, int big_h, int big_w, int c, int stride)
+{
+    if (stride != 2) return hipErrorInvalidValue;
+    if (c == 64) return launch_gather_dgrad_inst<64, 64, 2>(st, d, wpk, aux, out, N, big_h, big_w);
+    if (c == 32) return launch_gather_dgrad_inst<32, 32, 2>(st, d, wpk, aux, out, N, big_h, big_w);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_conv3x3_gather(hipStream_t st, const float* in, const float* wpk, const float* bias,

@@ -325,8 +325,8 @@ hipError_t launch_elbo(hipStream_t st, const float* pm, const float* plv, const 
 //   avg-pool -> Linear(C->H) -> ELU(ELU(.)) -> [u | latent] -> LSTMCell -> updates read from the CELL state c1
 //   (the reference's `(c, h) = lstm(...)` names h1 "c" and c1 "h") -> lambda += delta (iodine.py:642-643).
 // One block per slot; weights pre-transposed to [in][out] so lane j streams column j coalesced.
-//   saved (training): pooled[n][C], u[n][H], gates[n][4H] (post-activation i,f,g,o), c_prev copy not needed
-//   (state buffers are per-iteration in training mode).
+//   saved (training): pooled[n][C], s[n][H] (MLP pre-activation), gates[n][4H] (post-activation i,f,g,o),
+//   xin[n][H+4L] (LSTM input); the state buffers are per-iteration in training mode.
 // -----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, int C, int H, int L,
@@ -339,8 +339,8 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
                         const float* __restrict__ h_prev, const float* __restrict__ c_prev,
                         float* __restrict__ h_out, float* __restrict__ c_out,
                         float* __restrict__ pm, float* __restrict__ plv,
-                        float* __restrict__ sv_pooled, float* __restrict__ sv_u, float* __restrict__ sv_gates,
-                        float* __restrict__ d_mean_out, float* __restrict__ d_logvar_out)
+                        float* __restrict__ sv_pooled, float* __restrict__ sv_s, float* __restrict__ sv_gates,
+                        float* __restrict__ sv_xin, float* __restrict__ d_mean_out, float* __restrict__ d_logvar_out)
 {
     extern __shared__ float sm[];
     float* s_pool = sm;                 // C
@@ -372,11 +372,13 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
         for (int c = 0; c < C; ++c) s = fmaf(s_pool[c], mlp_wT[(size_t)c * H + j], s);
         const float u = elu1(elu1(s));
         s_x[j] = u;
-        if (sv_u) sv_u[(size_t)n * H + j] = u;
+        if (sv_s) sv_s[(size_t)n * H + j] = s;                   // pre-activation (training backward recomputes the ELUs)
         s_h[j] = h_prev[(size_t)n * H + j];
     }
     for (int j = tid; j < 4 * L; j += 256) s_x[H + j] = latent[(size_t)n * 4 * L + j];
     __syncthreads();
+    if (sv_xin)
+        for (int j = tid; j < H + 4 * L; j += 256) sv_xin[(size_t)n * (H + 4 * L) + j] = s_x[j];
     // LSTM cell, gate order i, f, g, o (torch.nn.LSTMCell)
     const int IN = H + 4 * L, H4 = 4 * H;
     for (int j = tid; j < H; j += 256) {
@@ -421,14 +423,14 @@ hipError_t launch_refine_head(hipStream_t st, const float* feat, int N, int PL, 
                               const float* mlp_wT, const float* mlp_b, const float* wihT, const float* whhT,
                               const float* lstm_b, const float* wmT, const float* bm, const float* wvT, const float* bv,
                               const float* latent, const float* h_prev, const float* c_prev, float* h_out, float* c_out,
-                              float* pm, float* plv, float* sv_pooled, float* sv_u, float* sv_gates, float* d_mean,
-                              float* d_logvar)
+                              float* pm, float* plv, float* sv_pooled, float* sv_s, float* sv_gates, float* sv_xin,
+                              float* d_mean, float* d_logvar)
 {
     if (256 % C != 0) return hipErrorInvalidValue;
     const size_t lds = (size_t)(C + (H + 4 * L) + H + H + 256) * sizeof(float);
     hipLaunchKernelGGL(refine_head_kernel, dim3(N), dim3(256), lds, st, feat, PL, C, H, L, mlp_wT, mlp_b, wihT, whhT,
-                       lstm_b, wmT, bm, wvT, bv, latent, h_prev, c_prev, h_out, c_out, pm, plv, sv_pooled, sv_u,
-                       sv_gates, d_mean, d_logvar);
+                       lstm_b, wmT, bm, wvT, bv, latent, h_prev, c_prev, h_out, c_out, pm, plv, sv_pooled, sv_s,
+                       sv_gates, sv_xin, d_mean, d_logvar);
     return hipGetLastError();
 }
 

@@ -1,0 +1,538 @@
+// Training-only kernels: weight gradients of the conv stacks (fp32 MFMA, reduction over pixels),
+// parameter gradients of the spatial-broadcast layer, and the small dense algebra of the
+// refinement head's backward (LSTM BPTT).
+//
+// They replace what autograd does for the outer ``loss.backward()`` (lib/engine/train.py:63) on the
+// graph built by IODINE.forward (lib/modeling/iodine.py:115-158).  Because every ELBO_i reaches the
+// decoder parameters only through decoder pass i, and the inner backward of iteration i already
+// produced d(B*ELBO_i)/d(pre-activations) for every decoder layer, the decoder weight gradients are
+// accumulated during the forward loop with the factor -w_i/B (w_i = (i+1)/(T+1), iodine.py:151-153);
+// the refinement network is back-propagated through time afterwards (inputs are detached,
+// iodine.py:343; lambda is detached before the additive update, iodine.py:642-643).
+#include "common.h"
+
+// =========================================================================================
+// stride-1 3x3 weight gradient, LDS-tiled:  dW[tap][ci][co] = sum_{n,p} a[n, p+tap, ci] * d[n, p, co]
+//   GEMM view per tap: M = ci, N = co, K = pixels.  Block = 4 waves, persistent over 8x16-pixel tiles;
+//   wave -> (ci half, co half, pixel split); each wave keeps the 9 taps' 32x32 accumulators (144 regs).
+//   Partial sums go to part[(block*KS + ks)][tap][ci][co_pad]; a second kernel reduces them in fixed order.
+// =========================================================================================
+template <int CI, int NCO>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_wgrad_tile_kernel(const float* __restrict__ a, const float* __restrict__ d, float* __restrict__ part,
+                               float* __restrict__ part_b, int S, int ntiles, int tiles_x, int tiles_y)
+{
+    constexpr int MT = CI / 32;
+    constexpr int NTT = (NCO + 31) / 32;
+    constexpr int KS = 4 / (MT * NTT);
+    constexpr int NCOP = NTT * 32;
+    constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2;
+    constexpr int A4 = CI / 4, D4 = NCO / 4;
+    constexpr int PXW = (TH * TW) / KS;                 // pixels per wave per tile
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_a = smem;                                   // HH*HW*CI
+    float* s_d = smem + HH * HW * CI;                    // TH*TW*NCO
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, li = lane & 31;
+    const int mi = wv % MT, ni = (wv / MT) % NTT, ks = wv / (MT * NTT);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int n = t / tiles_y;
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+        const float* a_n = a + (size_t)n * S * S * CI;
+        const float* d_n = d + (size_t)n * S * S * NCO;
+        __syncthreads();
+        for (int idx = tid; idx < HH * HW * A4; idx += 256) {
+            const int px = idx / A4, c4 = idx % A4;
+            const int gy = y0 + px / HW, gx = x0 + px % HW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < S && gx >= 0 && gx < S)
+                v = *reinterpret_cast<const float4*>(a_n + ((size_t)gy * S + gx) * CI + c4 * 4);
+            *reinterpret_cast<float4*>(s_a + px * CI + c4 * 4) = v;
+        }
+        for (int idx = tid; idx < TH * TW * D4; idx += 256) {
+            const int px = idx / D4, c4 = idx % D4;
+            const int gy = ty * TH + px / TW, gx = tx * TW + px % TW;
+            const float4 v = *reinterpret_cast<const float4*>(d_n + ((size_t)gy * S + gx) * NCO + c4 * 4);
+            *reinterpret_cast<float4*>(s_d + px * NCO + c4 * 4) = v;
+            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int s = 0; s < PXW / 2; ++s) {
+            const int px = ks * PXW + 2 * s + half;
+            const int r = px / TW, c = px % TW;
+            float bval = 0.f;
+            if (NCO >= 32 || li < NCO) bval = s_d[px * NCO + ni * 32 + li];
+            const float* ap = s_a + (r * HW + c) * CI + mi * 32 + li;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float aval = ap[((tap / 3) * HW + (tap % 3)) * CI];
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bval, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+
+    // partial dW: rows = ci (accumulator rows), cols = co (lane & 31)
+    float* pw = part + ((size_t)(blockIdx.x * KS + ks) * 9) * CI * NCOP;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            pw[((size_t)tap * CI + ci) * NCOP + ni * 32 + li] = acc[tap][r];
+        }
+    // partial bias gradient: thread's channel group is fixed (256 % D4 == 0)
+    __syncthreads();
+    float4* s_red = reinterpret_cast<float4*>(smem);
+    s_red[tid] = bsum;
+    __syncthreads();
+    if (tid < D4) {
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = tid; j < 256; j += D4) { const float4 v = s_red[j]; t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w; }
+        *reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * NCO + tid * 4) = t4;
+    }
+}
+
+int wgrad_tile_blocks(int N, int S) { const int nt = N * (S / 8) * (S / 16); return nt < 512 ? nt : 512; }
+
+template <int CI, int NCO>
+static hipError_t launch_wgrad_tile_inst(hipStream_t st, const float* a, const float* d, float* part, float* part_b,
+                                         int N, int S, int* nparts, int* ncop)
+{
+    constexpr int MT = CI / 32, NTT = (NCO + 31) / 32, KS = 4 / (MT * NTT);
+    constexpr size_t lds = (size_t)(10 * 18 * CI + 8 * 16 * NCO) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_tile_kernel<CI, NCO>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles_x = S / 16, tiles_y = S / 8, ntiles = N * tiles_x * tiles_y;
+    const int blocks = wgrad_tile_blocks(N, S);
+    hipLaunchKernelGGL((conv3x3_wgrad_tile_kernel<CI, NCO>), dim3(blocks), dim3(256), lds, st, a, d, part, part_b, S,
+                       ntiles, tiles_x, tiles_y);
+    *nparts = blocks * KS;
+    *ncop = NTT * 32;
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_wgrad_tile(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
+                                     int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts)
+{
+    if (S % 16 != 0) return hipErrorInvalidValue;
+    *nbias_parts = wgrad_tile_blocks(N, S);
+    if (ci == 64 && nco == 64) return launch_wgrad_tile_inst<64, 64>(st, a, d, part, part_b, N, S, nparts, ncop);
+    if (ci == 32 && nco == 32) return launch_wgrad_tile_inst<32, 32>(st, a, d, part, part_b, N, S, nparts, ncop);
+    if (ci == 64 && nco == 4) return launch_wgrad_tile_inst<64, 4>(st, a, d, part, part_b, N, S, nparts, ncop);
+    if (ci == 32 && nco == 4) return launch_wgrad_tile_inst<32, 4>(st, a, d, part, part_b, N, S, nparts, ncop);
+    return hipErrorInvalidValue;
+}
+
+// =========================================================================================
+// strided 3x3 weight gradient, operands gathered from global memory (refinement stack):
+//   dW[tap][ci][co] = sum_m in[n(m), STRIDE*o(m) + tap - 1, ci] * d[m, co],  m over all output pixels.
+// =========================================================================================
+template <int CIP, int CO, int STRIDE>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_wgrad_gather_kernel(const float* __restrict__ in, const float* __restrict__ d, float* __restrict__ part,
+                                 int M, int IH, int IW, int OH, int OW, int nchunks)
+{
+    constexpr int MT = (CIP + 31) / 32;
+    constexpr int NTT = CO / 32;
+    constexpr int KS = 4 / (MT * NTT);
+    constexpr int PXW = 128 / KS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, li = lane & 31;
+    const int mi = wv % MT, ni = (wv / MT) % NTT, ks = wv / (MT * NTT);
+    const int ci = mi * 32 + li;
+    const bool ci_ok = ci < CIP;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+#pragma unroll 2
+        for (int s = 0; s < PXW / 2; ++s) {
+            const int m = chunk * 128 + ks * PXW + 2 * s + half;
+            const bool valid = m < M;
+            int t = valid ? m : 0;
+            const int ox = t % OW; t /= OW;
+            const int oy = t % OH;
+            const int n = t / OH;
+            const float bval = valid ? d[(size_t)m * CO + ni * 32 + li] : 0.f;
+            const float* in_n = in + (size_t)n * IH * IW * CIP + ci;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int iy = oy * STRIDE + tap / 3 - 1, ix = ox * STRIDE + tap % 3 - 1;
+                float aval = 0.f;
+                if (valid && ci_ok && iy >= 0 && iy < IH && ix >= 0 && ix < IW) aval = in_n[((size_t)iy * IW + ix) * CIP];
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bval, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    constexpr int CIPAD = MT * 32;
+    float* pw = part + ((size_t)(blockIdx.x * KS + ks) * 9) * CIPAD * CO;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            pw[((size_t)tap * CIPAD + cr) * CO + ni * 32 + li] = acc[tap][r];
+        }
+}
+
+template <int CIP, int CO, int STRIDE>
+static hipError_t launch_wgrad_gather_inst(hipStream_t st, const float* in, const float* d, float* part, int N, int IH,
+                                           int IW, int* nparts, int* cipad)
+{
+    constexpr int MT = (CIP + 31) / 32, NTT = CO / 32, KS = 4 / (MT * NTT);
+    const int OH = (IH - 1) / STRIDE + 1, OW = (IW - 1) / STRIDE + 1;
+    const int M = N * OH * OW, nchunks = (M + 127) / 128;
+    const int blocks = nchunks < 512 ? nchunks : 512;
+    hipLaunchKernelGGL((conv3x3_wgrad_gather_kernel<CIP, CO, STRIDE>), dim3(blocks), dim3(256), 0, st, in, d, part, M, IH,
+                       IW, OH, OW, nchunks);
+    *nparts = blocks * KS;
+    *cipad = MT * 32;
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_wgrad_gather(hipStream_t st, const float* in, const float* d, float* part, int N, int IH,
+                                       int IW, int cip, int co, int stride, int* nparts, int* cipad)
+{
+    if (stride != 2) return hipErrorInvalidValue;
+    if (cip == 20 && co == 64) return launch_wgrad_gather_inst<20, 64, 2>(st, in, d, part, N, IH, IW, nparts, cipad);
+    if (cip == 64 && co == 64) return launch_wgrad_gather_inst<64, 64, 2>(st, in, d, part, N, IH, IW, nparts, cipad);
+    if (cip == 20 && co == 32) return launch_wgrad_gather_inst<20, 32, 2>(st, in, d, part, N, IH, IW, nparts, cipad);
+    if (cip == 32 && co == 32) return launch_wgrad_gather_inst<32, 32, 2>(st, in, d, part, N, IH, IW, nparts, cipad);
+    return hipErrorInvalidValue;
+}
+
+// fixed-order reduction of the partial tiles into an OIHW gradient:
+//   dst[co][ci_off + ci][tap] += alpha * sum_b part[b][tap][ci][co]      (ci < I_real, co < O_real)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int ci_pad, int co_pad, int O_real,
+                                    int I_real, int I_dst, float alpha, float* __restrict__ dst)
+{
+    const int total = 9 * ci_pad * co_pad;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int co = e % co_pad, ci = (e / co_pad) % ci_pad, tap = e / (co_pad * ci_pad);
+    if (co >= O_real || ci >= I_real) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nparts; b += 4) {
+        s0 += part[(size_t)b * total + e];
+        s1 += part[(size_t)(b + 1) * total + e];
+        s2 += part[(size_t)(b + 2) * total + e];
+        s3 += part[(size_t)(b + 3) * total + e];
+    }
+    for (; b < nparts; ++b) s0 += part[(size_t)b * total + e];
+    float* o = dst + ((size_t)co * I_dst + ci) * 9 + tap;
+    *o += alpha * ((s0 + s1) + (s2 + s3));
+}
+
+hipError_t launch_wgrad_reduce(hipStream_t st, const float* part, int nparts, int ci_pad, int co_pad, int O_real,
+                               int I_real, int I_dst, float alpha, float* dst)
+{
+    const int total = 9 * ci_pad * co_pad;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, nparts, ci_pad, co_pad,
+                       O_real, I_real, I_dst, alpha, dst);
+    return hipGetLastError();
+}
+
+// dst[c] += alpha * sum_r src[r][c]   (bias gradients, init_mean / init_logvar gradients, partial-bias reduction)
+__global__ void colsum_kernel(const float* __restrict__ src, int rows, int cols, int ld, float alpha, float* __restrict__ dst)
+{
+    __shared__ float s_red[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    float s = 0.f;
+    for (int r = tid; r < rows; r += 256) s += src[(size_t)r * ld + c];
+    s_red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) s_red[tid] += s_red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) dst[c] += alpha * s_red[0];
+}
+
+hipError_t launch_colsum(hipStream_t st, const float* src, int rows, int cols, int ld, float alpha, float* dst)
+{
+    hipLaunchKernelGGL(colsum_kernel, dim3(cols), dim3(256), 0, st, src, rows, cols, ld, alpha, dst);
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// generic small SGEMM (row-major): C[M][N] = alpha * op(A)[M][K] * op(B)[K][N] + beta * C, 16x16 LDS tiles.
+// Used for the head backward (N = B*K rows; at most a few hundred MFLOP per call).
+// =========================================================================================
+__global__ __launch_bounds__(256)
+void sgemm_kernel(int ta, int tb, int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
+                  const float* __restrict__ B, int ldb, float beta, float* __restrict__ Cm, int ldc)
+{
+    __shared__ float sA[16][17], sB[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const int ka = k0 + tx, kb = k0 + ty;
+        sA[ty][tx] = (row < M && ka < K) ? (ta ? A[(size_t)ka * lda + row] : A[(size_t)row * lda + ka]) : 0.f;
+        sB[ty][tx] = (kb < K && col < N) ? (tb ? B[(size_t)col * ldb + kb] : B[(size_t)kb * ldb + col]) : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fmaf(sA[ty][k], sB[k][tx], acc);
+        __syncthreads();
+    }
+    if (row < M && col < N) {
+        float* c = Cm + (size_t)row * ldc + col;
+        *c = alpha * acc + (beta != 0.f ? beta * *c : 0.f);
+    }
+}
+
+hipError_t launch_sgemm(hipStream_t st, int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
+                        const float* B, int ldb, float beta, float* C, int ldc)
+{
+    hipLaunchKernelGGL(sgemm_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, st, ta, tb, M, N, K, alpha, A, lda,
+                       B, ldb, beta, C, ldc);
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// spatial-broadcast layer parameter gradients
+// =========================================================================================
+// D[p][c] = sum_n dpre0[n][p][c]
+__global__ void sum_over_slots_kernel(const float4* __restrict__ dpre, float4* __restrict__ D, int N, size_t pc4)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pc4) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = 0; n < N; ++n) {
+        const float4 v = dpre[(size_t)n * pc4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    D[i] = s;
+}
+
+hipError_t launch_sum_over_slots(hipStream_t st, const float* dpre, float* D, int N, int P, int C)
+{
+    const size_t pc4 = (size_t)P * C / 4;
+    hipLaunchKernelGGL(sum_over_slots_kernel, dim3((unsigned)((pc4 + 255) / 256)), dim3(256), 0, st, (const float4*)dpre,
+                       (float4*)D, N, pc4);
+    return hipGetLastError();
+}
+
+// RT[n][tap][c] = sum over the border classes in which `tap` stays inside the image of Rc[n][cls][c]
+__global__ void l0_tap_sums_kernel(const float* __restrict__ Rc, float* __restrict__ RT, int N, int C)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 9 * C) return;
+    const int c = i % C, tap = (i / C) % 9, n = i / (9 * C);
+    const int dy = tap / 3, dx = tap % 3;
+    float s = 0.f;
+    for (int rc = 0; rc < 3; ++rc) {
+        if ((rc == 0 && dy == 0) || (rc == 2 && dy == 2)) continue;
+        for (int cc = 0; cc < 3; ++cc) {
+            if ((cc == 0 && dx == 0) || (cc == 2 && dx == 2)) continue;
+            s += Rc[((size_t)n * 9 + rc * 3 + cc) * C + c];
+        }
+    }
+    RT[i] = s;
+}
+
+hipError_t launch_l0_tap_sums(hipStream_t st, const float* Rc, float* RT, int N, int C)
+{
+    hipLaunchKernelGGL(l0_tap_sums_kernel, dim3((N * 9 * C + 255) / 256), dim3(256), 0, st, Rc, RT, N, C);
+    return hipGetLastError();
+}
+
+// gw[co][ci][tap] += alpha * tmp[ci][tap*C + co]  for the latent channels (tmp = z^T . RT)
+__global__ void l0_scatter_z_kernel(const float* __restrict__ tmp, int L, int C, float alpha, float* __restrict__ gw)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L * 9 * C) return;
+    const int co = i % C, tap = (i / C) % 9, ci = i / (9 * C);
+    gw[((size_t)co * (L + 2) + ci) * 9 + tap] += alpha * tmp[i];
+}
+
+hipError_t launch_l0_scatter_z(hipStream_t st, const float* tmp, int L, int C, float alpha, float* gw)
+{
+    hipLaunchKernelGGL(l0_scatter_z_kernel, dim3((L * 9 * C + 255) / 256), dim3(256), 0, st, tmp, L, C, alpha, gw);
+    return hipGetLastError();
+}
+
+// coordinate-channel weights and the bias of layer 0 from D[p][c]; one block per output channel
+__global__ __launch_bounds__(256)
+void l0_coord_grads_kernel(const float* __restrict__ D, const float* __restrict__ lin, int S, int C, int L, float alpha,
+                           float* __restrict__ gw, float* __restrict__ gb)
+{
+    __shared__ float s_red[256];
+    const int co = blockIdx.x, tid = threadIdx.x;
+    float acc[19];
+#pragma unroll
+    for (int j = 0; j < 19; ++j) acc[j] = 0.f;
+    for (int p = tid; p < S * S; p += 256) {
+        const float v = D[(size_t)p * C + co];
+        const int y = p / S, x = p % S;
+        acc[18] += v;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy < 0 || yy >= S || xx < 0 || xx >= S) continue;
+            acc[tap] += lin[xx] * v;
+            acc[9 + tap] += lin[yy] * v;
+        }
+    }
+    for (int j = 0; j < 19; ++j) {
+        s_red[tid] = acc[j];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) s_red[tid] += s_red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            if (j < 9) gw[((size_t)co * (L + 2) + L) * 9 + j] += alpha * s_red[0];
+            else if (j < 18) gw[((size_t)co * (L + 2) + L + 1) * 9 + (j - 9)] += alpha * s_red[0];
+            else gb[co] += alpha * s_red[0];
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_l0_coord_grads(hipStream_t st, const float* D, const float* lin, int S, int C, int L, float alpha,
+                                 float* gw, float* gb)
+{
+    hipLaunchKernelGGL(l0_coord_grads_kernel, dim3(C), dim3(256), 0, st, D, lin, S, C, L, alpha, gw, gb);
+    return hipGetLastError();
+}
+
+// =========================================================================================
+// loss and pointwise pieces of the head backward
+// =========================================================================================
+// loss = -sum_i (i+1)/(T+1) * ELBO_i   (iodine.py:151-158)
+__global__ void loss_kernel(const float* __restrict__ scal, int n, float* __restrict__ loss)
+{
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += (double)(i + 1) / n * scal[3 * i];
+        *loss = (float)(-s);
+    }
+}
+
+hipError_t launch_loss(hipStream_t st, const float* scal, int n, float* loss)
+{
+    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(64), 0, st, scal, n, loss);
+    return hipGetLastError();
+}
+
+__global__ void scale_kernel(const float* __restrict__ a, float alpha, float* __restrict__ o, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = alpha * a[i];
+}
+
+hipError_t launch_scale(hipStream_t st, const float* a, float alpha, float* o, int n)
+{
+    hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, alpha, o, n);
+    return hipGetLastError();
+}
+
+__global__ void axpy_kernel(const float* __restrict__ x, float alpha, float* __restrict__ y, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += alpha * x[i];
+}
+
+hipError_t launch_axpy(hipStream_t st, const float* x, float alpha, float* y, int n)
+{
+    hipLaunchKernelGGL(axpy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, alpha, y, n);
+    return hipGetLastError();
+}
+
+// LSTM cell backward, pointwise part.  gates = post-activation (i, f, g, o); c1 = f*c0 + i*g; h1 = o*tanh(c1).
+//   in : dc1 (from the update read-out), dh1 / dc1_carry (from the next iteration; may be NULL)
+//   out: dgates (pre-activation gradients, [N][4H]), dc0 (carry to the previous iteration)
+__global__ void lstm_bwd_pointwise_kernel(const float* __restrict__ gates, const float* __restrict__ c0,
+                                          const float* __restrict__ c1, const float* __restrict__ dc1_read,
+                                          const float* __restrict__ dh1, const float* __restrict__ dc1_carry,
+                                          float* __restrict__ dgates, float* __restrict__ dc0, int N, int H)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * H) return;
+    const int n = idx / H, j = idx % H;
+    const float* g = gates + (size_t)n * 4 * H;
+    const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
+    const float tc = tanhf(c1[idx]);
+    const float dh = dh1 ? dh1[idx] : 0.f;
+    float dc = dc1_read[idx] + (dc1_carry ? dc1_carry[idx] : 0.f);
+    dc += dh * go * (1.f - tc * tc);
+    float* dg = dgates + (size_t)n * 4 * H;
+    dg[j] = dc * gg * gi * (1.f - gi);
+    dg[H + j] = dc * c0[idx] * gf * (1.f - gf);
+    dg[2 * H + j] = dc * gi * (1.f - gg * gg);
+    dg[3 * H + j] = dh * tc * go * (1.f - go);
+    dc0[idx] = dc * gf;
+}
+
+hipError_t launch_lstm_bwd_pointwise(hipStream_t st, const float* gates, const float* c0, const float* c1,
+                                     const float* dc1_read, const float* dh1, const float* dc1_carry, float* dgates,
+                                     float* dc0, int N, int H)
+{
+    hipLaunchKernelGGL(lstm_bwd_pointwise_kernel, dim3((N * H + 255) / 256), dim3(256), 0, st, gates, c0, c1, dc1_read,
+                       dh1, dc1_carry, dgates, dc0, N, H);
+    return hipGetLastError();
+}
+
+// u = ELU(ELU(s)): ds = du * ELU'(y) * ELU'(s), y = ELU(s)     (iodine.py:485,565)
+__global__ void mlp_bwd_pointwise_kernel(const float* __restrict__ du, int ldu, const float* __restrict__ s,
+                                         float* __restrict__ ds, int N, int H)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * H) return;
+    const int n = idx / H, j = idx % H;
+    const float sv = s[idx];
+    const float y = elu1(sv);
+    const float g1 = sv > 0.f ? 1.f : y + 1.f;          // ELU'(s)
+    const float g2 = y > 0.f ? 1.f : expf(y);           // ELU'(y)
+    ds[idx] = du[(size_t)n * ldu + j] * g1 * g2;
+}
+
+hipError_t launch_mlp_bwd_pointwise(hipStream_t st, const float* du, int ldu, const float* s, float* ds, int N, int H)
+{
+    hipLaunchKernelGGL(mlp_bwd_pointwise_kernel, dim3((N * H + 255) / 256), dim3(256), 0, st, du, ldu, s, ds, N, H);
+    return hipGetLastError();
+}
+
+// avg-pool backward fused with the ELU derivative of the last refinement conv layer
+__global__ void pool_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ act, float* __restrict__ dpre,
+                                int PL, int C, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = i % C;
+    const size_t n = i / ((size_t)PL * C);
+    dpre[i] = dpooled[n * C + c] / (float)PL * elu1_grad_from_out(act[i]);
+}
+
+hipError_t launch_pool_bwd(hipStream_t st, const float* dpooled, const float* act, float* dpre, int N, int PL, int C)
+{
+    const size_t total = (size_t)N * PL * C;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dpooled, act, dpre, PL, C,
+                       total);
+    return hipGetLastError();
+}

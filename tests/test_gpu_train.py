@@ -1,0 +1,101 @@
+"""Parity of the HIP training step (loss = model(x); loss.backward(), lib/engine/train.py:60-63) with the
+reference-generated goldens and the CPU oracle: loss, per-iteration ELBOs and every parameter gradient.
+Gates: ELBO 1e-3 relative, parameter-gradient rel-L2 1e-3; asserted tighter."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import iodine_oracle as O
+from util import golden_setup, load_golden, make_hip_model, rel_err, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _train_step(m, x, eps):
+    m.zero_grad(set_to_none=True)
+    loss = m(x.to(DEV), eps.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss
+
+
+def test_tiny_gradients_full_tensors():
+    g = load_golden('tiny')
+    arch, params, x, eps, _ = golden_setup(g)
+    m = make_hip_model(arch, params)
+    loss = _train_step(m, x, eps)
+    assert abs(loss.item() - float(g['f32.train.loss'])) <= 1e-5 * abs(float(g['f32.train.loss']))
+    assert rel_err(m.elbo_terms[:, 0].cpu(), g['f32.train.elbos']) < 1e-5
+    bad = []
+    for n, p in m.named_parameters():
+        ref = g['f64.train.grad.' + n]
+        e = rel_l2(p.grad.cpu().numpy(), ref)
+        if not e < 2e-4:
+            bad.append((n, e))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('case', ['cfg1_dsprites_k4_t3_b4', 'cfg2_dsprites_k6_t5_b2', 'cfg3_clevr_k7_t5_b1',
+                                  'cfg5_clevr_k11_t7_b1'])
+def test_train_step_matches_reference_goldens(case):
+    g = load_golden(case)
+    arch, params, x, eps, _ = golden_setup(g)
+    m = make_hip_model(arch, params)
+    loss = _train_step(m, x, eps)
+    ref_loss = float(g['f32.train.loss'])
+    assert abs(loss.item() - ref_loss) <= 1e-4 * abs(ref_loss)
+    assert abs(loss.item() - float(g['f64.train.loss'])) <= 1e-4 * abs(ref_loss)
+    assert rel_err(m.elbo_terms[:, 0].cpu(), g['f32.train.elbos']) < 1e-4
+    bad = []
+    for n, p in m.named_parameters():
+        a = p.grad.double().cpu().flatten()
+        ss, ref_ss = float((a * a).sum()), float(g[f'f64.train.grad.{n}.sumsq'])
+        step = max(1, a.numel() // 16)
+        smp = a[::step][:16].numpy()
+        rms = np.sqrt(ref_ss / a.numel())
+        if abs(ss - ref_ss) > 2e-3 * ref_ss + 1e-12 or np.abs(smp - g[f'f64.train.grad.{n}.sample']).max() > 2e-3 * rms + 1e-7:
+            bad.append((n, ss, ref_ss))
+    assert not bad, bad
+
+
+def test_train_step_matches_oracle_on_fresh_inputs():
+    from iodine_amd import synth
+    arch = O.dsprites_arch(slots=3, iters=2)
+    pn = synth.make_params(O.param_shapes(arch), seed=21, dec_gain=3.0, posterior_scale=0.05)
+    params = {k: torch.from_numpy(v) for k, v in pn.items()}
+    imgs, _ = synth.make_images(2, arch.img_size, seed=8, kind='blobs')
+    x = torch.from_numpy(imgs)
+    eps = torch.from_numpy(synth.make_eps(arch.iters, 2, arch.slots, arch.dim_latent, seed=10))
+    out, grads = O.train_step_grads(x, eps, params, arch)
+    m = make_hip_model(arch, params)
+    loss = _train_step(m, x, eps)
+    assert abs(loss.item() - out['loss'].item()) <= 1e-5 * abs(out['loss'].item())
+    bad = [(n, rel_l2(p.grad.cpu().numpy(), grads[n].numpy())) for n, p in m.named_parameters()
+           if not rel_l2(p.grad.cpu().numpy(), grads[n].numpy()) < 1e-3]
+    assert not bad, bad
+
+
+def test_backward_accumulates_and_scales_like_autograd():
+    g = load_golden('tiny')
+    arch, params, x, eps, _ = golden_setup(g)
+    m = make_hip_model(arch, params)
+    _train_step(m, x, eps)
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    loss = m(x.to(DEV), eps.to(DEV))
+    (0.5 * loss).backward()                          # no zero_grad: .grad accumulates (train.py:62 zeroes explicitly)
+    for n, p in m.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), 1.5 * g1[n].cpu().numpy()) < 1e-5, n
+
+
+def test_sgd_step_changes_next_loss():
+    """set_params is re-run when the optimizer updates the weights in place (param version tracking)."""
+    g = load_golden('tiny')
+    arch, params, x, eps, _ = golden_setup(g)
+    m = make_hip_model(arch, params)
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4)                 # lib/solver/build.py:5-16
+    l0 = _train_step(m, x, eps).item()
+    opt.step()
+    l1 = _train_step(m, x, eps).item()
+    assert l1 != l0 and np.isfinite(l1)
+    assert l1 < l0                                                   # one Adam step on the same batch lowers the loss
