@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from iodine_amd import IODINE, synth  # noqa: E402
+from iodine_amd import IODINE, parallel, synth  # noqa: E402
 from iodine_amd.model import clevr6_arch, dsprites_arch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -40,7 +40,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--mode', choices=['infer', 'train'], default=os.environ.get('IODINE_BENCH_MODE', 'infer'))
+    ap.add_argument('--mode', choices=['infer', 'train'], default=os.environ.get('IODINE_BENCH_MODE', 'train'))
     ap.add_argument('--config', choices=['clevr6', 'dsprites'], default='clevr6')
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--slots', type=int, default=None)
@@ -116,6 +116,7 @@ def main():
             model.zero_grad(set_to_none=True)
             loss = model(x, eps)
             loss.backward()
+            parallel.allreduce_gradients(model.parameters(), world)       # one RCCL all-reduce of the flat grads
             return loss
 
     def barrier():
@@ -141,19 +142,40 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * B * T / (dt / args.steps)
 
+    # secondary measurement (not `value`): the other step type on the same workload
+    other = None
+    if args.mode == 'train':
+        def istep():
+            return model.reconstruct(x, eps)
+        istep()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            istep()
+        barrier()
+        dti = (time.perf_counter() - t1) / args.steps
+        if world > 1:
+            t = torch.tensor([dti], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dti = float(t.item())
+        other = dict(step='infer (reconstruct: T iterations + final decode)', ms_per_step=round(dti * 1e3, 3),
+                     image_refinement_iters_per_s=round(world * B * T / dti, 2))
+
     # ---- roofline of the dominant kernel: conv3x3_tile_kernel<C,C,*> (decoder 3x3 conv C->C, fwd + dgrad) ----
     C_ = arch.DEC.CONV_CHAN
     flops_per_launch = 2.0 * C_ * C_ * 9 * S * S * B * K
     prof = {}
-    for cat in ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad', 'dec_out', 'dec_out_dgrad', 'dec_l0',
-                'l0_reduce', 'pixel_pass1', 'pixel_pass2', 'refine_conv', 'refine_head'):
+    for cat in ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad', 'dec_out', 'dec_out_dgrad', 'dec_out_wgrad',
+                'dec_l0', 'l0_reduce', 'l0_slot_sum', 'pixel_pass1', 'pixel_pass2', 'refine_conv', 'refine_head',
+                'refine_wgrad', 'refine_dgrad', 'refine_bias_grad'):
         tot, cnt = model.profile_read(cat)
         if cnt:
             prof[cat] = dict(ms_total=round(tot, 3), launches=cnt, ms_avg=round(tot / cnt, 4))
     dom_ms = sum(prof[c]['ms_total'] for c in ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad') if c in prof)
     dom_n = sum(prof[c]['launches'] for c in ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad') if c in prof)
     achieved = flops_per_launch / (dom_ms / dom_n * 1e-3) / 1e12 if dom_n else 0.0
-    roofline = dict(bound='mfma', kernel=f'conv3x3_tile_kernel<{C_},{C_}> (decoder 3x3 conv, fwd+dgrad launches)',
+    roofline = dict(bound='mfma', kernel=f'conv3x3_tile_kernel<{C_},{C_}> + conv3x3_wgrad_tile_kernel<{C_},{C_}> '
+                                         f'(decoder 3x3 conv {C_}->{C_}: fwd, dgrad, wgrad launches)',
                     achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
                     flops_per_launch=flops_per_launch, avg_launch_ms=round(dom_ms / max(dom_n, 1), 4),
@@ -168,14 +190,20 @@ def main():
                                     f'K={K}, T={T}, batch {B}/GPU, {args.mode} step '
                                     f'({"reconstruct: T iterations + final decode" if args.mode == "infer" else "forward + backward, no optimizer"})',
                            step=args.mode, global_batch=B * world, slots=K, iters=T, img_size=S,
-                           parallelism=f'dp{world} (images sharded, no data-path collective in inference)'),
+                           parallelism=f'dp{world} (images sharded over ranks; '
+                                       f'{"one RCCL all-reduce of the flat gradient buffer per step" if args.mode == "train" else "no data-path collective"})'),
                batch_iters_per_s=round(T / (dt / args.steps), 3), roofline=roofline, kernels=prof)
+    if other:
+        out['inference_step'] = other
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, (xc, ec, ref_elbos) = cpu_baseline(args, arch, params, args.mode)
         out['cpu_baseline'] = cb
         # parity of this very run against the oracle on the CPU sample (gate 1e-3, north_star)
-        model.reconstruct(xc.to(device), ec.to(device))
+        if args.mode == 'infer':
+            model.reconstruct(xc.to(device), ec.to(device))
+        else:
+            model(xc.to(device), ec.to(device))
         got = model.elbo_terms[:, 0].double().cpu().numpy()
         n = min(len(got), len(ref_elbos))
         out['elbo_rel_err_vs_cpu'] = float(abs(got[:n] - ref_elbos[:n]).max() / abs(ref_elbos[:n]).max())

@@ -86,6 +86,8 @@ hipError_t launch_conv3x3_wgrad_gather(hipStream_t st, const float* in, const fl
 hipError_t launch_wgrad_reduce(hipStream_t st, const float* part, int nparts, int ci_pad, int co_pad, int O_real,
                                int I_real, int I_dst, float alpha, float* dst);
 hipError_t launch_colsum(hipStream_t st, const float* src, int rows, int cols, int ld, float alpha, float* dst);
+hipError_t launch_colsum_tall(hipStream_t st, const float* src, int rows, int cols, float alpha, float* dst, float* tmp,
+                              size_t tmp_elems);
 hipError_t launch_sgemm(hipStream_t st, int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
                         const float* B, int ldb, float beta, float* C, int ldc);
 hipError_t launch_sum_over_slots(hipStream_t st, const float* dpre, float* D, int N, int P, int C);

@@ -734,7 +734,8 @@ int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, floa
                                                                     &nparts, &cipad));
             const std::string base = "refine.mlc.layers." + std::to_string(l);
             HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, G(base + ".weight")));
-            HIPCHK(h, launch_colsum(st, b.rdpre[l], N * sz[l + 1] * sz[l + 1], Cr, Cr, 1.f, G(base + ".bias")));
+            PROF(h, st, "refine_bias_grad", launch_colsum_tall(st, b.rdpre[l], N * sz[l + 1] * sz[l + 1], Cr, 1.f,
+                                                               G(base + ".bias"), b.wg_part_b, (size_t)512 * 64));
             if (l > 0)
                 PROF(h, st, "refine_dgrad", launch_conv3x3_gather_dgrad(st, b.rdpre[l], h->ref_wb[l], b.ract[i][l - 1],
                                                                         b.rdpre[l - 1], N, sz[l], sz[l], Cr, 2));

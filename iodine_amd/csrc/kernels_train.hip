@@ -278,6 +278,45 @@ hipError_t launch_colsum(hipStream_t st, const float* src, int rows, int cols, i
     return hipGetLastError();
 }
 
+// column sums of a tall matrix (rows ~ 1e6, cols <= 256, cols % 4 == 0, contiguous): coalesced float4 streaming,
+// one partial row per block, then the small column-sum kernel over the partials (fixed order -> deterministic).
+__global__ __launch_bounds__(256)
+void colsum_tall_partial_kernel(const float4* __restrict__ src, int rows, int c4, int rows_per_block,
+                                float4* __restrict__ partial)
+{
+    __shared__ float4 s_red[256];
+    const int tid = threadIdx.x;
+    const int rl = 256 / c4;                               // row lanes
+    const int c = tid % c4, r0 = tid / c4;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(rows, rbeg + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 < rl)
+        for (int r = rbeg + r0; r < rend; r += rl) {
+            const float4 v = src[(size_t)r * c4 + c];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    s_red[tid] = s;
+    __syncthreads();
+    if (tid < c4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < rl; ++j) { const float4 v = s_red[j * c4 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        partial[(size_t)blockIdx.x * c4 + tid] = t;
+    }
+}
+
+hipError_t launch_colsum_tall(hipStream_t st, const float* src, int rows, int cols, float alpha, float* dst, float* tmp,
+                              size_t tmp_elems)
+{
+    if (cols % 4 != 0 || cols > 256 || 256 % (cols / 4) != 0 || rows < 8192) return launch_colsum(st, src, rows, cols, cols, alpha, dst);
+    int nblk = (int)std::min<size_t>(448, tmp_elems / cols);
+    if (nblk < 1) return hipErrorInvalidValue;
+    const int rpb = (rows + nblk - 1) / nblk;
+    nblk = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_tall_partial_kernel, dim3(nblk), dim3(256), 0, st, (const float4*)src, rows, cols / 4, rpb,
+                       (float4*)tmp);
+    return launch_colsum(st, tmp, nblk, cols, cols, alpha, dst);
+}
+
 // =========================================================================================
 // generic small SGEMM (row-major): C[M][N] = alpha * op(A)[M][K] * op(B)[K][N] + beta * C, 16x16 LDS tiles.
 // Used for the head backward (N = B*K rows; at most a few hundred MFLOP per call).

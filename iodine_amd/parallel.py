@@ -1,0 +1,57 @@
+"""Rank-per-GPU data parallelism for the IODINE step (replaces torch.nn.DataParallel,
+lib/modeling/build.py:11-12).
+
+The path shards over images only: every image is independent (layer-norms are per (b, k), the ELBO is a
+batch mean of per-image sums, the inner gradients are per-image by construction - SURVEY.md section 8e), and
+the K slots of one image must stay on one GPU (softmax / log-mixture / leave-one-out couple them per pixel).
+DataParallel's per-step traffic (parameter broadcast, input scatter, loss gather, gradient reduce-to-device-0
+on each of the T+1 backwards) collapses to ONE all-reduce per training step of the flat gradient buffer
+(4.44 MB for the CLEVR architecture) over RCCL/xGMI; inference needs no collective at all.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Images [start, stop) of the global batch owned by `rank` (equal shards, like DataParallel's scatter)."""
+    if global_batch % world != 0:
+        raise ValueError(f'global batch {global_batch} is not divisible by world size {world}')
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], world: int = None, group=None) -> None:
+    """Average .grad over ranks through one flat buffer (== ``loss.mean()`` over DataParallel replicas,
+    lib/engine/train.py:61).  Works with any backend (nccl = RCCL on ROCm, gloo on CPU)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return
+    world = world or dist.get_world_size(group)
+    if world == 1:
+        return
+    ps = [p for p in params if p.grad is not None]
+    if not ps:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(world)
+    off = 0
+    for p in ps:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
+
+
+def allreduce_mean(t: torch.Tensor, world: int = None, group=None) -> torch.Tensor:
+    """Mean of a (small) tensor over ranks: ELBO / KL / LL scalars, ARI sums."""
+    if not dist.is_available() or not dist.is_initialized():
+        return t
+    world = world or dist.get_world_size(group)
+    if world == 1:
+        return t
+    out = t.clone()
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    return out / world
