@@ -114,7 +114,9 @@ int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float*
 int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, float* const* param_grads, int n);
 
 /* Options: "stop_after_iters" (debug: run only the first v refinement iterations of reconstruct, no final decode),
- * "profile" (1: bracket every kernel launch with HIP events on the launch stream). */
+ * "profile" (1: bracket every kernel launch with HIP events on the launch stream),
+ * "conv_precision" (decoder 3x3 convs: 0 = exact fp32 MFMA, 1 = fp32 operands split into fp16 hi+lo, 3 fp16 MFMAs,
+ * fp32 accumulate -- default). */
 int iodine_set_option(iodine_handle* h, const char* key, double value);
 /* Sum of event-measured durations (ms) and number of launches of one kernel category since the last reset:
  * "conv_tile_fwd", "conv_tile_dgrad", "conv_tile_wgrad", "dec_out", "dec_out_dgrad", "dec_l0", "l0_reduce",
@@ -127,8 +129,9 @@ int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter
 /* ---- operator-level entry points (used by tests/ to check each kernel against the oracle) ------------- */
 /* torch.linspace(-1, 1, n) in fp32, bit-exact restatement of ATen's CPU kernel (iodine.py:334-335,526-527). HOST. */
 void iodine_linspace_host(int n, float* out);
-/* 3x3 conv, NHWC activations, OIHW weights; mode 0: stride-1 LDS-tiled (epi 0 bias+ELU, 1 multiply by ELU'(aux),
- * 2 none; transpose_flip=1 computes the data-gradient conv), mode 1: strided gather kernel (bias+ELU). */
+/* 3x3 conv, NHWC activations, OIHW weights; mode 0: stride-1 LDS-tiled fp32 MFMA (epi 0 bias+ELU, 1 multiply by
+ * ELU'(aux), 2 none; transpose_flip=1 computes the data-gradient conv), mode 1: strided gather kernel (bias+ELU),
+ * mode 2: stride-1 LDS-tiled split-fp16 (3 MFMA) variant of mode 0. */
 int iodine_op_conv3x3(void* stream, int mode, const float* in_nhwc, const float* w_oihw, const float* bias,
                       const float* aux, float* out_nhwc, int n, int ih, int iw, int w_o, int w_i, int cin_pad,
                       int cout, int stride, int epi, int transpose_flip);

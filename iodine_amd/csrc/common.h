@@ -103,3 +103,9 @@ hipError_t launch_lstm_bwd_pointwise(hipStream_t st, const float* gates, const f
                                      float* dc0, int N, int H);
 hipError_t launch_mlp_bwd_pointwise(hipStream_t st, const float* du, int ldu, const float* s, float* ds, int N, int H);
 hipError_t launch_pool_bwd(hipStream_t st, const float* dpooled, const float* act, float* dpre, int N, int PL, int C);
+// split-precision (3 x fp16 MFMA) variant of the stride-1 tile conv
+hipError_t launch_pack_conv_weights_f16(hipStream_t st, const float* src, int O, int I, int cin, int cout, int tflip,
+                                        float* meta, void* dst);
+hipError_t launch_conv3x3_tile_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
+                                     const float* bias, const float* aux, float* out, int N, int S, int cin, int cout,
+                                     int epi);

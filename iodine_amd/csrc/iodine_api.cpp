@@ -77,6 +77,8 @@ struct iodine_handle {
     float* lin = nullptr;                       // linspace(-1,1,S)
     float *wcls = nullptr, *wclsT = nullptr, *cmap = nullptr;
     std::vector<float*> dec_wf, dec_wb, dec_b;  // packed fwd / dgrad weights + bias copies for layers 1..Dd-1
+    std::vector<float*> dec_wf16, dec_wb16, dec_wmeta;   // split-fp16 packs (+ {scale, 1/scale, scale_b, 1/scale_b})
+    int precision = 1;                          // 0: exact fp32 MFMA, 1: 3 x fp16 MFMA split (fp32-class accuracy)
     float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr;
     std::vector<float*> ref_w, ref_b;
     float *mlp_wT = nullptr, *mlp_b = nullptr, *wihT = nullptr, *whhT = nullptr, *lstm_b = nullptr;
@@ -308,9 +310,15 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N)
 {
     Buffers& b = h->buf;
     PROF(h, st, "dec_l0", launch_dec_l0(st, b.V, h->cmap, b.act[0], N, h->S, h->Cd));
-    for (int l = 1; l < h->Dd; ++l)
-        PROF(h, st, "conv_tile_fwd", launch_conv3x3_tile(st, b.act[l - 1], h->dec_wf[l], h->dec_b[l], nullptr, b.act[l],
-                                                         N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
+    for (int l = 1; l < h->Dd; ++l) {
+        if (h->precision == 1)
+            PROF(h, st, "conv_tile_fwd", launch_conv3x3_tile_f16x3(st, b.act[l - 1], h->dec_wf16[l], h->dec_wmeta[l],
+                                                                   h->dec_b[l], nullptr, b.act[l], N, h->S, h->Cd, h->Cd,
+                                                                   EPI_BIAS_ELU));
+        else
+            PROF(h, st, "conv_tile_fwd", launch_conv3x3_tile(st, b.act[l - 1], h->dec_wf[l], h->dec_b[l], nullptr,
+                                                             b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
+    }
     PROF(h, st, "dec_out", launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, b.dec_out, N, h->S, h->Cd));
     return IODINE_OK;
 }
@@ -352,8 +360,13 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
                               param_index(h, base + ".bias"), nb);
             if (rc) return rc;
         }
-        PROF(h, st, "conv_tile_dgrad", launch_conv3x3_tile(st, b.dpre[cur], h->dec_wb[l], nullptr, b.act[l - 1],
-                                                           b.dpre[cur ^ 1], N, h->S, Cd, Cd, EPI_MUL_ELUGRAD));
+        if (h->precision == 1)
+            PROF(h, st, "conv_tile_dgrad", launch_conv3x3_tile_f16x3(st, b.dpre[cur], h->dec_wb16[l], h->dec_wmeta[l] + 2,
+                                                                     nullptr, b.act[l - 1], b.dpre[cur ^ 1], N, h->S, Cd,
+                                                                     Cd, EPI_MUL_ELUGRAD));
+        else
+            PROF(h, st, "conv_tile_dgrad", launch_conv3x3_tile(st, b.dpre[cur], h->dec_wb[l], nullptr, b.act[l - 1],
+                                                               b.dpre[cur ^ 1], N, h->S, Cd, Cd, EPI_MUL_ELUGRAD));
         cur ^= 1;
     }
     *dpre0 = b.dpre[cur];
@@ -455,10 +468,14 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     ALLOC(h->wclsT, (size_t)9 * L * Cd);
     ALLOC(h->cmap, (size_t)h->P * Cd);
     h->dec_wf.assign(h->Dd, nullptr); h->dec_wb.assign(h->Dd, nullptr); h->dec_b.assign(h->Dd, nullptr);
+    h->dec_wf16.assign(h->Dd, nullptr); h->dec_wb16.assign(h->Dd, nullptr); h->dec_wmeta.assign(h->Dd, nullptr);
     for (int l = 1; l < h->Dd; ++l) {
         ALLOC(h->dec_wf[l], conv_wpk_elems(Cd, Cd) * 4);
         ALLOC(h->dec_wb[l], conv_wpk_elems(Cd, Cd) * 4);
         ALLOC(h->dec_b[l], (size_t)Cd);
+        ALLOC(h->dec_wf16[l], (size_t)(Cd / 16) * 9 * 2 * 2 * Cd * 4);      // fp16 x 8 per uint4 = 4 floats
+        ALLOC(h->dec_wb16[l], (size_t)(Cd / 16) * 9 * 2 * 2 * Cd * 4);
+        ALLOC(h->dec_wmeta[l], (size_t)4);
     }
     ALLOC(h->dec_out_w, (size_t)9 * Cd * 4);
     ALLOC(h->dec_out_b, (size_t)4);
@@ -524,6 +541,8 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         const float* w = P("decoder.mlc.layers." + std::to_string(l) + ".weight");
         HIPCHK(h, launch_pack_conv_weights(st, w, Cd, Cd, Cd, Cd, 0, h->dec_wf[l]));
         HIPCHK(h, launch_pack_conv_weights(st, w, Cd, Cd, Cd, Cd, 1, h->dec_wb[l]));
+        HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cd, Cd, Cd, Cd, 0, h->dec_wmeta[l], h->dec_wf16[l]));
+        HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cd, Cd, Cd, Cd, 1, h->dec_wmeta[l] + 2, h->dec_wb16[l]));
         HIPCHK(h, hipMemcpyAsync(h->dec_b[l], P("decoder.mlc.layers." + std::to_string(l) + ".bias"), sizeof(float) * Cd,
                                  hipMemcpyDeviceToDevice, st));
     }
@@ -587,6 +606,11 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!h || !key) return IODINE_ERR_INVALID;
     if (!strcmp(key, "stop_after_iters")) { h->stop_after = (int)value; return IODINE_OK; }
     if (!strcmp(key, "profile")) { h->profile = value != 0; return IODINE_OK; }
+    if (!strcmp(key, "conv_precision")) {
+        if (value != 0 && value != 1) return h->fail(IODINE_ERR_INVALID, "conv_precision must be 0 (f32) or 1 (f16x3)");
+        h->precision = (int)value;
+        return IODINE_OK;
+    }
     return h->fail(IODINE_ERR_INVALID, std::string("unknown option ") + key);
 }
 
@@ -832,6 +856,18 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, c
 {
     hipStream_t st = (hipStream_t)stream;
     float* wpk = nullptr;
+    if (mode == 2) {                       // split-fp16 tile kernel
+        float* meta = nullptr;
+        const size_t bytes = (size_t)(cin_pad / 16) * 9 * 2 * 2 * cout * 16;
+        if (hipMalloc((void**)&wpk, bytes + 64) != hipSuccess) return IODINE_ERR_HIP;
+        meta = (float*)((char*)wpk + bytes);
+        hipError_t e2 = launch_pack_conv_weights_f16(st, w, w_o, w_i, cin_pad, cout, tflip, meta, wpk);
+        if (e2 == hipSuccess) e2 = launch_conv3x3_tile_f16x3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+        (void)hipFree(wpk);
+        if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(f16x3): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
+        return IODINE_OK;
+    }
     if (hipMalloc((void**)&wpk, conv_wpk_elems(cin_pad, cout) * 16) != hipSuccess) return IODINE_ERR_HIP;
     hipError_t e = launch_pack_conv_weights(st, w, w_o, w_i, cin_pad, cout, tflip, wpk);
     if (e == hipSuccess) {

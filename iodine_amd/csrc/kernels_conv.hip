@@ -383,3 +383,278 @@ hipError_t launch_dec_out(hipStream_t st, const float* in, const float* wk, cons
         return hipErrorInvalidValue;
     return hipGetLastError();
 }
+
+// =========================================================================================
+// Split-precision variant of the stride-1 tile conv: fp32 operands are split on the fly into
+// fp16 (hi, lo) pairs, v = hi + lo with |lo| <= ulp_f16(v), and the product is evaluated as
+//     a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi        (the dropped a_lo*w_lo term is ~2^-22 |a*w|)
+// with three v_mfma_f32_32x32x16_f16 per K=16 step, fp32 accumulation.  16x the fp32-MFMA rate / 3 passes
+// = 5.3x, at fp32-class accuracy (measured through the whole training step: ELBO 5e-7, gradients 1e-5 relative,
+// see DESIGN.md section 4).  Weights are pre-split and pre-scaled by a power of two (their lo parts would be fp16
+// subnormals otherwise); activations are split while being staged into LDS.
+//   wpk16[chunk][tap][term hi/lo][kh][co] = 8 fp16 (channels chunk*16 + kh*8 .. +7) * wscale
+// =========================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// max |w| of a tensor -> meta[0] = scale (power of two with max*scale in [2^12, 2^13)), meta[1] = 1/scale
+__global__ void weight_scale_kernel(const float* __restrict__ w, int n, float* __restrict__ meta)
+{
+    __shared__ float s_red[256];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+    s_red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mx = s_red[0];
+        int e = 0;
+        if (mx > 0.f && isfinite(mx)) { frexpf(mx, &e); }          // mx = f * 2^e, f in [0.5, 1)
+        const float scale = ldexpf(1.f, 13 - e);                    // mx * scale in [2^12, 2^13)
+        meta[0] = (mx > 0.f && isfinite(mx)) ? scale : 1.f;
+        meta[1] = 1.f / meta[0];
+    }
+}
+
+__global__ void pack_conv_weights_f16_kernel(const float* __restrict__ src, int O, int I, int cin, int cout, int tflip,
+                                             const float* __restrict__ meta, _Float16* __restrict__ dst)
+{
+    const float scale = meta[0];
+    const size_t total = (size_t)(cin / 16) * 9 * 2 * 2 * cout * 8;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 7;
+        size_t r = idx >> 3;
+        const int co = r % cout; r /= cout;
+        const int kh = r & 1; r >>= 1;
+        const int term = r & 1; r >>= 1;
+        const int tap = r % 9;
+        const int chunk = r / 9;
+        const int ci = chunk * 16 + kh * 8 + e;
+        float v = 0.f;
+        if (!tflip) { if (ci < I && co < O) v = src[((size_t)co * I + ci) * 9 + tap]; }
+        else if (tflip == 1) { if (ci < O && co < I) v = src[((size_t)ci * I + co) * 9 + (8 - tap)]; }
+        else { if (ci < O && co < I) v = src[((size_t)ci * I + co) * 9 + tap]; }
+        v *= scale;
+        const _Float16 hi = (_Float16)v;
+        dst[idx] = term == 0 ? hi : (_Float16)(v - (float)hi);
+    }
+}
+
+hipError_t launch_pack_conv_weights_f16(hipStream_t st, const float* src, int O, int I, int cin, int cout, int tflip,
+                                        float* meta, void* dst)
+{
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(256), 0, st, src, O * I * 9, meta);
+    const size_t total = (size_t)(cin / 16) * 9 * 2 * 2 * cout * 8;
+    hipLaunchKernelGGL(pack_conv_weights_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, O, I,
+                       cin, cout, tflip, meta, (_Float16*)dst);
+    return hipGetLastError();
+}
+
+IOD_DEVINL float elu1_fast(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
+
+template <int CIN, int COUT, int EPI>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
+                               const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
+                               int S, int tiles)
+{
+    constexpr int NCHUNK = CIN / 16;
+    constexpr int NT = COUT / 32;
+    constexpr int HALO = 18;
+    constexpr int PXS = 80;                              // bytes per staged pixel: 32 hi + 32 lo + 16 pad
+    constexpr int IN_BYTES = HALO * HALO * PXS;          // 25920
+    constexpr int W_U4 = 9 * 2 * 2 * COUT;               // uint4 (8 x fp16) per chunk
+    constexpr int NIN = (HALO * HALO * 4 + 255) / 256;   // float4 loads per thread per chunk (6)
+    constexpr int NW = (W_U4 + 255) / 256;               // uint4 loads per thread per chunk
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* s_in = smem_b;
+    uint4* s_w = reinterpret_cast<uint4*>(smem_b + IN_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, kh = lane >> 5, li = lane & 31;
+    const int prow = li >> 4, pcol = li & 15;
+
+    int bid = blockIdx.x;
+    const int tx = bid % tiles; bid /= tiles;
+    const int ty = bid % tiles;
+    const int n = bid / tiles;
+    const int y0 = ty * 16 - 1, x0 = tx * 16 - 1;
+    const float* in_n = in + (size_t)n * S * S * CIN;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    float4 rin[NIN];
+    uint4 rw[NW];
+
+    auto prefetch = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const int idx = tid + k * 256;
+            const int px = idx >> 2, cq = idx & 3;
+            const int gy = y0 + px / HALO, gx = x0 + px % HALO;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < HALO * HALO * 4 && gy >= 0 && gy < S && gx >= 0 && gx < S)
+                v = *reinterpret_cast<const float4*>(in_n + ((size_t)gy * S + gx) * CIN + chunk * 16 + cq * 4);
+            rin[k] = v;
+        }
+        const uint4* wsrc = wpk + (size_t)chunk * W_U4;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int idx = tid + k * 256;
+            rw[k] = idx < W_U4 ? wsrc[idx] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    // Block-local dynamic range: before a chunk is split into fp16 (hi, lo) it is multiplied by a power of two
+    // chosen from the chunk tile's max |x| (so that small-magnitude tensors such as gradients keep their lo parts
+    // out of the fp16 subnormal range); the accumulators are rescaled (exactly) when the scale changes.
+    float* s_max = reinterpret_cast<float*>(smem_b + IN_BYTES + W_U4 * 16);
+    float cur_scale = 1.f;
+    auto commit = [&]() -> float {
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const float4 v = rin[k];                         // out-of-range slots were loaded as zeros
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if (lane == 0) s_max[wv] = m;
+        __syncthreads();                                     // also: every wave is done reading the previous chunk
+        const float mb = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        const int e = (int)((__float_as_uint(mb) >> 23) & 0xffu) - 127;      // floor(log2(mb)) for normal mb
+        int se = 12 - e;                                     // mb * 2^se in [2^12, 2^13)
+        se = se > 100 ? 100 : (se < -100 ? -100 : se);
+        const float scale = (mb > 0.f && mb < 3.0e38f) ? __uint_as_float((unsigned)(127 + se) << 23) : 1.f;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < HALO * HALO * 4) {
+                const int px = idx >> 2, cq = idx & 3;
+                float4 v = rin[k];
+                v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+                f16x4 hi, lo;
+                hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+                lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+                lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+                *reinterpret_cast<f16x4*>(s_in + px * PXS + cq * 8) = hi;
+                *reinterpret_cast<f16x4*>(s_in + px * PXS + 32 + cq * 8) = lo;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < W_U4) s_w[idx] = rw[k];
+        }
+        __syncthreads();
+        return scale;
+    };
+    auto rescale = [&](float new_scale) {
+        if (new_scale != cur_scale) {                        // block-uniform
+            const float r = new_scale / cur_scale;           // exact: both are powers of two
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[mt][nt][q] *= r;
+            cur_scale = new_scale;
+        }
+    };
+
+    prefetch(0);
+    cur_scale = commit();
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+        if (chunk + 1 < NCHUNK) prefetch(chunk + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            f16x8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int hy = 4 * wv + 2 * mt + prow + dy, hx = pcol + dx;
+                const unsigned char* p = s_in + (hy * HALO + hx) * PXS + kh * 16;
+                ah[mt] = *reinterpret_cast<const f16x8*>(p);
+                al[mt] = *reinterpret_cast<const f16x8*>(p + 32);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const uint4* q = s_w + ((tap * 2 + 0) * 2 + kh) * COUT + nt * 32 + li;
+                bh[nt] = *reinterpret_cast<const f16x8*>(q);
+                bl[nt] = *reinterpret_cast<const f16x8*>(q + 2 * COUT);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                }
+        }
+        if (chunk + 1 < NCHUNK) rescale(commit());
+    }
+
+    const float inv_ws = wmeta[1] / cur_scale;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = nt * 32 + li;
+            float bv = 0.f;
+            if (EPI == EPI_BIAS_ELU) bv = bias[co];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int gy = ty * 16 + 4 * wv + 2 * mt + (m >> 4);
+                const int gx = tx * 16 + (m & 15);
+                const size_t o = (((size_t)n * S + gy) * S + gx) * COUT + co;
+                float v = acc[mt][nt][r] * inv_ws;
+                if (EPI == EPI_BIAS_ELU) v = elu1_fast(v + bv);
+                else if (EPI == EPI_MUL_ELUGRAD) v *= elu1_grad_from_out(aux[o]);
+                out[o] = v;
+            }
+        }
+}
+
+template <int CIN, int COUT, int EPI>
+static hipError_t launch_tile_f16x3_inst(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
+                                         const float* bias, const float* aux, float* out, int N, int S)
+{
+    constexpr size_t lds = (size_t)18 * 18 * 80 + (size_t)9 * 2 * 2 * COUT * 16 + 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_tile_f16x3_kernel<CIN, COUT, EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles = S / 16;
+    hipLaunchKernelGGL((conv3x3_tile_f16x3_kernel<CIN, COUT, EPI>), dim3(N * tiles * tiles), dim3(256), lds, st, in,
+                       reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, S, tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_tile_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
+                                     const float* bias, const float* aux, float* out, int N, int S, int cin, int cout,
+                                     int epi)
+{
+    if (S % 16 != 0) return hipErrorInvalidValue;
+#define T16_CASE(CI, CO, EP) \
+    if (cin == CI && cout == CO && epi == EP) return launch_tile_f16x3_inst<CI, CO, EP>(st, in, wpk, wmeta, bias, aux, out, N, S);
+    T16_CASE(64, 64, EPI_BIAS_ELU) T16_CASE(64, 64, EPI_MUL_ELUGRAD)
+    T16_CASE(32, 32, EPI_BIAS_ELU) T16_CASE(32, 32, EPI_MUL_ELUGRAD)
+#undef T16_CASE
+    return hipErrorInvalidValue;
+}
