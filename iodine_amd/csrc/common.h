@@ -30,7 +30,7 @@ __host__ __device__ constexpr size_t conv_wpk_elems(int cin, int cout) {
     return (size_t)conv_nchunk(cin) * conv_nqp(cin) * cout;
 }
 
-enum ConvEpilogue { EPI_BIAS_ELU = 0, EPI_MUL_ELUGRAD = 1, EPI_NONE = 2 };
+enum ConvEpilogue { EPI_BIAS_ELU = 0, EPI_MUL_ELUGRAD = 1, EPI_NONE = 2, EPI_OUT4 = 3 };
 
 // ---- launchers (each returns hipError_t from the launch) -------------------------------
 hipError_t launch_pack_conv_weights(hipStream_t st, const float* src_oihw, int O, int I, int cin_pad,

@@ -79,7 +79,7 @@ struct iodine_handle {
     std::vector<float*> dec_wf, dec_wb, dec_b;  // packed fwd / dgrad weights + bias copies for layers 1..Dd-1
     std::vector<float*> dec_wf16, dec_wb16, dec_wmeta;   // split-fp16 packs (+ {scale, 1/scale, scale_b, 1/scale_b})
     int precision = 1;                          // 0: exact fp32 MFMA, 1: 3 x fp16 MFMA split (fp32-class accuracy)
-    float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr;
+    float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr, *dec_out_w16 = nullptr, *dec_out_meta = nullptr;
     std::vector<float*> ref_w, ref_b;
     float *mlp_wT = nullptr, *mlp_b = nullptr, *wihT = nullptr, *whhT = nullptr, *lstm_b = nullptr;
     float *wmT = nullptr, *bm = nullptr, *wvT = nullptr, *bv = nullptr, *init_mean = nullptr, *init_logvar = nullptr;
@@ -319,7 +319,11 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N)
             PROF(h, st, "conv_tile_fwd", launch_conv3x3_tile(st, b.act[l - 1], h->dec_wf[l], h->dec_b[l], nullptr,
                                                              b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
     }
-    PROF(h, st, "dec_out", launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, b.dec_out, N, h->S, h->Cd));
+    if (h->precision == 1)
+        PROF(h, st, "dec_out", launch_conv3x3_tile_f16x3(st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b,
+                                                         nullptr, b.dec_out, N, h->S, h->Cd, 32, EPI_OUT4));
+    else
+        PROF(h, st, "dec_out", launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, b.dec_out, N, h->S, h->Cd));
     return IODINE_OK;
 }
 
@@ -480,6 +484,8 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     ALLOC(h->dec_out_w, (size_t)9 * Cd * 4);
     ALLOC(h->dec_out_b, (size_t)4);
     ALLOC(h->dec_out_wb, conv_wpk_elems(4, Cd) * 4);
+    ALLOC(h->dec_out_w16, (size_t)(Cd / 16) * 9 * 2 * 2 * 32 * 4);
+    ALLOC(h->dec_out_meta, (size_t)4);
     h->ref_w.assign(h->Dr, nullptr); h->ref_b.assign(h->Dr, nullptr);
     for (int l = 0; l < h->Dr; ++l) {
         ALLOC(h->ref_w[l], conv_wpk_elems(l == 0 ? 20 : Cr, Cr) * 4);
@@ -549,6 +555,7 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     HIPCHK(h, launch_pack_dec_out(st, P("decoder.conv.weight"), h->dec_out_w, Cd));
     HIPCHK(h, hipMemcpyAsync(h->dec_out_b, P("decoder.conv.bias"), sizeof(float) * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(h, launch_pack_conv_weights(st, P("decoder.conv.weight"), 4, Cd, 4, Cd, 1, h->dec_out_wb));
+    HIPCHK(h, launch_pack_conv_weights_f16(st, P("decoder.conv.weight"), 4, Cd, Cd, 32, 0, h->dec_out_meta, h->dec_out_w16));
     // refinement conv stack
     for (int l = 0; l < h->Dr; ++l) {
         const float* w = P("refine.mlc.layers." + std::to_string(l) + ".weight");

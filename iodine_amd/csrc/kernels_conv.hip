@@ -220,12 +220,28 @@ void conv3x3_gather_kernel(const float* __restrict__ in, const float4* __restric
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, li = lane & 31;
-    const int m = blockIdx.x * 128 + wv * 32 + li;
-    const bool mvalid = m < M;
-    int t = mvalid ? m : 0;
-    const int ox = t % OW; t /= OW;
-    const int oy = t % OH;
-    const int n = t / OH;
+    // MODE 0: blocks walk the output pixels linearly.  MODE 1 (STRIDE 2, even OH/OW): blocks are grouped by the
+    // parity class (oy & 1, ox & 1) of the pixels they own, because a pixel only receives the taps with
+    // tap_y = oy + 1 (mod 2), tap_x = ox + 1 (mod 2): 1 / 2 / 2 / 4 of the 9 taps -> 4x fewer MFMAs, wave-uniform.
+    const int OH2 = OH / 2, OW2 = OW / 2, Mc = M / 4;
+    const int bpc = (Mc + 127) / 128;
+    const int cls = MODE == 1 ? blockIdx.x / bpc : 0;
+    const int cy = cls >> 1, cx = cls & 1;
+    const int mbase = MODE == 1 ? (blockIdx.x % bpc) * 128 : blockIdx.x * 128;
+    const int Mlim = MODE == 1 ? Mc : M;
+    auto decode = [&](int mloc, int& n_, int& oy_, int& ox_) {
+        if (MODE == 1) {
+            ox_ = 2 * (mloc % OW2) + cx; mloc /= OW2;
+            oy_ = 2 * (mloc % OH2) + cy; n_ = mloc / OH2;
+        } else {
+            ox_ = mloc % OW; mloc /= OW;
+            oy_ = mloc % OH; n_ = mloc / OH;
+        }
+    };
+    const int m = mbase + wv * 32 + li;
+    const bool mvalid = m < Mlim;
+    int n, oy, ox;
+    decode(mvalid ? m : 0, n, oy, ox);
     const float* in_n = in + (size_t)n * IH * IW * CIN;
     const int iy0 = MODE == 0 ? oy * STRIDE - 1 : oy + 1, ix0 = MODE == 0 ? ox * STRIDE - 1 : ox + 1;
 
@@ -242,6 +258,10 @@ void conv3x3_gather_kernel(const float* __restrict__ in, const float4* __restric
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < NPAIR; ++g) {
+            if (MODE == 1 && (QPT % 2) == 0) {           // both quads of the pair belong to tap g / (QPT/2)
+                const int tapg = (2 * g) / QPT;
+                if (((cy + 1 - tapg / 3) & 1) || ((cx + 1 - tapg % 3) & 1)) continue;      // block-uniform
+            }
             const int q = 2 * g + half;
             const int qa = q < NQ ? q : NQ - 1;
             const int tap = qa / QPT, cig = qa % QPT;
@@ -274,9 +294,15 @@ void conv3x3_gather_kernel(const float* __restrict__ in, const float4* __restric
         const float bv = MODE == 0 ? bias[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int mm = blockIdx.x * 128 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (mm < M) {
-                const size_t o = (size_t)mm * COUT + co;
+            const int mm = mbase + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (mm < Mlim) {
+                size_t pix = (size_t)mm;
+                if (MODE == 1) {
+                    int n2, oy2, ox2;
+                    decode(mm, n2, oy2, ox2);
+                    pix = ((size_t)n2 * OH + oy2) * OW + ox2;
+                }
+                const size_t o = pix * COUT + co;
                 out[o] = MODE == 0 ? elu1(acc[nt][r] + bv) : acc[nt][r] * elu1_grad_from_out(aux[o]);
             }
         }
@@ -303,7 +329,9 @@ static hipError_t launch_gather_dgrad_inst(hipStream_t st, const float* d, const
     constexpr size_t lds = (size_t)conv_nqp(CIN) * COUT * 16;
     const int dh = (big_h - 1) / STRIDE + 1, dw = (big_w - 1) / STRIDE + 1;
     const int M = N * big_h * big_w;
-    hipLaunchKernelGGL((conv3x3_gather_kernel<CIN, COUT, STRIDE, 1>), dim3((M + 127) / 128), dim3(256), lds, st, d,
+    if ((big_h & 1) || (big_w & 1)) return hipErrorInvalidValue;
+    const int bpc = (M / 4 + 127) / 128;
+    hipLaunchKernelGGL((conv3x3_gather_kernel<CIN, COUT, STRIDE, 1>), dim3(4 * bpc), dim3(256), lds, st, d,
                        reinterpret_cast<const float4*>(wpk), nullptr, aux, out, M, dh, dw, big_h, big_w);
     return hipGetLastError();
 }
@@ -614,6 +642,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             const int co = nt * 32 + li;
             float bv = 0.f;
             if (EPI == EPI_BIAS_ELU) bv = bias[co];
+            if (EPI == EPI_OUT4) bv = li < 4 ? bias[li] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -621,6 +650,10 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
                 const int gx = tx * 16 + (m & 15);
                 const size_t o = (((size_t)n * S + gy) * S + gx) * COUT + co;
                 float v = acc[mt][nt][r] * inv_ws;
+                if (EPI == EPI_OUT4) {                   // decoder output conv: 4 real channels, out is [N][P][4]
+                    if (li < 4) out[(((size_t)n * S + gy) * S + gx) * 4 + li] = v + bv;
+                    continue;
+                }
                 if (EPI == EPI_BIAS_ELU) v = elu1_fast(v + bv);
                 else if (EPI == EPI_MUL_ELUGRAD) v *= elu1_grad_from_out(aux[o]);
                 out[o] = v;
@@ -655,6 +688,7 @@ hipError_t launch_conv3x3_tile_f16x3(hipStream_t st, const float* in, const void
     if (cin == CI && cout == CO && epi == EP) return launch_tile_f16x3_inst<CI, CO, EP>(st, in, wpk, wmeta, bias, aux, out, N, S);
     T16_CASE(64, 64, EPI_BIAS_ELU) T16_CASE(64, 64, EPI_MUL_ELUGRAD)
     T16_CASE(32, 32, EPI_BIAS_ELU) T16_CASE(32, 32, EPI_MUL_ELUGRAD)
+    T16_CASE(64, 32, EPI_OUT4) T16_CASE(32, 32, EPI_OUT4)
 #undef T16_CASE
     return hipErrorInvalidValue;
 }

@@ -167,24 +167,33 @@ void conv3x3_wgrad_gather_kernel(const float* __restrict__ in, const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    constexpr int UNR = 4;                                   // k-steps whose 10 gathers each are issued before any MFMA
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-#pragma unroll 2
-        for (int s = 0; s < PXW / 2; ++s) {
-            const int m = chunk * 128 + ks * PXW + 2 * s + half;
-            const bool valid = m < M;
-            int t = valid ? m : 0;
-            const int ox = t % OW; t /= OW;
-            const int oy = t % OH;
-            const int n = t / OH;
-            const float bval = valid ? d[(size_t)m * CO + ni * 32 + li] : 0.f;
-            const float* in_n = in + (size_t)n * IH * IW * CIP + ci;
+        for (int s0 = 0; s0 < PXW / 2; s0 += UNR) {
+            float bval[UNR], aval[UNR][9];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int iy = oy * STRIDE + tap / 3 - 1, ix = ox * STRIDE + tap % 3 - 1;
-                float aval = 0.f;
-                if (valid && ci_ok && iy >= 0 && iy < IH && ix >= 0 && ix < IW) aval = in_n[((size_t)iy * IW + ix) * CIP];
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bval, acc[tap], 0, 0, 0);
+            for (int u = 0; u < UNR; ++u) {
+                const int m = chunk * 128 + ks * PXW + 2 * (s0 + u) + half;
+                const bool valid = m < M;
+                int t = valid ? m : 0;
+                const int ox = t % OW; t /= OW;
+                const int oy = t % OH;
+                const int n = t / OH;
+                bval[u] = valid ? d[(size_t)m * CO + ni * 32 + li] : 0.f;
+                const float* in_n = in + (size_t)n * IH * IW * CIP + ci;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int iy = oy * STRIDE + tap / 3 - 1, ix = ox * STRIDE + tap % 3 - 1;
+                    float v = 0.f;
+                    if (valid && ci_ok && iy >= 0 && iy < IH && ix >= 0 && ix < IW) v = in_n[((size_t)iy * IW + ix) * CIP];
+                    aval[u][tap] = v;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval[u][tap], bval[u], acc[tap], 0, 0, 0);
         }
     }
     constexpr int CIPAD = MT * 32;
