@@ -349,16 +349,24 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
     PROF(h, st, "dec_out_dgrad", launch_conv3x3_tile(st, b.g, h->dec_out_wb, nullptr, b.act[Dd - 1], b.dpre[cur], N,
                                                      h->S, 4, Cd, EPI_MUL_ELUGRAD));
     if (train_alpha != 0.f) {
-        PROF(h, st, "dec_out_wgrad", launch_conv3x3_wgrad_tile(st, b.act[Dd - 1], b.g, b.wg_part, b.wg_part_b, N, h->S,
-                                                                Cd, 4, &nparts, &ncop, &nb));
+        if (h->precision == 1)
+            PROF(h, st, "dec_out_wgrad", launch_conv3x3_wgrad_f16x3(st, b.act[Dd - 1], b.g, b.wg_part, b.wg_part_b, N,
+                                                                     h->S, Cd, 4, &nparts, &ncop, &nb));
+        else
+            PROF(h, st, "dec_out_wgrad", launch_conv3x3_wgrad_tile(st, b.act[Dd - 1], b.g, b.wg_part, b.wg_part_b, N,
+                                                                    h->S, Cd, 4, &nparts, &ncop, &nb));
         rc = reduce_wgrad(h, st, nparts, Cd, ncop, 4, Cd, Cd, train_alpha, param_index(h, "decoder.conv.weight"),
                           param_index(h, "decoder.conv.bias"), nb);
         if (rc) return rc;
     }
     for (int l = Dd - 1; l >= 1; --l) {
         if (train_alpha != 0.f) {
-            PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_tile(st, b.act[l - 1], b.dpre[cur], b.wg_part, b.wg_part_b,
-                                                                      N, h->S, Cd, Cd, &nparts, &ncop, &nb));
+            if (h->precision == 1)
+                PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_f16x3(st, b.act[l - 1], b.dpre[cur], b.wg_part,
+                                                                           b.wg_part_b, N, h->S, Cd, Cd, &nparts, &ncop, &nb));
+            else
+                PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_tile(st, b.act[l - 1], b.dpre[cur], b.wg_part,
+                                                                          b.wg_part_b, N, h->S, Cd, Cd, &nparts, &ncop, &nb));
             const std::string base = "decoder.mlc.layers." + std::to_string(l);
             rc = reduce_wgrad(h, st, nparts, Cd, ncop, Cd, Cd, Cd, train_alpha, param_index(h, base + ".weight"),
                               param_index(h, base + ".bias"), nb);
