@@ -131,7 +131,7 @@ int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter
 void iodine_linspace_host(int n, float* out);
 /* 3x3 conv, NHWC activations, OIHW weights; mode 0: stride-1 LDS-tiled fp32 MFMA (epi 0 bias+ELU, 1 multiply by
  * ELU'(aux), 2 none; transpose_flip=1 computes the data-gradient conv), mode 1: strided gather kernel (bias+ELU),
- * mode 2: stride-1 LDS-tiled split-fp16 (3 MFMA) variant of mode 0. */
+ * mode 2: stride-1 LDS-tiled split-fp16 (3 MFMA) variant of mode 0, mode 4: its warp-specialised persistent form. */
 int iodine_op_conv3x3(void* stream, int mode, const float* in_nhwc, const float* w_oihw, const float* bias,
                       const float* aux, float* out_nhwc, int n, int ih, int iw, int w_o, int w_i, int cin_pad,
                       int cout, int stride, int epi, int transpose_flip);

@@ -79,6 +79,7 @@ struct iodine_handle {
     std::vector<float*> dec_wf, dec_wb, dec_b;  // packed fwd / dgrad weights + bias copies for layers 1..Dd-1
     std::vector<float*> dec_wf16, dec_wb16, dec_wmeta;   // split-fp16 packs (+ {scale, 1/scale, scale_b, 1/scale_b})
     int precision = 1;                          // 0: exact fp32 MFMA, 1: 3 x fp16 MFMA split (fp32-class accuracy)
+    int variant = 1;                            // split-fp16 tile conv: 1 = one tile per block (2 blocks/CU), 3 = warp-specialised persistent (experimental)
     float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr, *dec_out_w16 = nullptr, *dec_out_meta = nullptr;
     std::vector<float*> ref_w, ref_b;
     float *mlp_wT = nullptr, *mlp_b = nullptr, *wihT = nullptr, *whhT = nullptr, *lstm_b = nullptr;
@@ -100,6 +101,9 @@ struct iodine_handle {
 };
 
 namespace {
+
+hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, const void* wpk, const float* wmeta,
+                      const float* bias, const float* aux, float* out, int N, int S, int cin, int cout, int epi);
 
 #define HIPCHK(h, expr)                                                                          \
     do {                                                                                         \
@@ -126,6 +130,13 @@ namespace {
         HIPCHK(h, expr);                                                             \
         if (e1_) HIPCHK(h, hipEventRecord(e1_, st));                                 \
     } while (0)
+
+hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, const void* wpk, const float* wmeta,
+                      const float* bias, const float* aux, float* out, int N, int S, int cin, int cout, int epi)
+{
+    if (h->variant == 3) return launch_conv3x3_tile_f16x3_v3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi);
+    return launch_conv3x3_tile_f16x3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi);
+}
 
 template <typename T>
 hipError_t dev_alloc(iodine_handle* h, T** p, size_t n)
@@ -312,16 +323,15 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N)
     PROF(h, st, "dec_l0", launch_dec_l0(st, b.V, h->cmap, b.act[0], N, h->S, h->Cd));
     for (int l = 1; l < h->Dd; ++l) {
         if (h->precision == 1)
-            PROF(h, st, "conv_tile_fwd", launch_conv3x3_tile_f16x3(st, b.act[l - 1], h->dec_wf16[l], h->dec_wmeta[l],
-                                                                   h->dec_b[l], nullptr, b.act[l], N, h->S, h->Cd, h->Cd,
-                                                                   EPI_BIAS_ELU));
+            PROF(h, st, "conv_tile_fwd", conv_f16x3(h, st, b.act[l - 1], h->dec_wf16[l], h->dec_wmeta[l], h->dec_b[l],
+                                                    nullptr, b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
         else
             PROF(h, st, "conv_tile_fwd", launch_conv3x3_tile(st, b.act[l - 1], h->dec_wf[l], h->dec_b[l], nullptr,
                                                              b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
     }
     if (h->precision == 1)
-        PROF(h, st, "dec_out", launch_conv3x3_tile_f16x3(st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b,
-                                                         nullptr, b.dec_out, N, h->S, h->Cd, 32, EPI_OUT4));
+        PROF(h, st, "dec_out", conv_f16x3(h, st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b, nullptr,
+                                          b.dec_out, N, h->S, h->Cd, 32, EPI_OUT4));
     else
         PROF(h, st, "dec_out", launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, b.dec_out, N, h->S, h->Cd));
     return IODINE_OK;
@@ -373,9 +383,8 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
             if (rc) return rc;
         }
         if (h->precision == 1)
-            PROF(h, st, "conv_tile_dgrad", launch_conv3x3_tile_f16x3(st, b.dpre[cur], h->dec_wb16[l], h->dec_wmeta[l] + 2,
-                                                                     nullptr, b.act[l - 1], b.dpre[cur ^ 1], N, h->S, Cd,
-                                                                     Cd, EPI_MUL_ELUGRAD));
+            PROF(h, st, "conv_tile_dgrad", conv_f16x3(h, st, b.dpre[cur], h->dec_wb16[l], h->dec_wmeta[l] + 2, nullptr,
+                                                      b.act[l - 1], b.dpre[cur ^ 1], N, h->S, Cd, Cd, EPI_MUL_ELUGRAD));
         else
             PROF(h, st, "conv_tile_dgrad", launch_conv3x3_tile(st, b.dpre[cur], h->dec_wb[l], nullptr, b.act[l - 1],
                                                                b.dpre[cur ^ 1], N, h->S, Cd, Cd, EPI_MUL_ELUGRAD));
@@ -621,6 +630,11 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!h || !key) return IODINE_ERR_INVALID;
     if (!strcmp(key, "stop_after_iters")) { h->stop_after = (int)value; return IODINE_OK; }
     if (!strcmp(key, "profile")) { h->profile = value != 0; return IODINE_OK; }
+    if (!strcmp(key, "conv_variant")) {
+        if (value != 1 && value != 3) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1 or 3");
+        h->variant = (int)value;
+        return IODINE_OK;
+    }
     if (!strcmp(key, "conv_precision")) {
         if (value != 0 && value != 1) return h->fail(IODINE_ERR_INVALID, "conv_precision must be 0 (f32) or 1 (f16x3)");
         h->precision = (int)value;
@@ -871,13 +885,15 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, c
 {
     hipStream_t st = (hipStream_t)stream;
     float* wpk = nullptr;
-    if (mode == 2) {                       // split-fp16 tile kernel
+    if (mode == 2 || mode == 4) {          // split-fp16 tile kernels (4 = warp-specialised persistent variant)
         float* meta = nullptr;
         const size_t bytes = (size_t)(cin_pad / 16) * 9 * 2 * 2 * cout * 16;
         if (hipMalloc((void**)&wpk, bytes + 64) != hipSuccess) return IODINE_ERR_HIP;
         meta = (float*)((char*)wpk + bytes);
         hipError_t e2 = launch_pack_conv_weights_f16(st, w, w_o, w_i, cin_pad, cout, tflip, meta, wpk);
-        if (e2 == hipSuccess) e2 = launch_conv3x3_tile_f16x3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi);
+        if (e2 == hipSuccess)
+            e2 = mode == 2 ? launch_conv3x3_tile_f16x3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi)
+                           : launch_conv3x3_tile_f16x3_v3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
         (void)hipFree(wpk);
         if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(f16x3): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }

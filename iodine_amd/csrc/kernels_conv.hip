@@ -6,6 +6,9 @@
 // v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain, so results differ from the CPU path only
 // by summation order.
 #include "common.h"
+#include <cstdlib>
+#include <cstdio>
+#include <type_traits>
 
 // =========================================================================================
 // weight packer: OIHW (or its dgrad transform) -> wpk[chunk][quad][co] float4
@@ -493,16 +496,17 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 {
     constexpr int NCHUNK = CIN / 16;
     constexpr int NT = COUT / 32;
-    constexpr int HALO = 18;
+    constexpr int HALO = 18, NPX = HALO * HALO;
     constexpr int PXS = 80;                              // bytes per staged pixel: 32 hi + 32 lo + 16 pad
-    constexpr int IN_BYTES = HALO * HALO * PXS;          // 25920
+    constexpr int IN_BYTES = (NPX + 1) * PXS;            // +1 pixel: dump slot for idle lanes
     constexpr int W_U4 = 9 * 2 * 2 * COUT;               // uint4 (8 x fp16) per chunk
-    constexpr int NIN = (HALO * HALO * 4 + 255) / 256;   // float4 loads per thread per chunk (6)
+    constexpr int NIN = (NPX * 4 + 255) / 256;           // float4 loads per thread per chunk (6)
     constexpr int NW = (W_U4 + 255) / 256;               // uint4 loads per thread per chunk
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* s_in = smem_b;
     uint4* s_w = reinterpret_cast<uint4*>(smem_b + IN_BYTES);
+    float* s_max = reinterpret_cast<float*>(smem_b + IN_BYTES + W_U4 * 16);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, kh = lane >> 5, li = lane & 31;
@@ -512,8 +516,17 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     const int tx = bid % tiles; bid /= tiles;
     const int ty = bid % tiles;
     const int n = bid / tiles;
-    const int y0 = ty * 16 - 1, x0 = tx * 16 - 1;
-    const float* in_n = in + (size_t)n * S * S * CIN;
+
+    // element offsets of this thread's halo float4s (32-bit: tensors are < 2^31 floats); -1 = outside the image / idle
+    int goff[NIN];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        const int idx = tid + k * 256;
+        const int px = idx >> 2, cq = idx & 3;
+        const int gy = ty * 16 - 1 + px / HALO, gx = tx * 16 - 1 + px % HALO;
+        const bool ok = idx < NPX * 4 && gy >= 0 && gy < S && gx >= 0 && gx < S;
+        goff[k] = ok ? ((n * S + gy) * S + gx) * CIN + cq * 4 : -1;
+    }
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -524,36 +537,33 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     float4 rin[NIN];
-    uint4 rw[NW];
-
     auto prefetch = [&](int chunk) {
+        const float* base = in + chunk * 16;
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
-            const int idx = tid + k * 256;
-            const int px = idx >> 2, cq = idx & 3;
-            const int gy = y0 + px / HALO, gx = x0 + px % HALO;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < HALO * HALO * 4 && gy >= 0 && gy < S && gx >= 0 && gx < S)
-                v = *reinterpret_cast<const float4*>(in_n + ((size_t)gy * S + gx) * CIN + chunk * 16 + cq * 4);
-            rin[k] = v;
-        }
-        const uint4* wsrc = wpk + (size_t)chunk * W_U4;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const int idx = tid + k * 256;
-            rw[k] = idx < W_U4 ? wsrc[idx] : make_uint4(0, 0, 0, 0);
+            const bool ok = goff[k] >= 0;
+            const float4 v = *reinterpret_cast<const float4*>(base + (ok ? goff[k] : 0));
+            rin[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     // Block-local dynamic range: before a chunk is split into fp16 (hi, lo) it is multiplied by a power of two
     // chosen from the chunk tile's max |x| (so that small-magnitude tensors such as gradients keep their lo parts
     // out of the fp16 subnormal range); the accumulators are rescaled (exactly) when the scale changes.
-    float* s_max = reinterpret_cast<float*>(smem_b + IN_BYTES + W_U4 * 16);
+    // (The packed weights of the chunk are fetched inside commit(): a register array that lives across the inline-asm
+    // MFMA section gets demoted to scratch by hipcc, and they are L2-resident anyway.)
     float cur_scale = 1.f;
-    auto commit = [&]() -> float {
+    auto commit = [&](int chunk) -> float {
+        uint4 rw[NW];
+        const uint4* wsrc = wpk + (size_t)chunk * W_U4;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int idx = tid + k * 256;
+            rw[k] = idx < W_U4 ? wsrc[idx] : make_uint4(0u, 0u, 0u, 0u);
+        }
         float m = 0.f;
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
-            const float4 v = rin[k];                         // out-of-range slots were loaded as zeros
+            const float4 v = rin[k];
             m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         }
 #pragma unroll
@@ -568,17 +578,21 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
             const int idx = tid + k * 256;
-            if (idx < HALO * HALO * 4) {
-                const int px = idx >> 2, cq = idx & 3;
-                float4 v = rin[k];
-                v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-                f16x4 hi, lo;
-                hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-                lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
-                lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
-                *reinterpret_cast<f16x4*>(s_in + px * PXS + cq * 8) = hi;
-                *reinterpret_cast<f16x4*>(s_in + px * PXS + 32 + cq * 8) = lo;
-            }
+            const int px = idx < NPX * 4 ? idx >> 2 : NPX, cq = idx & 3;          // idle lanes write the dump slot
+            float4 v = rin[k];
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            // hi = v truncated to fp16 precision (mask the 13 low mantissa bits: exact in fp16 for the scaled range),
+            // lo = v - hi (exact in fp32); both packed with v_cvt_pkrtz (two values per instruction)
+            const float hx = __uint_as_float(__float_as_uint(v.x) & 0xffffe000u), hy = __uint_as_float(__float_as_uint(v.y) & 0xffffe000u);
+            const float hz = __uint_as_float(__float_as_uint(v.z) & 0xffffe000u), hw = __uint_as_float(__float_as_uint(v.w) & 0xffffe000u);
+            typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+            const h2 h01 = __builtin_amdgcn_cvt_pkrtz(hx, hy), h23 = __builtin_amdgcn_cvt_pkrtz(hz, hw);
+            const h2 l01 = __builtin_amdgcn_cvt_pkrtz(v.x - hx, v.y - hy), l23 = __builtin_amdgcn_cvt_pkrtz(v.z - hz, v.w - hw);
+            uint2 hi, lo;
+            __builtin_memcpy(&hi.x, &h01, 4); __builtin_memcpy(&hi.y, &h23, 4);
+            __builtin_memcpy(&lo.x, &l01, 4); __builtin_memcpy(&lo.y, &l23, 4);
+            *reinterpret_cast<uint2*>(s_in + px * PXS + cq * 8) = hi;
+            *reinterpret_cast<uint2*>(s_in + px * PXS + 32 + cq * 8) = lo;
         }
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
@@ -601,38 +615,69 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         }
     };
 
+    // Fragment reads are inline-asm ds_read_b128 (invisible to hipcc's wait-count pass, which otherwise drains
+    // lgkmcnt(0) - including the reads just issued for the NEXT tap - in front of every MFMA group).  LDS returns in
+    // order, so a counted wait after issuing the next tap's 4 + 2*NT reads retires exactly the current tap's fragments.
+    struct Frag { f16x8 ah[2], al[2], bh[NT], bl[NT]; };
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_b;
+    const unsigned a_addr0 = lds_base + ((4 * wv + prow) * HALO + pcol) * PXS + kh * 16;
+    const unsigned a_addr1 = a_addr0 + 2 * HALO * PXS;
+    const unsigned b_addr = lds_base + IN_BYTES + (kh * COUT + li) * 16;
+#define IOD_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    auto LOADF = [&](auto tapc, Frag& f) {
+        constexpr int tap = decltype(tapc)::value;
+        constexpr int aoff = ((tap / 3) * HALO + (tap % 3)) * PXS;
+        constexpr int boff = tap * 4 * COUT * 16;
+        IOD_DSR128(f.ah[0], a_addr0, aoff);
+        IOD_DSR128(f.al[0], a_addr0, aoff + 32);
+        IOD_DSR128(f.ah[1], a_addr1, aoff);
+        IOD_DSR128(f.al[1], a_addr1, aoff + 32);
+        IOD_DSR128(f.bh[0], b_addr, boff);
+        IOD_DSR128(f.bl[0], b_addr, boff + 2 * COUT * 16);
+        if constexpr (NT == 2) {
+            IOD_DSR128(f.bh[1], b_addr, boff + 512);
+            IOD_DSR128(f.bl[1], b_addr, boff + 2 * COUT * 16 + 512);
+        }
+    };
+#undef IOD_DSR128
+    auto MMA = [&](const Frag& f) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+    };
+    using std::integral_constant;
+#define IOD_STEP(T, FCUR, FNEXT)                                                                  \
+    if constexpr (T + 1 < 9) LOADF(integral_constant<int, (T + 1 < 9 ? T + 1 : 8)>{}, FNEXT);       \
+    if constexpr (T + 1 < 9) { if (NT == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      \
+                               else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); }            \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    MMA(FCUR);                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+
     prefetch(0);
-    cur_scale = commit();
+    cur_scale = commit(0);
     for (int chunk = 0; chunk < NCHUNK; ++chunk) {
         if (chunk + 1 < NCHUNK) prefetch(chunk + 1);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
-            f16x8 ah[2], al[2], bh[NT], bl[NT];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int hy = 4 * wv + 2 * mt + prow + dy, hx = pcol + dx;
-                const unsigned char* p = s_in + (hy * HALO + hx) * PXS + kh * 16;
-                ah[mt] = *reinterpret_cast<const f16x8*>(p);
-                al[mt] = *reinterpret_cast<const f16x8*>(p + 32);
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const uint4* q = s_w + ((tap * 2 + 0) * 2 + kh) * COUT + nt * 32 + li;
-                bh[nt] = *reinterpret_cast<const f16x8*>(q);
-                bl[nt] = *reinterpret_cast<const f16x8*>(q + 2 * COUT);
-            }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                }
-        }
-        if (chunk + 1 < NCHUNK) rescale(commit());
+        Frag f0, f1;
+        LOADF(integral_constant<int, 0>{}, f0);
+        IOD_STEP(0, f0, f1) IOD_STEP(1, f1, f0) IOD_STEP(2, f0, f1) IOD_STEP(3, f1, f0) IOD_STEP(4, f0, f1)
+        IOD_STEP(5, f1, f0) IOD_STEP(6, f0, f1) IOD_STEP(7, f1, f0) IOD_STEP(8, f0, f1)
+        if (chunk + 1 < NCHUNK) rescale(commit(chunk + 1));
     }
+#undef IOD_STEP
 
     const float inv_ws = wmeta[1] / cur_scale;
 #pragma unroll
@@ -648,12 +693,13 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
                 const int gy = ty * 16 + 4 * wv + 2 * mt + (m >> 4);
                 const int gx = tx * 16 + (m & 15);
-                const size_t o = (((size_t)n * S + gy) * S + gx) * COUT + co;
+                const int pix = (n * S + gy) * S + gx;
                 float v = acc[mt][nt][r] * inv_ws;
                 if (EPI == EPI_OUT4) {                   // decoder output conv: 4 real channels, out is [N][P][4]
-                    if (li < 4) out[(((size_t)n * S + gy) * S + gx) * 4 + li] = v + bv;
+                    if (li < 4) out[(size_t)pix * 4 + li] = v + bv;
                     continue;
                 }
+                const size_t o = (size_t)pix * COUT + co;
                 if (EPI == EPI_BIAS_ELU) v = elu1_fast(v + bv);
                 else if (EPI == EPI_MUL_ELUGRAD) v *= elu1_grad_from_out(aux[o]);
                 out[o] = v;
@@ -665,7 +711,7 @@ template <int CIN, int COUT, int EPI>
 static hipError_t launch_tile_f16x3_inst(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                          const float* bias, const float* aux, float* out, int N, int S)
 {
-    constexpr size_t lds = (size_t)18 * 18 * 80 + (size_t)9 * 2 * 2 * COUT * 16 + 16;
+    constexpr size_t lds = (size_t)(18 * 18 + 1) * 80 + (size_t)9 * 2 * 2 * COUT * 16 + 16;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_tile_f16x3_kernel<CIN, COUT, EPI>,
@@ -690,5 +736,372 @@ hipError_t launch_conv3x3_tile_f16x3(hipStream_t st, const float* in, const void
     T16_CASE(32, 32, EPI_BIAS_ELU) T16_CASE(32, 32, EPI_MUL_ELUGRAD)
     T16_CASE(64, 32, EPI_OUT4) T16_CASE(32, 32, EPI_OUT4)
 #undef T16_CASE
+    return hipErrorInvalidValue;
+}
+
+// =========================================================================================
+// v3 of the split-fp16 tile conv: warp-specialised persistent kernel.  512 threads, one block per CU:
+//   waves 0-3  CONSUMERS: LDS fragment reads + MFMA only (64 px x COUT per wave), epilogue stores
+//   waves 4-7  PRODUCERS: global loads (input halo chunk 3 steps ahead, packed weights 2 steps ahead), power-of-two
+//              scaling, fp32 -> fp16 hi/lo split, LDS writes into the OTHER buffer, tile-chunk max |x|
+// One raw s_barrier per (tile, chunk) step; no LDS-DMA (so hipcc keeps counted vmcnt waits) and no conditional
+// stages (steps past the end are clamped and land in buffers nobody reads).  The measured serialisation of the
+// one-tile-per-block kernel (load 0.25 + convert 0.24 + MFMA 0.49 + store 0.13 ms per 64->64 layer at cfg3) is
+// what this removes: producers and consumers are different waves on the same SIMDs, MFMA and VALU/VMEM co-issue.
+// =========================================================================================
+template <int CIN, int COUT, int EPI>
+__global__ __launch_bounds__(512, 2)
+void conv3x3_tile_f16x3_v3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk,
+                                  const float* __restrict__ wmeta, const float* __restrict__ bias,
+                                  const float* __restrict__ aux, float* __restrict__ out, int S, int tiles, int ntiles,
+                                  int flags, unsigned long long* __restrict__ prof)
+{
+    constexpr int NCHUNK = CIN / 16;
+    constexpr int NT = COUT / 32;
+    constexpr int HALO = 18, PXS = 80, NPX = HALO * HALO, IN_BYTES = (NPX + 1) * PXS;
+    constexpr int W_U4 = 9 * 2 * 2 * COUT, W_BYTES = W_U4 * 16;
+    constexpr int NPT = 192;                               // input-producer threads (waves 4-6); wave 7 streams weights
+    constexpr int NIN = (NPX * 4 + NPT - 1) / NPT;         // float4 per input-producer thread per chunk (7)
+    constexpr int W_PIECES = W_U4 / 64;                    // 1 KiB LDS-DMA pieces per chunk (36 / 18)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    float* s_max = reinterpret_cast<float*>(smem_b + 2 * IN_BYTES + 3 * W_BYTES);        // [3][4]
+    // weights are TRIPLE buffered (slot = step % 3) so that a chunk's weights are fetched and stored within one
+    // producer iteration (no register array living across barriers)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, kh = lane >> 5, li = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wv >= 4;
+    const int ptid = tid - 256;                             // input-producer thread index (0..191)
+    const int cwv = wv & 3;                                 // consumer wave: tile rows 4*cwv .. +3
+
+    const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nq = my_tiles * NCHUNK;
+    if (nq == 0) return;
+
+    auto tile_coords = [&](int q, int& n, int& ty, int& tx) {
+        int t = blockIdx.x + (q / NCHUNK) * gridDim.x;
+        tx = t % tiles; t /= tiles;
+        ty = t % tiles; n = t / tiles;
+    };
+    auto SCALE = [&](int slot) -> float {
+        if (flags & 8) return 1.f;
+        const float* p = s_max + slot * 4;
+        const float mb = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
+        const int e = (int)((__float_as_uint(mb) >> 23) & 0xffu) - 127;
+        int se = 12 - e;
+        se = se > 100 ? 100 : (se < -100 ? -100 : se);
+        return (mb > 0.f && mb < 3.0e38f) ? __uint_as_float((unsigned)(127 + se) << 23) : 1.f;
+    };
+    unsigned long long t_wait = 0, t_last = __builtin_amdgcn_s_memtime(), t_work = 0;
+    auto block_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes / reads retired
+        if (prof) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            t_work += t0 - t_last; t_wait += t1 - t0; t_last = t1;
+        } else {
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    auto prof_flush = [&](int role) {
+        if (prof && lane == 0) { atomicAdd(&prof[role * 2], t_work); atomicAdd(&prof[role * 2 + 1], t_wait); }
+    };
+
+    if (producer && wv == 7) {
+        // ------------------------------------------------------------ WEIGHT STREAMER ----
+        // packed fp16 weights go global -> LDS by DMA (no VGPR round trip); this wave issues nothing else, so its
+        // vmcnt(0) before each barrier only covers its own pieces.
+        auto DMA = [&](int q_, int wslot) {
+            const int q = q_ < nq ? q_ : nq - 1;
+            const uint4* wsrc = wpk + (size_t)(q % NCHUNK) * W_U4;
+            unsigned char* wdst = smem_b + 2 * IN_BYTES + wslot * W_BYTES;
+#pragma unroll 4
+            for (int piece = 0; piece < W_PIECES; ++piece)
+                if (!(flags & 4)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + piece * 64 + lane),
+                                                 (__attribute__((address_space(3))) void*)(wdst + piece * 1024), 16, 0, 0);
+        };
+        auto wbarrier = [&]() {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (prof) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_s_barrier();
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                t_work += t0 - t_last; t_wait += t1 - t0; t_last = t1;
+            } else {
+                __builtin_amdgcn_s_barrier();
+            }
+        };
+        DMA(0, 0);
+        DMA(1, 1);
+        if (lane == 0) { s_max[3] = 0.f; s_max[7] = 0.f; s_max[11] = 0.f; }      // unused 4th producer slot
+        wbarrier();                                         // P1
+        wbarrier();                                         // P2
+        for (int q = 0; q < nq; ++q) {
+            DMA(q + 2, (q + 2) % 3);
+            wbarrier();
+        }
+        prof_flush(2);
+        return;
+    }
+    if (producer) {
+        // ------------------------------------------------------------ INPUT PRODUCERS ----
+        // per-thread element offsets of its NIN halo float4s inside the current look-ahead tile (32-bit: tensors are
+        // < 2^31 floats), recomputed only when the look-ahead step enters a new tile; -1 = outside the image / idle
+        int goff[NIN];
+        auto tile_offsets = [&](int q) {
+            int n, ty, tx;
+            tile_coords(q, n, ty, tx);
+            const int y0 = ty * 16 - 1, x0 = tx * 16 - 1;
+            const int nbase = n * S * S;
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) {
+                const int idx = ptid + k * NPT;
+                const int px = idx >> 2, cq = idx & 3;
+                const int gy = y0 + px / HALO, gx = x0 + px % HALO;
+                const bool ok = idx < NPX * 4 && gy >= 0 && gy < S && gx >= 0 && gx < S;
+                goff[k] = ok ? (nbase + gy * S + gx) * CIN + cq * 4 : -1;
+            }
+        };
+        auto G = [&](int q_, float4 (&r)[NIN]) {
+            const int q = q_ < nq ? q_ : nq - 1;
+            if (q % NCHUNK == 0 || q_ <= 2) tile_offsets(q);            // block-uniform
+            const float* base = in + (q % NCHUNK) * 16;
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) {
+                const bool ok = goff[k] >= 0 && !(flags & 2);
+                const float4 v = *reinterpret_cast<const float4*>(base + (ok ? goff[k] : 0));
+                r[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto MAXPUB = [&](int slot, const float4 (&r)[NIN]) {
+            if (flags & 8) return;
+            float m = 0.f;
+#pragma unroll
+            for (int k = 0; k < NIN; ++k)
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(r[k].x), fabsf(r[k].y)), fmaxf(fabsf(r[k].z), fabsf(r[k].w))));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            if (lane == 0) s_max[slot * 4 + (wv - 4)] = m;
+        };
+        auto WIN = [&](int q, const float4 (&r)[NIN], float scale) {
+            if (flags & 32) return;
+            unsigned char* s_in = smem_b + (q & 1) * IN_BYTES;
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) {
+                const int idx = ptid + k * NPT;
+                const int px = idx < NPX * 4 ? idx >> 2 : NPX, cq = idx & 3;      // idle lanes write the dump slot
+                float4 v = r[k];
+                v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+                // hi = v truncated to fp16 precision (mask the 13 low mantissa bits: exact in fp16 for the scaled
+                // range), lo = v - hi (exact in fp32), both packed with v_cvt_pkrtz (2 values per instruction)
+                const float hx = __uint_as_float(__float_as_uint(v.x) & 0xffffe000u), hy = __uint_as_float(__float_as_uint(v.y) & 0xffffe000u);
+                const float hz = __uint_as_float(__float_as_uint(v.z) & 0xffffe000u), hw = __uint_as_float(__float_as_uint(v.w) & 0xffffe000u);
+                typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+                const h2 h01 = __builtin_amdgcn_cvt_pkrtz(hx, hy), h23 = __builtin_amdgcn_cvt_pkrtz(hz, hw);
+                const h2 l01 = __builtin_amdgcn_cvt_pkrtz(v.x - hx, v.y - hy), l23 = __builtin_amdgcn_cvt_pkrtz(v.z - hz, v.w - hw);
+                uint2 hi, lo;
+                __builtin_memcpy(&hi.x, &h01, 4); __builtin_memcpy(&hi.y, &h23, 4);
+                __builtin_memcpy(&lo.x, &l01, 4); __builtin_memcpy(&lo.y, &l23, 4);
+                *reinterpret_cast<uint2*>(s_in + px * PXS + cq * 8) = hi;
+                *reinterpret_cast<uint2*>(s_in + px * PXS + 32 + cq * 8) = lo;
+            }
+        };
+
+        float4 R0[NIN], R1[NIN], R2[NIN];
+        // prologue: stage chunk 0, chunks 1 and 2 in flight, max(1) published
+        G(0, R0);
+        G(1, R1); G(2, R2);
+        MAXPUB(0, R0);
+        block_barrier();                                    // P1: max(0) visible
+        WIN(0, R0, SCALE(0));
+        MAXPUB(1, R1);
+        block_barrier();                                    // P2: chunk 0 staged, max(1) visible
+
+        // iteration q: fetch input q+3, stage input q+1, publish max(q+2)
+        auto iteration = [&](int q, int sl, float4 (&Rnext)[NIN], float4 (&Rmax)[NIN], float4 (&Rload)[NIN]) {
+            G(q + 3, Rload);
+            WIN(q + 1, Rnext, SCALE((sl + 1) % 3));
+            MAXPUB((sl + 2) % 3, Rmax);
+            block_barrier();
+        };
+        for (int q = 0; q < nq; q += 3) {
+            iteration(q, 0, R1, R2, R0);
+            if (q + 1 < nq) iteration(q + 1, 1, R2, R0, R1);
+            if (q + 2 < nq) iteration(q + 2, 2, R0, R1, R2);
+        }
+        prof_flush(1);
+        return;
+    }
+
+    // ---------------------------------------------------------------------- CONSUMER ----
+    const int prow = li >> 4, pcol = li & 15;
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    const float inv_ws = wmeta[1];
+    block_barrier();                                        // P1
+    float cur_scale = SCALE(0);
+    block_barrier();                                        // P2
+
+    struct Frag { f16x8 ah[2], al[2], bh[NT], bl[NT]; };
+    for (int q = 0; q < nq; ++q) {
+        const int sl = q % 3;
+        const float sc_next = SCALE((sl + 1) % 3);
+        // Fragment reads are issued as inline-asm ds_read_b128 (invisible to hipcc's wait-count pass, which otherwise
+        // drains lgkmcnt(0) - including the reads just issued for the NEXT tap - in front of every MFMA group).
+        // LDS returns in order, so "lgkmcnt(8)" after issuing the next tap's 4 + 2*NT reads retires exactly the
+        // current tap's fragments.
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_b;
+        const unsigned a_addr0 = lds_base + (q & 1) * IN_BYTES + ((4 * cwv + prow) * HALO + pcol) * PXS + kh * 16;
+        const unsigned a_addr1 = a_addr0 + 2 * HALO * PXS;
+        const unsigned b_addr = lds_base + 2 * IN_BYTES + sl * W_BYTES + (kh * COUT + li) * 16;
+#define IOD_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+        auto LOADF = [&](auto tapc, Frag& f) {
+            constexpr int tap = decltype(tapc)::value;
+            constexpr int aoff = ((tap / 3) * HALO + (tap % 3)) * PXS;
+            constexpr int boff = tap * 4 * COUT * 16;
+            IOD_DSR128(f.ah[0], a_addr0, aoff);
+            IOD_DSR128(f.al[0], a_addr0, aoff + 32);
+            IOD_DSR128(f.ah[1], a_addr1, aoff);
+            IOD_DSR128(f.al[1], a_addr1, aoff + 32);
+            IOD_DSR128(f.bh[0], b_addr, boff);
+            IOD_DSR128(f.bl[0], b_addr, boff + 2 * COUT * 16);
+            if constexpr (NT == 2) {
+                IOD_DSR128(f.bh[1], b_addr, boff + 512);
+                IOD_DSR128(f.bl[1], b_addr, boff + 2 * COUT * 16 + 512);
+            }
+        };
+#undef IOD_DSR128
+        auto MMA = [&](const Frag& f) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+        };
+        Frag f0, f1;
+        using std::integral_constant;
+#define IOD_STEP(T, FCUR, FNEXT)                                                                  \
+        if constexpr (T + 1 < 9) LOADF(integral_constant<int, (T + 1 < 9 ? T + 1 : 8)>{}, FNEXT);   \
+        if constexpr (T + 1 < 9) { if (NT == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  \
+                                   else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); }        \
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        if (!(flags & 1)) MMA(FCUR);                                                                \
+        __builtin_amdgcn_sched_barrier(0);
+        LOADF(integral_constant<int, 0>{}, f0);
+        IOD_STEP(0, f0, f1) IOD_STEP(1, f1, f0) IOD_STEP(2, f0, f1) IOD_STEP(3, f1, f0) IOD_STEP(4, f0, f1)
+        IOD_STEP(5, f1, f0) IOD_STEP(6, f0, f1) IOD_STEP(7, f1, f0) IOD_STEP(8, f0, f1)
+#undef IOD_STEP
+        if (q % NCHUNK == NCHUNK - 1) {
+            int n, ty, tx;
+            tile_coords(q, n, ty, tx);
+            const float inv = inv_ws / cur_scale;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int co = nt * 32 + li;
+                    float bv = 0.f;
+                    if (EPI == EPI_BIAS_ELU) bv = bias[co];
+                    if (EPI == EPI_OUT4) bv = li < 4 ? bias[li] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        const int gy = ty * 16 + 4 * cwv + 2 * mt + (m >> 4);
+                        const int gx = tx * 16 + (m & 15);
+                        float v = acc[mt][nt][r] * inv;
+                        acc[mt][nt][r] = 0.f;
+                        if (flags & 16) continue;
+                        if (EPI == EPI_OUT4) {
+                            if (li < 4) out[(((size_t)n * S + gy) * S + gx) * 4 + li] = v + bv;
+                            continue;
+                        }
+                        const size_t o = (((size_t)n * S + gy) * S + gx) * COUT + co;
+                        if (EPI == EPI_BIAS_ELU) v = elu1_fast(v + bv);
+                        else if (EPI == EPI_MUL_ELUGRAD) v *= elu1_grad_from_out(aux[o]);
+                        out[o] = v;
+                    }
+                }
+            cur_scale = sc_next;
+        } else if (sc_next != cur_scale) {
+            const float r = sc_next / cur_scale;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[mt][nt][e] *= r;
+            cur_scale = sc_next;
+        }
+        block_barrier();
+    }
+    prof_flush(0);
+}
+
+template <int CIN, int COUT, int EPI>
+static hipError_t launch_tile_f16x3_v3_inst(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
+                                            const float* bias, const float* aux, float* out, int N, int S)
+{
+    constexpr size_t lds = (size_t)2 * (18 * 18 + 1) * 80 + (size_t)3 * 9 * 2 * 2 * COUT * 16 + 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_tile_f16x3_v3_kernel<CIN, COUT, EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles = S / 16, ntiles = N * tiles * tiles;
+    const int blocks = ntiles < 256 ? ntiles : 256;
+    static int flags = -1;
+    if (flags < 0) { const char* e = getenv("IODINE_CONV_ABLATE"); flags = e ? atoi(e) : 0; }
+    unsigned long long* prof = nullptr;
+    if (getenv("IODINE_CONV_PROF")) {                       // debug: per-role work / barrier-wait cycle totals
+        static unsigned long long* dprof = nullptr;
+        if (!dprof) (void)hipMalloc((void**)&dprof, 64);
+        (void)hipMemsetAsync(dprof, 0, 64, st);
+        prof = dprof;
+    }
+    hipLaunchKernelGGL((conv3x3_tile_f16x3_v3_kernel<CIN, COUT, EPI>), dim3(blocks), dim3(512), lds, st, in,
+                       reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, S, tiles, ntiles, flags, prof);
+    if (prof) {
+        unsigned long long hp[8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hp, prof, 64, hipMemcpyDeviceToHost);
+        const double nb = blocks;
+        fprintf(stderr, "[v3 prof] per-wave avg memtime ticks: consumer work %.0f wait %.0f | producer work %.0f wait %.0f | weights work %.0f wait %.0f\n",
+                hp[0] / (4 * nb), hp[1] / (4 * nb), hp[2] / (3 * nb), hp[3] / (3 * nb), hp[4] / nb, hp[5] / nb);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_tile_f16x3_v3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
+                                        const float* bias, const float* aux, float* out, int N, int S, int cin, int cout,
+                                        int epi)
+{
+    if (S % 16 != 0) return hipErrorInvalidValue;
+#define T16V3_CASE(CI, CO, EP) \
+    if (cin == CI && cout == CO && epi == EP) return launch_tile_f16x3_v3_inst<CI, CO, EP>(st, in, wpk, wmeta, bias, aux, out, N, S);
+    T16V3_CASE(64, 64, EPI_BIAS_ELU) T16V3_CASE(64, 64, EPI_MUL_ELUGRAD)
+    T16V3_CASE(32, 32, EPI_BIAS_ELU) T16V3_CASE(32, 32, EPI_MUL_ELUGRAD)
+    T16V3_CASE(64, 32, EPI_OUT4) T16V3_CASE(32, 32, EPI_OUT4)
+#undef T16V3_CASE
     return hipErrorInvalidValue;
 }

@@ -87,17 +87,18 @@ def test_dec_out_conv(C_, S, N):
     assert rel_err(out.cpu(), ref) < 2e-6
 
 
-@pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 2), (64, 128, 1)])
-def test_conv_tile_f16x3_forward_and_dgrad(C_, S, N):
+@pytest.mark.parametrize('mode', [2, 4])
+@pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 2), (64, 128, 1), (64, 16, 300), (32, 32, 70)])
+def test_conv_tile_f16x3_forward_and_dgrad(C_, S, N, mode):
     """split-fp16 (hi+lo, 3 MFMA) variant: fp32-class accuracy (dropped lo*lo term ~2^-22)"""
     x = _rand(N, C_, S, S, seed=21)
     w = _rand(C_, C_, 3, 3, seed=22, scale=3.0 / (C_ * 9) ** 0.5)
     b = _rand(C_, seed=23, scale=0.5)
     ref = nhwc(F.elu(F.conv2d(x.double(), w.double(), b.double(), padding=1))).float()
-    got = _conv_op(2, nhwc(x), w, b, None, N, S, S, C_, C_, C_, C_, 1, 0, 0, ref.shape)
+    got = _conv_op(mode, nhwc(x), w, b, None, N, S, S, C_, C_, C_, C_, 1, 0, 0, ref.shape)
     assert rel_err(got, ref) < 3e-6, rel_err(got, ref)
     g = _rand(N, C_, S, S, seed=24, scale=1e-3)                  # small-magnitude gradients
     a = F.elu(_rand(N, C_, S, S, seed=25, scale=2.0))
     refd = (F.conv_transpose2d(g.double(), w.double(), padding=1) * torch.where(a > 0, torch.ones_like(a), a + 1).double()).float()
-    gotd = _conv_op(2, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 1, 1, nhwc(refd).shape)
+    gotd = _conv_op(mode, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 1, 1, nhwc(refd).shape)
     assert rel_err(gotd, nhwc(refd)) < 3e-6, rel_err(gotd, nhwc(refd))
