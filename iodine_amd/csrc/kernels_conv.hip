@@ -536,8 +536,12 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    float4 rin[NIN];
-    auto prefetch = [&](int chunk) {
+    // The chunk loop is fully unrolled (straight-line code keeps hipcc's vmcnt waits COUNTED: a loop back-edge makes it
+    // drain vmcnt(0), i.e. wait for the prefetch it has just issued).  Input chunks are fetched two steps ahead into two
+    // alternating register sets, the (L2-resident) packed weights one step ahead.
+    float4 rinA[NIN], rinB[NIN];
+    uint4 rw[NW];
+    auto prefetch_in = [&](int chunk, float4 (&rin)[NIN]) {
         const float* base = in + chunk * 16;
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
@@ -546,20 +550,19 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             rin[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    // Block-local dynamic range: before a chunk is split into fp16 (hi, lo) it is multiplied by a power of two
-    // chosen from the chunk tile's max |x| (so that small-magnitude tensors such as gradients keep their lo parts
-    // out of the fp16 subnormal range); the accumulators are rescaled (exactly) when the scale changes.
-    // (The packed weights of the chunk are fetched inside commit(): a register array that lives across the inline-asm
-    // MFMA section gets demoted to scratch by hipcc, and they are L2-resident anyway.)
-    float cur_scale = 1.f;
-    auto commit = [&](int chunk) -> float {
-        uint4 rw[NW];
+    auto prefetch_w = [&](int chunk) {
         const uint4* wsrc = wpk + (size_t)chunk * W_U4;
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
             const int idx = tid + k * 256;
-            rw[k] = idx < W_U4 ? wsrc[idx] : make_uint4(0u, 0u, 0u, 0u);
+            rw[k] = idx < W_U4 ? wsrc[idx] : make_uint4(0u, 0u, 0u, 0u);    // (a clamped index here sends rw to scratch)
         }
+    };
+    // Block-local dynamic range: before a chunk is split into fp16 (hi, lo) it is multiplied by a power of two
+    // chosen from the chunk tile's max |x| (so that small-magnitude tensors such as gradients keep their lo parts
+    // out of the fp16 subnormal range); the accumulators are rescaled (exactly) when the scale changes.
+    float cur_scale = 1.f;
+    auto commit = [&](const float4 (&rin)[NIN]) -> float {
         float m = 0.f;
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
@@ -667,16 +670,35 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     MMA(FCUR);                                                                                      \
     __builtin_amdgcn_sched_barrier(0);
 
-    prefetch(0);
-    cur_scale = commit(0);
-    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
-        if (chunk + 1 < NCHUNK) prefetch(chunk + 1);
+    auto compute = [&]() {
         Frag f0, f1;
         LOADF(integral_constant<int, 0>{}, f0);
         IOD_STEP(0, f0, f1) IOD_STEP(1, f1, f0) IOD_STEP(2, f0, f1) IOD_STEP(3, f1, f0) IOD_STEP(4, f0, f1)
         IOD_STEP(5, f1, f0) IOD_STEP(6, f0, f1) IOD_STEP(7, f1, f0) IOD_STEP(8, f0, f1)
-        if (chunk + 1 < NCHUNK) rescale(commit(chunk + 1));
+    };
+    prefetch_in(0, rinA);
+    prefetch_w(0);
+    if (NCHUNK > 1) prefetch_in(1, rinB);
+    cur_scale = commit(rinA);                                // chunk 0 staged (waits for rinA + rw only)
+    if (NCHUNK > 1) prefetch_w(1);
+    if (NCHUNK > 2) prefetch_in(2, rinA);
+    compute();                                               // chunk 0
+    if constexpr (NCHUNK > 1) {
+        rescale(commit(rinB));                               // chunk 1 staged
+        if (NCHUNK > 2) prefetch_w(2);
+        if (NCHUNK > 3) prefetch_in(3, rinB);
+        compute();                                           // chunk 1
     }
+    if constexpr (NCHUNK > 2) {
+        rescale(commit(rinA));
+        if (NCHUNK > 3) prefetch_w(3);
+        compute();                                           // chunk 2
+    }
+    if constexpr (NCHUNK > 3) {
+        rescale(commit(rinB));
+        compute();                                           // chunk 3
+    }
+    static_assert(NCHUNK <= 4, "chunk schedule is unrolled for at most 64 input channels");
 #undef IOD_STEP
 
     const float inv_ws = wmeta[1] / cur_scale;
