@@ -32,6 +32,8 @@ from iodine_amd import IODINE, parallel, synth  # noqa: E402
 from iodine_amd.model import clevr6_arch, dsprites_arch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (the 5 PF headline is 2:1 sparse)
+SPLIT_PASSES = 3                   # fp32 product = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, three f16 MFMAs, fp32 accumulate
 PUBLISHED_TRAIN_ITERS_PER_S = 94.0  # 1.7 s / 32-image T=5 training step on 4 unknown GPUs (log.md:3)
 
 
@@ -45,6 +47,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--slots', type=int, default=None)
     ap.add_argument('--iters', type=int, default=None)
+    ap.add_argument('--conv-precision', type=int, choices=[0, 1], default=1,
+                    help='decoder 3x3 convs: 1 = fp32 operands split into fp16 hi+lo, 3 f16 MFMAs (default); 0 = exact fp32 MFMA')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=None)
     return ap.parse_args()
@@ -125,6 +129,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    model.set_option('conv_precision', args.conv_precision)
     for _ in range(args.warmup):
         step()
     model.set_option('profile', 1)
@@ -174,18 +179,32 @@ def main():
     dom_ms = sum(prof[c]['ms_total'] for c in ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad') if c in prof)
     dom_n = sum(prof[c]['launches'] for c in ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad') if c in prof)
     achieved = flops_per_launch / (dom_ms / dom_n * 1e-3) / 1e12 if dom_n else 0.0
-    roofline = dict(bound='mfma', kernel=f'conv3x3_tile_kernel<{C_},{C_}> + conv3x3_wgrad_tile_kernel<{C_},{C_}> '
-                                         f'(decoder 3x3 conv {C_}->{C_}: fwd, dgrad, wgrad launches)',
-                    achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+    if args.conv_precision == 1:
+        # the kernel executes SPLIT_PASSES f16 MFMAs per algorithmic (fp32-class) multiply-add: the peak for ALGORITHMIC
+        # FLOPs is the dense f16 MFMA peak divided by the number of passes
+        peak = PEAK_F16_MFMA_TFLOPS / SPLIT_PASSES
+        kname = (f'conv3x3_tile_f16x3_kernel<{C_},{C_}> + conv3x3_wgrad_f16x3_kernel<{C_},{C_}> (decoder 3x3 conv {C_}->{C_}: '
+                 f'fwd, dgrad, wgrad launches; fp32 in/out, operands split into f16 hi+lo, 3 f16 MFMAs, fp32 accumulate)')
+    else:
+        peak = PEAK_F32_MFMA_TFLOPS
+        kname = (f'conv3x3_tile_kernel<{C_},{C_}> + conv3x3_wgrad_tile_kernel<{C_},{C_}> (decoder 3x3 conv {C_}->{C_}: '
+                 f'fwd, dgrad, wgrad launches; exact fp32 MFMA)')
+    # HBM traffic per launch from the rocprofv3 PMC pass recorded in profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+    # measured on the forward launch of this shape; null for other shapes
+    traffic = 1.05e9 + 0.94e9 if (args.config == 'clevr6' and B == 32 and K == 7 and args.conv_precision == 1) else None
+    roofline = dict(bound='mfma', kernel=kname, achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
+                    frac=round(achieved / peak, 4), traffic=traffic,
                     flops_per_launch=flops_per_launch, avg_launch_ms=round(dom_ms / max(dom_n, 1), 4),
-                    launches=dom_n, kernel_time_share=round(dom_ms / (dt * 1e3), 4))
+                    launches=dom_n, kernel_time_share=round(dom_ms / (dt * 1e3), 4),
+                    executed_mfma_tflops=round(achieved * (SPLIT_PASSES if args.conv_precision == 1 else 1), 1),
+                    algorithmic_hbm_bytes_per_launch=2.0 * B * K * S * S * C_ * 4,
+                    hbm_gbps_algorithmic=round(2.0 * B * K * S * S * C_ * 4 / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9, 1))
 
     out = dict(metric='refinement_iters_per_s', value=round(value, 2), unit='image-refinement-iters/s',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3),
                higher_is_better=True, scaling='weak',
                vs_baseline=(round(value / PUBLISHED_TRAIN_ITERS_PER_S, 3) if args.mode == 'train' and args.config == 'clevr6' else None),
-               dtype='f32', data='synthetic',
+               dtype=('f32 (3xf16-split MFMA convs, f32 accumulate)' if args.conv_precision == 1 else 'f32'), data='synthetic',
                config=dict(workload=f'{"CLEVR6 128x128" if args.config == "clevr6" else "multi-dSprites 64x64"}, '
                                     f'K={K}, T={T}, batch {B}/GPU, {args.mode} step '
                                     f'({"reconstruct: T iterations + final decode" if args.mode == "infer" else "forward + backward, no optimizer"})',
