@@ -113,6 +113,20 @@ int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float*
  * (+=, like autograd's .grad accumulation; zero_grad is the caller's job, train.py:62). */
 int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, float* const* param_grads, int n);
 
+/* optimizer.step() -- lib/engine/train.py:65 with the Adam built by lib/solver/build.py:5-16.  One fused launch over all
+ * tensors.  ptrs_dev[4*t + {0,1,2,3}] = device addresses of {param, grad, exp_avg, exp_avg_sq} of tensor t (as int64),
+ * offsets_dev[t] = first flat element index of tensor t, total = sum of the element counts; step counts from 1.
+ * Semantics of torch.optim.Adam (amsgrad=False, maximize=False, coupled weight decay). */
+int iodine_adam_step(void* stream, const long long* ptrs_dev, const long long* offsets_dev, int n_tensors, long long total,
+                     double lr, double beta1, double beta2, double eps, double weight_decay, int step);
+
+/* ARI evaluation epilogue -- lib/eval/ari_eval.py:25-39 + lib/utils/ari.py:36-52: per-pixel argmax over the K slot masks and
+ * the integer contingency table[b][i][k] = |gt_i AND (argmax == k)|.  mask (B,K,1,S,S) fp32 (device, as returned by
+ * iodine_reconstruct), gt (B,G,S,S) uint8 0/1 (device, padded with empty masks), table (B,G,K) int32 (device, overwritten).
+ * The ARI formula itself (lib/utils/ari.py:6-33, a handful of scalars per image) stays on the host. */
+int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, int batch, int slots, int n_gt, int pixels,
+                     int* table);
+
 /* Options: "stop_after_iters" (debug: run only the first v refinement iterations of reconstruct, no final decode),
  * "profile" (1: bracket every kernel launch with HIP events on the launch stream),
  * "conv_precision" (decoder 3x3 convs: 0 = exact fp32 MFMA, 1 = fp32 operands split into fp16 hi+lo, 3 fp16 MFMAs,

@@ -20,7 +20,7 @@ EXPORTS = (
     'iodine_abi_version', 'iodine_create', 'iodine_destroy', 'iodine_last_error', 'iodine_num_params',
     'iodine_param_info', 'iodine_set_params', 'iodine_workspace_bytes', 'iodine_set_workspace',
     'iodine_reconstruct', 'iodine_decode', 'iodine_train_forward', 'iodine_train_backward',
-    'iodine_set_option', 'iodine_profile_read', 'iodine_debug_copy', 'iodine_linspace_host', 'iodine_op_conv3x3', 'iodine_op_dec_out',
+    'iodine_adam_step', 'iodine_ari_table', 'iodine_set_option', 'iodine_profile_read', 'iodine_debug_copy', 'iodine_linspace_host', 'iodine_op_conv3x3', 'iodine_op_dec_out',
 )
 
 
@@ -76,6 +76,8 @@ def lib() -> C.CDLL:
     L.iodine_decode.argtypes = [vp, vp, ci] + [vp] * 4
     L.iodine_train_forward.argtypes = [vp, vp, ci] + [vp] * 4
     L.iodine_train_backward.argtypes = [vp, vp, cf, C.POINTER(vp), ci]
+    L.iodine_adam_step.argtypes = [vp, vp, vp, ci, C.c_longlong] + [C.c_double] * 5 + [ci]
+    L.iodine_ari_table.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     L.iodine_set_option.argtypes = [vp, C.c_char_p, C.c_double]
     L.iodine_profile_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), ci]
     L.iodine_debug_copy.argtypes = [vp, vp, C.c_char_p, ci, vp, C.c_size_t, C.POINTER(C.c_size_t)]

@@ -114,3 +114,7 @@ hipError_t launch_conv3x3_wgrad_f16x3(hipStream_t st, const float* a, const floa
 hipError_t launch_conv3x3_tile_f16x3_v3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                         const float* bias, const float* aux, float* out, int N, int S, int cin, int cout,
                                         int epi);
+hipError_t launch_adam_multi(hipStream_t st, const long long* ptrs, const long long* offs, int n_tensors, long long total,
+                             double lr, double beta1, double beta2, double eps, double wd, int step);
+hipError_t launch_ari_table(hipStream_t st, const float* mask, const unsigned char* gt, int B, int K, int G, int P,
+                            int* table);

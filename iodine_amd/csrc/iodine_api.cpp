@@ -864,6 +864,28 @@ int iodine_profile_read(iodine_handle* h, const char* category, double* total_ms
     return IODINE_OK;
 }
 
+int iodine_adam_step(void* stream, const long long* ptrs_dev, const long long* offsets_dev, int n_tensors, long long total,
+                     double lr, double beta1, double beta2, double eps, double weight_decay, int step)
+{
+    if (!ptrs_dev || !offsets_dev || n_tensors < 1 || total < 1 || step < 1) { g_create_error = "iodine_adam_step: bad argument"; return IODINE_ERR_INVALID; }
+    const hipError_t e = launch_adam_multi((hipStream_t)stream, ptrs_dev, offsets_dev, n_tensors, total, lr, beta1, beta2, eps,
+                                           weight_decay, step);
+    if (e != hipSuccess) { g_create_error = std::string("iodine_adam_step: ") + hipGetErrorString(e); return IODINE_ERR_HIP; }
+    return IODINE_OK;
+}
+
+int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, int batch, int slots, int n_gt, int pixels,
+                     int* table)
+{
+    if (!mask || !gt || !table || batch < 1 || slots < 1 || n_gt < 1 || pixels < 1 || (size_t)n_gt * slots > 8192) {
+        g_create_error = "iodine_ari_table: bad argument";
+        return IODINE_ERR_INVALID;
+    }
+    const hipError_t e = launch_ari_table((hipStream_t)stream, mask, gt, batch, slots, n_gt, pixels, table);
+    if (e != hipSuccess) { g_create_error = std::string("iodine_ari_table: ") + hipGetErrorString(e); return IODINE_ERR_HIP; }
+    return IODINE_OK;
+}
+
 void iodine_linspace_host(int n, float* out)
 {
     // ATen's CPU linspace for float: step = (end - start) / (n - 1); first half counts up from start,

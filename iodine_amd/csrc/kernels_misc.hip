@@ -479,3 +479,90 @@ hipError_t launch_pack_dec_out(hipStream_t st, const float* w, float* wk, int C)
     hipLaunchKernelGGL(pack_dec_out_kernel, dim3((9 * C * 4 + 255) / 256), dim3(256), 0, st, w, wk, C);
     return hipGetLastError();
 }
+
+// -----------------------------------------------------------------------------------------------
+// the optimizer step adjacent to the training step (lib/solver/build.py:5-16 builds
+// torch.optim.Adam over every parameter; lib/engine/train.py:65 calls .step()).  One launch over all tensors:
+// ptrs[4*t + {0,1,2,3}] = {param, grad, exp_avg, exp_avg_sq} of tensor t, offs[t] = first flat element of tensor t.
+// Arithmetic follows torch.optim.Adam (amsgrad=False, maximize=False): weight decay added to the gradient,
+// bias corrections 1 - beta^step, denom = sqrt(v) / sqrt(bc2) + eps, p -= (lr / bc1) * m / denom.
+// -----------------------------------------------------------------------------------------------
+__global__ void adam_multi_kernel(const long long* __restrict__ ptrs, const long long* __restrict__ offs, int n_tensors,
+                                  long long total, float step_size, float beta1, float beta2, float omb1, float omb2,
+                                  float eps, float wd, float bc2_sqrt)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_tensors - 1;                       // last tensor whose offset <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (offs[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const long long j = i - offs[lo];
+        float* p = reinterpret_cast<float*>(ptrs[4 * lo + 0]);
+        const float* g = reinterpret_cast<const float*>(ptrs[4 * lo + 1]);
+        float* m = reinterpret_cast<float*>(ptrs[4 * lo + 2]);
+        float* v = reinterpret_cast<float*>(ptrs[4 * lo + 3]);
+        float grad = g[j];
+        const float pv = p[j];
+        if (wd != 0.f) grad = fmaf(wd, pv, grad);
+        const float mn = fmaf(omb1, grad, beta1 * m[j]);          // exp_avg.lerp_(grad, 1 - beta1)
+        const float vn = fmaf(omb2 * grad, grad, beta2 * v[j]);   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        m[j] = mn; v[j] = vn;
+        const float denom = sqrtf(vn) / bc2_sqrt + eps;
+        p[j] = pv - step_size * (mn / denom);
+    }
+}
+
+hipError_t launch_adam_multi(hipStream_t st, const long long* ptrs, const long long* offs, int n_tensors, long long total,
+                             double lr, double beta1, double beta2, double eps, double wd, int step)
+{
+    // scalar prefactors in double on the host, like the Python floats torch.optim.Adam derives them from
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2_sqrt = sqrt(1.0 - pow(beta2, (double)step));
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, st, ptrs, offs, n_tensors, total, (float)(lr / bc1),
+                       (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd,
+                       (float)bc2_sqrt);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------
+// ARI evaluation epilogue of reconstruct (lib/eval/ari_eval.py:25-39, lib/utils/ari.py:36-52):
+// argmax over the K slot masks per pixel, then the contingency table  table[b][i][k] = #pixels with gt_i set and
+// argmax == k  (integer arithmetic, int32 atomics on an LDS copy of the table, one flush per block).
+//   mask (B, K, 1, P) fp32 as returned by reconstruct; gt (B, G, P) uint8 0/1 (padded with empty masks to G rows).
+// -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void ari_table_kernel(const float* __restrict__ mask, const unsigned char* __restrict__ gt, int K, int G, int P,
+                      int* __restrict__ table)
+{
+    extern __shared__ int s_tab[];                            // G*K
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < G * K; i += 256) s_tab[i] = 0;
+    __syncthreads();
+    const float* mb = mask + (size_t)b * K * P;
+    const unsigned char* gb = gt + (size_t)b * G * P;
+    for (int p = blockIdx.x * 256 + tid; p < P; p += gridDim.x * 256) {
+        int best = 0;
+        float bv = mb[p];
+        for (int k = 1; k < K; ++k) {                         // torch.argmax: first maximal index
+            const float v = mb[(size_t)k * P + p];
+            if (v > bv) { bv = v; best = k; }
+        }
+        for (int i = 0; i < G; ++i)
+            if (gb[(size_t)i * P + p]) atomicAdd(&s_tab[i * K + best], 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < G * K; i += 256)
+        if (s_tab[i]) atomicAdd(&table[(size_t)b * G * K + i], s_tab[i]);
+}
+
+hipError_t launch_ari_table(hipStream_t st, const float* mask, const unsigned char* gt, int B, int K, int G, int P,
+                            int* table)
+{
+    hipError_t e = hipMemsetAsync(table, 0, sizeof(int) * (size_t)B * G * K, st);
+    if (e != hipSuccess) return e;
+    const int bx = std::min((P + 255) / 256, 16);
+    hipLaunchKernelGGL(ari_table_kernel, dim3(bx, B), dim3(256), (size_t)G * K * sizeof(int), st, mask, gt, K, G, P, table);
+    return hipGetLastError();
+}

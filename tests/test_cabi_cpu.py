@@ -80,3 +80,19 @@ def test_synth_is_deterministic_and_shard_invariant():
     assert np.array_equal(a[2:], b)
     imgs, masks = synth.make_images(2, 32, seed=0, kind='blobs')
     assert imgs.min() >= 0 and imgs.max() <= 1 and len(masks) == 2 and masks[0].shape[1:] == (32, 32)
+
+
+def test_reference_checkpoint_loads_on_cpu_side(tmp_path):
+    """A file written the way lib/utils/checkpoint.py:36-54 writes it (DataParallel 'module.' prefix) loads into the
+    module's parameter table; no GPU involved (load_state_dict only)."""
+    from util import golden_setup, hip_arch, load_golden
+    from iodine_amd import IODINE, checkpoint
+    g = load_golden('tiny')
+    arch, params, _, _, _ = golden_setup(g)
+    path = str(tmp_path / 'ref.pth')
+    torch.save({'model': {'module.' + k: v for k, v in params.items()}, 'optimizer': None, 'epoch': 3}, path)
+    m = IODINE(hip_arch(arch))
+    extra = checkpoint.load_checkpoint(path, m)
+    assert extra == {'epoch': 3}
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, params[k]), k
