@@ -49,6 +49,8 @@ def parse():
     ap.add_argument('--iters', type=int, default=None)
     ap.add_argument('--conv-precision', type=int, choices=[0, 1], default=1,
                     help='decoder 3x3 convs: 1 = fp32 operands split into fp16 hi+lo, 3 f16 MFMAs (default); 0 = exact fp32 MFMA')
+    ap.add_argument('--no-adam', action='store_true', help='time forward + backward only (default: + fused Adam step, '
+                    'like the reference batch_time, lib/engine/train.py:58-67)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=None)
     return ap.parse_args()
@@ -116,11 +118,16 @@ def main():
         def step():
             return model.reconstruct(x, eps)
     else:
+        from iodine_amd.optim import make_optimizer
+        opt = None if args.no_adam else make_optimizer(model, base_lr=3e-4, weight_decay=0.0)   # configs/clevr6_prop.yaml:19-20
+
         def step():
             model.zero_grad(set_to_none=True)
             loss = model(x, eps)
             loss.backward()
             parallel.allreduce_gradients(model.parameters(), world)       # one RCCL all-reduce of the flat grads
+            if opt is not None:
+                opt.step()
             return loss
 
     def barrier():
@@ -207,7 +214,7 @@ def main():
                dtype=('f32 (3xf16-split MFMA convs, f32 accumulate)' if args.conv_precision == 1 else 'f32'), data='synthetic',
                config=dict(workload=f'{"CLEVR6 128x128" if args.config == "clevr6" else "multi-dSprites 64x64"}, '
                                     f'K={K}, T={T}, batch {B}/GPU, {args.mode} step '
-                                    f'({"reconstruct: T iterations + final decode" if args.mode == "infer" else "forward + backward, no optimizer"})',
+                                    f'({"reconstruct: T iterations + final decode" if args.mode == "infer" else ("forward + backward" + ("" if args.no_adam else " + fused Adam step"))})',
                            step=args.mode, global_batch=B * world, slots=K, iters=T, img_size=S,
                            parallelism=f'dp{world} (images sharded over ranks; '
                                        f'{"one RCCL all-reduce of the flat gradient buffer per step" if args.mode == "train" else "no data-path collective"})'),

@@ -118,3 +118,6 @@ hipError_t launch_adam_multi(hipStream_t st, const long long* ptrs, const long l
                              double lr, double beta1, double beta2, double eps, double wd, int step);
 hipError_t launch_ari_table(hipStream_t st, const float* mask, const unsigned char* gt, int B, int K, int G, int P,
                             int* table);
+hipError_t launch_pack_dec_out_gemm(hipStream_t st, const float* w, int C, float* meta, void* dst);
+hipError_t launch_dec_out_gemm_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
+                                     const float* bias, float* out, int N, int S, int C);

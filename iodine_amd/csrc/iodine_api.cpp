@@ -330,8 +330,8 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N)
                                                              b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
     }
     if (h->precision == 1)
-        PROF(h, st, "dec_out", conv_f16x3(h, st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b, nullptr,
-                                          b.dec_out, N, h->S, h->Cd, 32, EPI_OUT4));
+        PROF(h, st, "dec_out", launch_dec_out_gemm_f16x3(st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b,
+                                                         b.dec_out, N, h->S, h->Cd));
     else
         PROF(h, st, "dec_out", launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, b.dec_out, N, h->S, h->Cd));
     return IODINE_OK;
@@ -501,7 +501,7 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     ALLOC(h->dec_out_w, (size_t)9 * Cd * 4);
     ALLOC(h->dec_out_b, (size_t)4);
     ALLOC(h->dec_out_wb, conv_wpk_elems(4, Cd) * 4);
-    ALLOC(h->dec_out_w16, (size_t)(Cd / 16) * 9 * 2 * 2 * 32 * 4);
+    ALLOC(h->dec_out_w16, (size_t)(Cd / 16) * 2 * 2 * 64 * 4);            // GEMM-form pack: [chunk][hi/lo][kh][64][8 fp16]
     ALLOC(h->dec_out_meta, (size_t)4);
     h->ref_w.assign(h->Dr, nullptr); h->ref_b.assign(h->Dr, nullptr);
     for (int l = 0; l < h->Dr; ++l) {
@@ -572,7 +572,7 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     HIPCHK(h, launch_pack_dec_out(st, P("decoder.conv.weight"), h->dec_out_w, Cd));
     HIPCHK(h, hipMemcpyAsync(h->dec_out_b, P("decoder.conv.bias"), sizeof(float) * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(h, launch_pack_conv_weights(st, P("decoder.conv.weight"), 4, Cd, 4, Cd, 1, h->dec_out_wb));
-    HIPCHK(h, launch_pack_conv_weights_f16(st, P("decoder.conv.weight"), 4, Cd, Cd, 32, 0, h->dec_out_meta, h->dec_out_w16));
+    HIPCHK(h, launch_pack_dec_out_gemm(st, P("decoder.conv.weight"), Cd, h->dec_out_meta, h->dec_out_w16));
     // refinement conv stack
     for (int l = 0; l < h->Dr; ++l) {
         const float* w = P("refine.mlc.layers." + std::to_string(l) + ".weight");
