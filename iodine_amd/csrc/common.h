@@ -61,7 +61,10 @@ hipError_t launch_dec_l0_prepare(hipStream_t st, const float* w, const float* bi
 hipError_t launch_dec_v(hipStream_t st, const float* pm, const float* plv, const float* eps, const float* z_in,
                         const float* wcls, float* z_out, float* V, int N, int L, int C);
 hipError_t launch_dec_l0(hipStream_t st, const float* V, const float* cmap, float* out, int N, int S, int C);
-hipError_t launch_l0_reduce(hipStream_t st, const float* dpre, float* rows, float* Rc, int N, int S, int C);
+// slot groups of the fused layer-0 reduction (each at most 32 slots); Dpart holds l0_dgroups(N) * P * C floats
+inline int l0_dgroups(int N) { const int g = (N + 31) / 32; return g < 8 ? 8 : g; }
+hipError_t launch_l0_reduce(hipStream_t st, const float* dpre, float* rows, float* Rc, int N, int S, int C, float* Dpart,
+                            float* Dacc, float alpha, int first);
 hipError_t launch_dz_latent(hipStream_t st, const float* Rc, const float* wclsT, const float* pm, const float* plv,
                             const float* eps, int N, int L, int C, int use_ln, float* g_pm, float* g_plv, float* latent);
 hipError_t launch_elbo(hipStream_t st, const float* pm, const float* plv, const float* ll_img, int B, int K, int L,
@@ -83,14 +86,14 @@ hipError_t launch_conv3x3_wgrad_tile(hipStream_t st, const float* a, const float
                                      int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts);
 hipError_t launch_conv3x3_wgrad_gather(hipStream_t st, const float* in, const float* d, float* part, int N, int IH,
                                        int IW, int cip, int co, int stride, int* nparts, int* cipad);
+constexpr int WGRAD_FOLD = 32;    // tiles left after the first reduction stage; `fold` holds WGRAD_FOLD * 9 * ci_pad * co_pad floats
 hipError_t launch_wgrad_reduce(hipStream_t st, const float* part, int nparts, int ci_pad, int co_pad, int O_real,
-                               int I_real, int I_dst, float alpha, float* dst);
+                               int I_real, int I_dst, float alpha, float* dst, float* fold);
 hipError_t launch_colsum(hipStream_t st, const float* src, int rows, int cols, int ld, float alpha, float* dst);
 hipError_t launch_colsum_tall(hipStream_t st, const float* src, int rows, int cols, float alpha, float* dst, float* tmp,
                               size_t tmp_elems);
 hipError_t launch_sgemm(hipStream_t st, int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
                         const float* B, int ldb, float beta, float* C, int ldc);
-hipError_t launch_sum_over_slots(hipStream_t st, const float* dpre, float* D, int N, int P, int C);
 hipError_t launch_l0_tap_sums(hipStream_t st, const float* Rc, float* RT, int N, int C);
 hipError_t launch_l0_scatter_z(hipStream_t st, const float* tmp, int L, int C, float alpha, float* gw);
 hipError_t launch_l0_coord_grads(hipStream_t st, const float* D, const float* lin, int S, int C, int L, float alpha,
@@ -121,3 +124,9 @@ hipError_t launch_ari_table(hipStream_t st, const float* mask, const unsigned ch
 hipError_t launch_pack_dec_out_gemm(hipStream_t st, const float* w, int C, float* meta, void* dst);
 hipError_t launch_dec_out_gemm_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                      const float* bias, float* out, int N, int S, int C);
+
+// kernels_refine.hip: split-fp16 stride-2 convs of the refinement network
+hipError_t launch_conv3x3_s2_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
+                                   float* out, int N, int S, int cin_real, int cout);
+hipError_t launch_conv3x3_s2_dgrad_f16x3(hipStream_t st, const float* d, const void* wpk, const float* wmeta, const float* aux,
+                                         float* out, int N, int S, int c);

@@ -45,7 +45,7 @@ struct Buffers {               // workspace carve-up for one batch size / mode
     std::vector<float*> z, g_pm, g_plv, latent, enc, pooled, u, gates, xin, h, c;
     std::vector<std::vector<float*>> ract;     // [iter][layer] refinement activations
     // training only
-    float *wg_part = nullptr, *wg_part_b = nullptr, *Dsum = nullptr, *RT = nullptr, *tmp_lz = nullptr;
+    float *wg_part = nullptr, *wg_part_b = nullptr, *wg_fold = nullptr, *Dsum = nullptr, *Dpart = nullptr, *RT = nullptr, *tmp_lz = nullptr;
     float *ddm = nullptr, *ddv = nullptr, *dc1 = nullptr, *dgates = nullptr, *dxin = nullptr, *ds = nullptr,
           *dpooled = nullptr;
     float* carry_h[2] = {nullptr, nullptr};
@@ -87,6 +87,7 @@ struct iodine_handle {
     // training: raw copies used by the head backward GEMMs, strided-dgrad packs, gradient accumulators
     float *raw_mlp_w = nullptr, *raw_wih = nullptr, *raw_whh = nullptr, *raw_wm = nullptr, *raw_wv = nullptr;
     std::vector<float*> ref_wb;
+    std::vector<float*> ref_wf16, ref_wb16, ref_wmeta;     // split-fp16 packs of the stride-2 convs (+ {scale, 1/scale} x {fwd, dgrad})
     std::vector<float*> gacc;                   // one per parameter, reference shapes
     bool fwd_done = false;
     int fwd_batch = 0;
@@ -216,6 +217,8 @@ std::string validate(const iodine_config& c)
 
 // spatial size of refinement layer l's OUTPUT (3x3, pad 1, stride 2): floor((s + 2 - 3)/2) + 1
 int ref_out_size(int s) { return (s - 1) / 2 + 1; }
+// the split-fp16 stride-2 kernels cover the shipped refinement stacks: 32 or 64 channels, even sizes at every layer
+bool refine_f16_ok(const iodine_handle* h);
 
 void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
 {
@@ -275,7 +278,9 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
                                       ? (size_t)512 * 4 * 9 * 32 * 32 : (size_t)512 * 9 * Cmax * Cmax;
         b.wg_part = a.take<float>(part_elems);
         b.wg_part_b = a.take<float>((size_t)512 * 64);
+        b.wg_fold = a.take<float>((size_t)WGRAD_FOLD * 9 * Cmax * Cmax);
         b.Dsum = a.take<float>((size_t)P * Cd);
+        b.Dpart = a.take<float>((size_t)l0_dgroups(N) * P * Cd);
         b.RT = a.take<float>((size_t)N * 9 * Cd);
         b.tmp_lz = a.take<float>((size_t)L * 9 * Cd);
         b.ddm = a.take<float>((size_t)N * L); b.ddv = a.take<float>((size_t)N * L);
@@ -342,7 +347,7 @@ int reduce_wgrad(iodine_handle* h, hipStream_t st, int nparts, int ci_pad, int c
                  int I_dst, float alpha, int wparam, int bparam, int nbias_parts)
 {
     Buffers& b = h->buf;
-    HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, ci_pad, co_pad, O_real, I_real, I_dst, alpha, h->gacc[wparam]));
+    HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, ci_pad, co_pad, O_real, I_real, I_dst, alpha, h->gacc[wparam], b.wg_fold));
     if (nbias_parts > 0) HIPCHK(h, launch_colsum(st, b.wg_part_b, nbias_parts, O_real, O_real, alpha, h->gacc[bparam]));
     return IODINE_OK;
 }
@@ -391,7 +396,10 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         cur ^= 1;
     }
     *dpre0 = b.dpre[cur];
-    PROF(h, st, "l0_reduce", launch_l0_reduce(st, *dpre0, b.rows, b.Rc, N, h->S, Cd));
+    // row / class sums of dpre0 for dz; in training the same read also feeds the slot-summed gradient map, which is
+    // accumulated (with this pass's factor) over the T+1 passes and consumed once after the last one
+    PROF(h, st, "l0_reduce", launch_l0_reduce(st, *dpre0, b.rows, b.Rc, N, h->S, Cd, train_alpha != 0.f ? b.Dpart : nullptr,
+                                              b.Dsum, train_alpha, it == 0));
     if (train_alpha != 0.f) {
         // layer 0 (spatial broadcast): latent-channel weights from z and the per-tap sums, coordinate channels
         // and bias from the slot-summed gradient map
@@ -399,8 +407,8 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         HIPCHK(h, launch_l0_tap_sums(st, b.Rc, b.RT, N, Cd));
         HIPCHK(h, launch_sgemm(st, 1, 0, h->L, 9 * Cd, N, 1.f, b.z[it], h->L, b.RT, 9 * Cd, 0.f, b.tmp_lz, 9 * Cd));
         HIPCHK(h, launch_l0_scatter_z(st, b.tmp_lz, h->L, Cd, train_alpha, h->gacc[wi]));
-        PROF(h, st, "l0_slot_sum", launch_sum_over_slots(st, *dpre0, b.Dsum, N, h->P, Cd));
-        HIPCHK(h, launch_l0_coord_grads(st, b.Dsum, h->lin, h->S, Cd, h->L, train_alpha, h->gacc[wi], h->gacc[bi]));
+        if (it == h->T)
+            HIPCHK(h, launch_l0_coord_grads(st, b.Dsum, h->lin, h->S, Cd, h->L, 1.f, h->gacc[wi], h->gacc[bi]));
     }
     return IODINE_OK;
 }
@@ -426,6 +434,14 @@ int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps
     return IODINE_OK;
 }
 
+bool refine_f16_ok(const iodine_handle* h)
+{
+    if (h->Cr != 64 && h->Cr != 32) return false;
+    int s = h->S;
+    for (int l = 0; l < h->Dr; ++l) { if (s % 2 != 0) return false; s /= 2; }
+    return true;
+}
+
 // refine() + posterior.update() for iteration i (iodine.py:95-100 / 144-145)
 int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
 {
@@ -436,8 +452,12 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
     int s = h->S;
     const float* in = b.enc[i];
     for (int l = 0; l < h->Dr; ++l) {
-        PROF(h, st, "refine_conv", launch_conv3x3_gather(st, in, h->ref_w[l], h->ref_b[l], b.ract[i][l], N, s, s,
-                                                         l == 0 ? 20 : h->Cr, h->Cr, 2));
+        if (h->precision == 1 && refine_f16_ok(h))
+            PROF(h, st, "refine_conv", launch_conv3x3_s2_f16x3(st, in, h->ref_wf16[l], h->ref_wmeta[l], h->ref_b[l],
+                                                               b.ract[i][l], N, s, l == 0 ? 20 : h->Cr, h->Cr));
+        else
+            PROF(h, st, "refine_conv", launch_conv3x3_gather(st, in, h->ref_w[l], h->ref_b[l], b.ract[i][l], N, s, s,
+                                                             l == 0 ? 20 : h->Cr, h->Cr, 2));
         in = b.ract[i][l];
         s = ref_out_size(s);
     }
@@ -516,6 +536,12 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     ALLOC(h->raw_wm, (size_t)L * H); ALLOC(h->raw_wv, (size_t)L * H);
     h->ref_wb.assign(h->Dr, nullptr);
     for (int l = 1; l < h->Dr; ++l) ALLOC(h->ref_wb[l], conv_wpk_elems(Cr, Cr) * 4);
+    h->ref_wf16.assign(h->Dr, nullptr); h->ref_wb16.assign(h->Dr, nullptr); h->ref_wmeta.assign(h->Dr, nullptr);
+    for (int l = 0; l < h->Dr; ++l) {
+        ALLOC(h->ref_wf16[l], (size_t)((l == 0 ? 32 : Cr) / 16) * 9 * 2 * 2 * Cr * 4);
+        ALLOC(h->ref_wmeta[l], (size_t)4);
+        if (l > 0) ALLOC(h->ref_wb16[l], (size_t)(Cr / 16) * 9 * 2 * 2 * Cr * 4);
+    }
     h->gacc.assign(h->params.size(), nullptr);
     for (size_t i = 0; i < h->params.size(); ++i) ALLOC(h->gacc[i], h->params[i].numel());
 #undef ALLOC
@@ -583,6 +609,15 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     for (int l = 1; l < h->Dr; ++l)
         HIPCHK(h, launch_pack_conv_weights(st, P("refine.mlc.layers." + std::to_string(l) + ".weight"), Cr, Cr, Cr, Cr, 2,
                                            h->ref_wb[l]));
+    if (refine_f16_ok(h)) {
+        for (int l = 0; l < h->Dr; ++l) {
+            const float* w = P("refine.mlc.layers." + std::to_string(l) + ".weight");
+            HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cr, l == 0 ? 17 : Cr, l == 0 ? 32 : Cr, Cr, 0, h->ref_wmeta[l],
+                                                   h->ref_wf16[l]));
+            if (l > 0)
+                HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cr, Cr, Cr, Cr, 2, h->ref_wmeta[l] + 2, h->ref_wb16[l]));
+        }
+    }
     auto copy_raw = [&](float* dst, const std::string& name) {
         return hipMemcpyAsync(dst, P(name), sizeof(float) * h->params[param_index(h, name)].numel(),
                               hipMemcpyDeviceToDevice, st);
@@ -786,12 +821,17 @@ int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, floa
             PROF(h, st, "refine_wgrad", launch_conv3x3_wgrad_gather(st, in, b.rdpre[l], b.wg_part, N, sz[l], sz[l], cip, Cr, 2,
                                                                     &nparts, &cipad));
             const std::string base = "refine.mlc.layers." + std::to_string(l);
-            HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, G(base + ".weight")));
+            HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, G(base + ".weight"), b.wg_fold));
             PROF(h, st, "refine_bias_grad", launch_colsum_tall(st, b.rdpre[l], N * sz[l + 1] * sz[l + 1], Cr, 1.f,
                                                                G(base + ".bias"), b.wg_part_b, (size_t)512 * 64));
-            if (l > 0)
-                PROF(h, st, "refine_dgrad", launch_conv3x3_gather_dgrad(st, b.rdpre[l], h->ref_wb[l], b.ract[i][l - 1],
-                                                                        b.rdpre[l - 1], N, sz[l], sz[l], Cr, 2));
+            if (l > 0) {
+                if (h->precision == 1 && refine_f16_ok(h))
+                    PROF(h, st, "refine_dgrad", launch_conv3x3_s2_dgrad_f16x3(st, b.rdpre[l], h->ref_wb16[l], h->ref_wmeta[l] + 2,
+                                                                              b.ract[i][l - 1], b.rdpre[l - 1], N, sz[l], Cr));
+                else
+                    PROF(h, st, "refine_dgrad", launch_conv3x3_gather_dgrad(st, b.rdpre[l], h->ref_wb[l], b.ract[i][l - 1],
+                                                                            b.rdpre[l - 1], N, sz[l], sz[l], Cr, 2));
+            }
         }
     }
     for (size_t p = 0; p < h->params.size(); ++p) {
@@ -907,6 +947,21 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, c
 {
     hipStream_t st = (hipStream_t)stream;
     float* wpk = nullptr;
+    if (mode == 5 || mode == 6) {          // split-fp16 stride-2 forward (5) / data gradient (6); ih = fine size
+        float* meta = nullptr;
+        const int cp = mode == 5 ? (cin_pad == 20 ? 32 : cin_pad) : cin_pad;
+        const size_t bytes = (size_t)(cp / 16) * 9 * 2 * 2 * cout * 16;
+        if (hipMalloc((void**)&wpk, bytes + 64) != hipSuccess) return IODINE_ERR_HIP;
+        meta = (float*)((char*)wpk + bytes);
+        hipError_t e2 = launch_pack_conv_weights_f16(st, w, w_o, w_i, cp, cout, mode == 5 ? 0 : 2, meta, wpk);
+        if (e2 == hipSuccess)
+            e2 = mode == 5 ? launch_conv3x3_s2_f16x3(st, in, wpk, meta, bias, out, n, ih, cin_pad, cout)
+                           : launch_conv3x3_s2_dgrad_f16x3(st, in, wpk, meta, aux, out, n, ih, cout);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+        (void)hipFree(wpk);
+        if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(s2 f16x3): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
+        return IODINE_OK;
+    }
     if (mode == 2 || mode == 4) {          // split-fp16 tile kernels (4 = warp-specialised persistent variant)
         float* meta = nullptr;
         const size_t bytes = (size_t)(cin_pad / 16) * 9 * 2 * 2 * cout * 16;

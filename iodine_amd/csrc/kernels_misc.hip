@@ -128,30 +128,35 @@ hipError_t launch_dec_v(hipStream_t st, const float* pm, const float* plv, const
     return hipGetLastError();
 }
 
+// act0[n][p][:] = ELU(V[n][class(p)][:] + cmap[p][:]).  Pure streaming write (N*P*C floats): grid.y = slot, 32-bit index
+// arithmetic only, four float4 stores in flight per thread.
 __global__ __launch_bounds__(256)
 void dec_l0_kernel(const float4* __restrict__ V, const float4* __restrict__ cmap, float4* __restrict__ out,
-                   int S, int C4, size_t total)
+                   int S, int C4, int pc4)
 {
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = idx % C4;
-        const size_t r = idx / C4;
-        const int p = r % ((size_t)S * S);
-        const size_t n = r / ((size_t)S * S);
-        const int y = p / S, x = p % S;
-        const int cls = (y == 0 ? 0 : (y == S - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x == S - 1 ? 2 : 1));
-        const float4 v = V[(n * 9 + cls) * C4 + c4];
-        const float4 m = cmap[(size_t)p * C4 + c4];
-        out[idx] = make_float4(elu1(v.x + m.x), elu1(v.y + m.y), elu1(v.z + m.z), elu1(v.w + m.w));
+    const int n = blockIdx.y;
+    const float4* Vn = V + (size_t)n * 9 * C4;
+    float4* on = out + (size_t)n * pc4;
+    const int base = blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = base + k * 256;
+        if (i < pc4) {
+            const int p = i / C4, c4 = i - p * C4;
+            const int y = p / S, x = p - y * S;
+            const int cls = (y == 0 ? 0 : (y == S - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x == S - 1 ? 2 : 1));
+            const float4 v = Vn[cls * C4 + c4];
+            const float4 m = cmap[i];
+            on[i] = make_float4(elu1(v.x + m.x), elu1(v.y + m.y), elu1(v.z + m.z), elu1(v.w + m.w));
+        }
     }
 }
 
 hipError_t launch_dec_l0(hipStream_t st, const float* V, const float* cmap, float* out, int N, int S, int C)
 {
-    const size_t total = (size_t)N * S * S * (C / 4);
-    const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
-    hipLaunchKernelGGL(dec_l0_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)V, (const float4*)cmap,
-                       (float4*)out, S, C / 4, total);
+    const int pc4 = S * S * (C / 4);
+    hipLaunchKernelGGL(dec_l0_kernel, dim3((pc4 + 1023) / 1024, N), dim3(256), 0, st, (const float4*)V,
+                       (const float4*)cmap, (float4*)out, S, C / 4, pc4);
     return hipGetLastError();
 }
 
@@ -206,15 +211,133 @@ __global__ void l0_reduce_cls_kernel(const float* __restrict__ rows, float* __re
     }
 }
 
-hipError_t launch_l0_reduce(hipStream_t st, const float* dpre, float* rows, float* Rc, int N, int S, int C)
+// Fused variant for rows of exactly NIT*256 float4: one block per (image row y, slot group g) walks the slots of its
+// group, reading dpre0 ONCE for both consumers:
+//   rows[n][y][3][C]   left / interior / right sums of this row (as above)
+//   Dpart[g][p][C]     sum over the group's slots (training only: layer-0 coordinate/bias gradients need sum_n dpre0)
+// All NIT loads of a slot are issued before they are consumed; the cross-pixel-lane reduction is shuffles inside a
+// wave plus one LDS pass per block (not per slot).
+template <int C, int NIT, bool WITH_D>
+__global__ __launch_bounds__(256)
+void l0_reduce_fused_kernel(const float4* __restrict__ dpre, float4* __restrict__ rows, float4* __restrict__ Dpart,
+                            int S, int N, int per_group)
 {
-    if (C == 64)
-        hipLaunchKernelGGL((l0_reduce_rows_kernel<64>), dim3(S, N), dim3(256), 0, st, (const float4*)dpre, (float4*)rows, S);
-    else if (C == 32)
-        hipLaunchKernelGGL((l0_reduce_rows_kernel<32>), dim3(S, N), dim3(256), 0, st, (const float4*)dpre, (float4*)rows, S);
-    else
-        return hipErrorInvalidValue;
+    constexpr int C4 = C / 4, PL = 256 / C4, WPL = 64 / C4;      // pixel lanes per block / per wave
+    constexpr int MAXG = 32;
+    __shared__ float4 s_part[MAXG][4][C4];
+    const int y = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int c4 = tid % C4, pl = tid / C4, wv = tid >> 6;
+    const int n0 = g * per_group, n1 = min(N, n0 + per_group);
+    float4 dacc[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) dacc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = n0; n < n1; ++n) {
+        const float4* src = dpre + ((size_t)n * S + y) * S * C4;
+        float4 v[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) v[k] = src[tid + k * 256];
+        float4 mid = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* o = rows + ((size_t)n * S + y) * 3 * C4;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            if (WITH_D) { dacc[k].x += v[k].x; dacc[k].y += v[k].y; dacc[k].z += v[k].z; dacc[k].w += v[k].w; }
+            const int x = pl + k * PL;
+            if (x == 0) o[c4] = v[k];
+            else if (x == S - 1) o[2 * C4 + c4] = v[k];
+            else { mid.x += v[k].x; mid.y += v[k].y; mid.z += v[k].z; mid.w += v[k].w; }
+        }
+#pragma unroll
+        for (int off = C4; off < 64; off <<= 1) {
+            mid.x += __shfl_xor(mid.x, off, 64); mid.y += __shfl_xor(mid.y, off, 64);
+            mid.z += __shfl_xor(mid.z, off, 64); mid.w += __shfl_xor(mid.w, off, 64);
+        }
+        if ((tid & 63) < C4) s_part[n - n0][wv][c4] = mid;
+    }
+    __syncthreads();
+    for (int j = tid; j < (n1 - n0) * C4; j += 256) {
+        const int nl = j / C4, cc = j % C4;
+        const float4 a = s_part[nl][0][cc], b2 = s_part[nl][1][cc], c2 = s_part[nl][2][cc], d2 = s_part[nl][3][cc];
+        rows[((size_t)(n0 + nl) * S + y) * 3 * C4 + C4 + cc] =
+            make_float4((a.x + b2.x) + (c2.x + d2.x), (a.y + b2.y) + (c2.y + d2.y), (a.z + b2.z) + (c2.z + d2.z),
+                        (a.w + b2.w) + (c2.w + d2.w));
+    }
+    if (WITH_D) {
+        float4* dst = Dpart + ((size_t)g * S + y) * S * C4;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) dst[tid + k * 256] = dacc[k];
+    }
+    (void)WPL;
+}
+
+// Dacc = (first ? 0 : Dacc) + alpha * sum_g Dpart[g]
+__global__ void d_accumulate_kernel(const float4* __restrict__ Dpart, int G, int pc4, float alpha, int first,
+                                    float4* __restrict__ Dacc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pc4) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < G; ++g) {
+        const float4 v = Dpart[(size_t)g * pc4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float4 o = first ? make_float4(0.f, 0.f, 0.f, 0.f) : Dacc[i];
+    o.x = fmaf(alpha, s.x, o.x); o.y = fmaf(alpha, s.y, o.y); o.z = fmaf(alpha, s.z, o.z); o.w = fmaf(alpha, s.w, o.w);
+    Dacc[i] = o;
+}
+
+// D[p][c] = sum_n dpre0[n][p][c]  (generic fallback of the fused kernel's Dpart)
+__global__ void sum_over_slots_kernel(const float4* __restrict__ dpre, float4* __restrict__ D, int N, size_t pc4)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pc4) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = 0; n < N; ++n) {
+        const float4 v = dpre[(size_t)n * pc4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    D[i] = s;
+}
+
+// Row / class sums of dpre0 (always) and, when Dpart != nullptr, Dacc (+)= alpha * sum_n dpre0 (training).
+// Dpart must hold L0_DGROUPS * P * C floats.
+hipError_t launch_l0_reduce(hipStream_t st, const float* dpre, float* rows, float* Rc, int N, int S, int C, float* Dpart,
+                            float* Dacc, float alpha, int first)
+{
+    const int pc4 = S * S * (C / 4);
+    const int per_group = (N + l0_dgroups(N) - 1) / l0_dgroups(N);   // <= 32
+    const int Gr = (N + per_group - 1) / per_group;              // groups actually launched
+    bool fused = false;
+#define L0F_CASE(CC, SS)                                                                                             \
+    if (C == CC && S == SS) {                                                                                       \
+        constexpr int NIT = SS * (CC / 4) / 256;                                                                     \
+        if (Dpart)                                                                                                   \
+            hipLaunchKernelGGL((l0_reduce_fused_kernel<CC, NIT, true>), dim3(S, Gr), dim3(256), 0, st,              \
+                               (const float4*)dpre, (float4*)rows, (float4*)Dpart, S, N, per_group);                \
+        else                                                                                                         \
+            hipLaunchKernelGGL((l0_reduce_fused_kernel<CC, NIT, false>), dim3(S, Gr), dim3(256), 0, st,             \
+                               (const float4*)dpre, (float4*)rows, (float4*)nullptr, S, N, per_group);              \
+        fused = true;                                                                                                \
+    }
+    L0F_CASE(64, 128) else L0F_CASE(32, 64) else L0F_CASE(64, 64) else L0F_CASE(32, 128)
+#undef L0F_CASE
+    int Gd = Gr;
+    if (!fused) {
+        if (C == 64)
+            hipLaunchKernelGGL((l0_reduce_rows_kernel<64>), dim3(S, N), dim3(256), 0, st, (const float4*)dpre, (float4*)rows, S);
+        else if (C == 32)
+            hipLaunchKernelGGL((l0_reduce_rows_kernel<32>), dim3(S, N), dim3(256), 0, st, (const float4*)dpre, (float4*)rows, S);
+        else
+            return hipErrorInvalidValue;
+        if (Dpart) {
+            hipLaunchKernelGGL(sum_over_slots_kernel, dim3((unsigned)((pc4 + 255) / 256)), dim3(256), 0, st,
+                               (const float4*)dpre, (float4*)Dpart, N, (size_t)pc4);
+            Gd = 1;
+        }
+    }
     hipLaunchKernelGGL(l0_reduce_cls_kernel, dim3(N), dim3(192), 0, st, rows, Rc, S, C);
+    if (Dpart)
+        hipLaunchKernelGGL(d_accumulate_kernel, dim3((pc4 + 255) / 256), dim3(256), 0, st, (const float4*)Dpart, Gd, pc4,
+                           alpha, first, (float4*)Dacc);
     return hipGetLastError();
 }
 

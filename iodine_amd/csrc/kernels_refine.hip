@@ -1,0 +1,317 @@
+// Split-fp16 (hi+lo, 3 MFMA, fp32 accumulate) kernels for the STRIDE-2 3x3 convs of the refinement network
+// (RefinementNetwork, lib/modeling/iodine.py:446-503: REF.CONV_LAYERS x [conv k3 s2 p1 + ELU]) and their data /
+// weight gradients.  gfx950 only.
+//
+// A stride-2 3x3 conv over a fine image (2Sc x 2Sc) is the sum of four stride-1 convs over the parity sub-images
+//     X_sb[Y][X] = x[2Y+py][2X+px],   sb = (py,px)
+// each with a SUBSET of the nine taps:  ky = 1 (dY = 0) for py = 0;  ky = 0 (dY = -1) or ky = 2 (dY = 0) for py = 1
+// (same along x), i.e. 1 + 2 + 2 + 4 = 9 tap products in total - no MFMA work on structural zeros.  The forward
+// kernel therefore reuses the stride-1 tile machinery of kernels_conv.hip (16x16 output tile, 4 waves x 64 px,
+// 16-channel chunks split into fp16 hi/lo while being staged into LDS, block-local power-of-two scaling) and walks
+// 4 * CIN/16 stages (sub-image, channel chunk) with 1, 2 or 4 taps each.  The data gradient is the mirror image:
+// the four parity classes of fine pixels are four stride-1 convs of the coarse gradient with the same tap subsets
+// (offsets 0/+1 instead of -1/0); one block computes one class of one 16x16 coarse tile.
+#include "common.h"
+#include <utility>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+IOD_DEVINL float elu1_fast_r(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
+
+template <class F, int... Is>
+IOD_DEVINL void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+IOD_DEVINL void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// tap slot j of parity class sb = py*2+px
+__host__ __device__ constexpr int s2_ntaps(int sb) { return (1 + (sb >> 1)) * (1 + (sb & 1)); }
+__host__ __device__ constexpr int s2_ky(int sb, int j) { return (sb >> 1) ? 2 * (j / (1 + (sb & 1))) : 1; }
+__host__ __device__ constexpr int s2_kx(int sb, int j) { return (sb & 1) ? 2 * (j % (1 + (sb & 1))) : 1; }
+// LDS tile offset (rows or columns) of a tap: forward tiles start at coarse -1 (k = 0 reads -1, else 0);
+// gradient tiles start at coarse 0 (k = 0 reads +1, else 0)
+__host__ __device__ constexpr int s2_off(int mode, int k) { return mode == 0 ? (k == 0 ? 0 : 1) : (k == 0 ? 1 : 0); }
+// forward stage order: the 4-tap class first (its weights are the largest staging burst)
+__host__ __device__ constexpr int s2_fwd_sb(int i) { return 3 - i; }
+
+template <int CIN_REAL, int CIN, int COUT, int MODE, int SBT>
+IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
+                             const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
+                             int Sc, int tiles, unsigned char* smem_b)
+{
+    constexpr int NC16 = CIN / 16;
+    constexpr int NSTAGE = MODE == 0 ? 4 * NC16 : NC16;
+    constexpr int NT = COUT / 32;
+    constexpr int HALO = 17, NPX = HALO * HALO;
+    constexpr int PXS = 80;                              // bytes per staged pixel: 32 hi + 32 lo + 16 pad
+    constexpr int IN_BYTES = (NPX + 1) * PXS;            // +1 pixel: dump slot for idle lanes
+    constexpr int TAP_U4 = 4 * COUT;                     // uint4 per tap: [term hi/lo][kh][co]
+    constexpr int NIN = (NPX * 4 + 255) / 256;           // 5 float4 per thread per stage
+    constexpr int NWT = (TAP_U4 + 255) / 256;
+    static_assert(TAP_U4 % 256 == 0 || TAP_U4 < 256, "weight staging assumes whole or partial single pass");
+
+    unsigned char* s_in = smem_b;
+    uint4* s_w = reinterpret_cast<uint4*>(smem_b + IN_BYTES);
+    float* s_max = reinterpret_cast<float*>(smem_b + IN_BYTES + 4 * TAP_U4 * 16);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, kh = lane >> 5, li = lane & 31;
+    const int prow = li >> 4, pcol = li & 15;
+    const int Sf = 2 * Sc;
+
+    int bid = blockIdx.x;
+    const int tx = bid % tiles; bid /= tiles;
+    const int ty = bid % tiles;
+    const int n = bid / tiles;
+
+    const int cq = tid & 3;
+    int goff[NIN];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        const int idx = tid + k * 256;
+        const int px = idx >> 2;
+        const int r = px / HALO, c = px % HALO;
+        if (MODE == 0) {
+            const int Y = ty * 16 - 1 + r, X = tx * 16 - 1 + c;
+            const bool ok = idx < NPX * 4 && Y >= 0 && Y < Sc && X >= 0 && X < Sc;
+            goff[k] = ok ? ((n * Sf + 2 * Y) * Sf + 2 * X) * CIN_REAL + cq * 4 : -1;
+        } else {
+            const int Y = ty * 16 + r, X = tx * 16 + c;
+            const bool ok = idx < NPX * 4 && Y < Sc && X < Sc;
+            goff[k] = ok ? ((n * Sc + Y) * Sc + X) * CIN_REAL + cq * 4 : -1;
+        }
+    }
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    float4 rin[2][NIN];
+    uint4 rw[4][NWT];
+
+    auto stage_sb = [](int I) constexpr { return MODE == 0 ? s2_fwd_sb(I / NC16) : SBT; };
+    auto stage_c16 = [](int I) constexpr { return MODE == 0 ? I % NC16 : I; };
+
+    auto prefetch_in = [&](auto Ic, float4 (&r)[NIN]) {
+        constexpr int I = decltype(Ic)::value;
+        constexpr int sb = stage_sb(I), c16 = stage_c16(I);
+        const int soff = MODE == 0 ? ((sb >> 1) * Sf + (sb & 1)) * CIN_REAL + c16 * 16 : c16 * 16;
+        const bool chv = c16 * 16 + cq * 4 < CIN_REAL;      // channels past CIN_REAL (17 -> 20 of a 32-wide pad) read as 0
+        const float* base = in + soff;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const bool ok = goff[k] >= 0 && chv;
+            const float4 v = *reinterpret_cast<const float4*>(base + (ok ? goff[k] : -soff));
+            r[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto prefetch_w = [&](auto Ic) {
+        constexpr int I = decltype(Ic)::value;
+        constexpr int sb = stage_sb(I), c16 = stage_c16(I);
+#pragma unroll
+        for (int j = 0; j < s2_ntaps(sb); ++j) {
+            const int tap = s2_ky(sb, j) * 3 + s2_kx(sb, j);
+            const uint4* wsrc = wpk + (size_t)(c16 * 9 + tap) * TAP_U4;
+#pragma unroll
+            for (int k = 0; k < NWT; ++k) {
+                const int idx = tid + k * 256;
+                rw[j][k] = idx < TAP_U4 ? wsrc[idx] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+    float cur_scale = 1.f;
+    auto commit = [&](auto Ic, const float4 (&r)[NIN]) -> float {
+        constexpr int I = decltype(Ic)::value;
+        constexpr int sb = stage_sb(I);
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const float4 v = r[k];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if (lane == 0) s_max[wv] = m;
+        __syncthreads();                                     // also: every wave is done reading the previous stage
+        const float mb = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        const int e = (int)((__float_as_uint(mb) >> 23) & 0xffu) - 127;
+        int se = 12 - e;
+        se = se > 100 ? 100 : (se < -100 ? -100 : se);
+        const float scale = (mb > 0.f && mb < 3.0e38f) ? __uint_as_float((unsigned)(127 + se) << 23) : 1.f;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const int idx = tid + k * 256;
+            const int px = idx < NPX * 4 ? idx >> 2 : NPX;
+            float4 v = r[k];
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            const float hx = __uint_as_float(__float_as_uint(v.x) & 0xffffe000u), hy = __uint_as_float(__float_as_uint(v.y) & 0xffffe000u);
+            const float hz = __uint_as_float(__float_as_uint(v.z) & 0xffffe000u), hw = __uint_as_float(__float_as_uint(v.w) & 0xffffe000u);
+            typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+            const h2 h01 = __builtin_amdgcn_cvt_pkrtz(hx, hy), h23 = __builtin_amdgcn_cvt_pkrtz(hz, hw);
+            const h2 l01 = __builtin_amdgcn_cvt_pkrtz(v.x - hx, v.y - hy), l23 = __builtin_amdgcn_cvt_pkrtz(v.z - hz, v.w - hw);
+            uint2 hi, lo;
+            __builtin_memcpy(&hi.x, &h01, 4); __builtin_memcpy(&hi.y, &h23, 4);
+            __builtin_memcpy(&lo.x, &l01, 4); __builtin_memcpy(&lo.y, &l23, 4);
+            *reinterpret_cast<uint2*>(s_in + px * PXS + cq * 8) = hi;
+            *reinterpret_cast<uint2*>(s_in + px * PXS + 32 + cq * 8) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < s2_ntaps(sb); ++j)
+#pragma unroll
+            for (int k = 0; k < NWT; ++k) {
+                const int idx = tid + k * 256;
+                if (idx < TAP_U4) s_w[j * TAP_U4 + idx] = rw[j][k];
+            }
+        __syncthreads();
+        return scale;
+    };
+    auto rescale = [&](float new_scale) {
+        if (new_scale != cur_scale) {                        // block-uniform; exact (powers of two)
+            const float r = new_scale / cur_scale;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[mt][nt][q] *= r;
+            cur_scale = new_scale;
+        }
+    };
+    const unsigned char* a_base = s_in + ((4 * wv + prow) * HALO + pcol) * PXS + kh * 16;
+    const uint4* b_base = s_w + kh * COUT + li;
+    auto compute = [&](auto Ic) {
+        constexpr int I = decltype(Ic)::value;
+        constexpr int sb = stage_sb(I);
+#pragma unroll
+        for (int j = 0; j < s2_ntaps(sb); ++j) {
+            const int aoff = (s2_off(MODE, s2_ky(sb, j)) * HALO + s2_off(MODE, s2_kx(sb, j))) * PXS;
+            f16x8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                ah[mt] = *reinterpret_cast<const f16x8*>(a_base + aoff + mt * 2 * HALO * PXS);
+                al[mt] = *reinterpret_cast<const f16x8*>(a_base + aoff + mt * 2 * HALO * PXS + 32);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const uint4 vh = b_base[j * TAP_U4 + nt * 32], vl = b_base[j * TAP_U4 + 2 * COUT + nt * 32];
+                __builtin_memcpy(&bh[nt], &vh, 16); __builtin_memcpy(&bl[nt], &vl, 16);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                }
+        }
+    };
+
+    // fully unrolled stage schedule (straight-line code keeps the vmcnt waits counted): inputs two stages ahead in
+    // two alternating register sets, weights one stage ahead
+    using std::integral_constant;
+    prefetch_in(integral_constant<int, 0>{}, rin[0]);
+    prefetch_w(integral_constant<int, 0>{});
+    if constexpr (NSTAGE > 1) prefetch_in(integral_constant<int, 1>{}, rin[1]);
+    static_for<NSTAGE>([&](auto Ic) {
+        constexpr int I = decltype(Ic)::value;
+        const float sc = commit(Ic, rin[I & 1]);
+        if (I == 0) cur_scale = sc; else rescale(sc);
+        if constexpr (I + 1 < NSTAGE) prefetch_w(integral_constant<int, (I + 1 < NSTAGE ? I + 1 : 0)>{});
+        if constexpr (I + 2 < NSTAGE) prefetch_in(integral_constant<int, (I + 2 < NSTAGE ? I + 2 : 0)>{}, rin[I & 1]);
+        compute(Ic);
+    });
+
+    const float inv_ws = wmeta[1] / cur_scale;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = nt * 32 + li;
+            const float bv = MODE == 0 ? bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int Y = ty * 16 + 4 * wv + 2 * mt + (m >> 4);
+                const int X = tx * 16 + (m & 15);
+                if (Y >= Sc || X >= Sc) continue;
+                float v = acc[mt][nt][r] * inv_ws;
+                if (MODE == 0) {
+                    out[(size_t)((n * Sc + Y) * Sc + X) * COUT + co] = elu1_fast_r(v + bv);
+                } else {
+                    const size_t o = (size_t)((n * Sf + 2 * Y + (SBT >> 1)) * Sf + 2 * X + (SBT & 1)) * COUT + co;
+                    out[o] = v * elu1_grad_from_out(aux[o]);
+                }
+            }
+        }
+}
+
+// MODE 0: in = fine [N][2Sc][2Sc][CIN_REAL] -> out = coarse [N][Sc][Sc][COUT], bias + ELU
+// MODE 1: in = coarse gradient [N][Sc][Sc][CIN] -> out = fine [N][2Sc][2Sc][COUT] times ELU'(aux); grid.y = parity class
+template <int CIN_REAL, int CIN, int COUT, int MODE>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_s2_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
+                             const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
+                             int Sc, int tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s2[];
+    if (MODE == 0) {
+        conv_s2_body<CIN_REAL, CIN, COUT, 0, 0>(in, wpk, wmeta, bias, aux, out, Sc, tiles, smem_s2);
+    } else {
+        switch (3 - (int)blockIdx.y) {                       // heaviest class (4 taps) is dispatched first
+        case 0: conv_s2_body<CIN_REAL, CIN, COUT, 1, 0>(in, wpk, wmeta, bias, aux, out, Sc, tiles, smem_s2); break;
+        case 1: conv_s2_body<CIN_REAL, CIN, COUT, 1, 1>(in, wpk, wmeta, bias, aux, out, Sc, tiles, smem_s2); break;
+        case 2: conv_s2_body<CIN_REAL, CIN, COUT, 1, 2>(in, wpk, wmeta, bias, aux, out, Sc, tiles, smem_s2); break;
+        default: conv_s2_body<CIN_REAL, CIN, COUT, 1, 3>(in, wpk, wmeta, bias, aux, out, Sc, tiles, smem_s2); break;
+        }
+    }
+}
+
+template <int CIN_REAL, int CIN, int COUT, int MODE>
+hipError_t launch_s2_inst(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
+                          const float* aux, float* out, int N, int Sc)
+{
+    constexpr size_t lds = (size_t)(17 * 17 + 1) * 80 + (size_t)4 * 4 * COUT * 16 + 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_s2_f16x3_kernel<CIN_REAL, CIN, COUT, MODE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles = (Sc + 15) / 16;
+    hipLaunchKernelGGL((conv3x3_s2_f16x3_kernel<CIN_REAL, CIN, COUT, MODE>), dim3(N * tiles * tiles, MODE == 0 ? 1 : 4),
+                       dim3(256), lds, st, in, reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, Sc, tiles);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// Forward stride-2 conv + bias + ELU.  S = fine (input) size, even; cin_real = floats per input pixel (20 for the
+// 17-channel encoding, packed with cin_pad = 32), wpk = launch_pack_conv_weights_f16(.., cin_pad, cout, tflip 0).
+hipError_t launch_conv3x3_s2_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
+                                   float* out, int N, int S, int cin_real, int cout)
+{
+    if (S % 2 != 0 || S < 2) return hipErrorInvalidValue;
+#define S2F_CASE(CR, CP, CO) \
+    if (cin_real == CR && cout == CO) return launch_s2_inst<CR, CP, CO, 0>(st, in, wpk, wmeta, bias, nullptr, out, N, S / 2);
+    S2F_CASE(20, 32, 64) S2F_CASE(64, 64, 64) S2F_CASE(20, 32, 32) S2F_CASE(32, 32, 32)
+#undef S2F_CASE
+    return hipErrorInvalidValue;
+}
+
+// Data gradient of the stride-2 conv times ELU'(aux): d = coarse [N][S/2][S/2][cout_conv] -> out = fine [N][S][S][cin_conv];
+// wpk = launch_pack_conv_weights_f16(w, O, I, cin_pad = O(conv out), cout = I(conv in), tflip 2).
+hipError_t launch_conv3x3_s2_dgrad_f16x3(hipStream_t st, const float* d, const void* wpk, const float* wmeta, const float* aux,
+                                         float* out, int N, int S, int c)
+{
+    if (S % 2 != 0 || S < 2) return hipErrorInvalidValue;
+    if (c == 64) return launch_s2_inst<64, 64, 64, 1>(st, d, wpk, wmeta, nullptr, aux, out, N, S / 2);
+    if (c == 32) return launch_s2_inst<32, 32, 32, 1>(st, d, wpk, wmeta, nullptr, aux, out, N, S / 2);
+    return hipErrorInvalidValue;
+}

@@ -256,10 +256,41 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nparts, 
     *o += alpha * ((s0 + s1) + (s2 + s3));
 }
 
+// first stage for many partial tiles: fold[f][e] = sum of the parts f*per .. f*per+per-1 (float4 columns, all of a
+// thread's loads independent), so that the layout-changing second stage reads WGRAD_FOLD tiles instead of hundreds
+__global__ __launch_bounds__(256)
+void wgrad_fold_kernel(const float4* __restrict__ part, int nparts, int per, int total4, float4* __restrict__ fold)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (e >= total4) return;
+    const int b0 = f * per, b1 = min(nparts, b0 + per);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    int b = b0;
+    for (; b + 7 < b1; b += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(b + j) * total4 + e];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            s0.x += v[j].x; s0.y += v[j].y; s0.z += v[j].z; s0.w += v[j].w;
+            s1.x += v[j + 1].x; s1.y += v[j + 1].y; s1.z += v[j + 1].z; s1.w += v[j + 1].w;
+        }
+    }
+    for (; b < b1; ++b) { const float4 v = part[(size_t)b * total4 + e]; s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w; }
+    fold[(size_t)f * total4 + e] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+}
+
 hipError_t launch_wgrad_reduce(hipStream_t st, const float* part, int nparts, int ci_pad, int co_pad, int O_real,
-                               int I_real, int I_dst, float alpha, float* dst)
+                               int I_real, int I_dst, float alpha, float* dst, float* fold)
 {
     const int total = 9 * ci_pad * co_pad;
+    if (fold && nparts >= 4 * WGRAD_FOLD && total % 4 == 0) {
+        const int per = (nparts + WGRAD_FOLD - 1) / WGRAD_FOLD, nf = (nparts + per - 1) / per;
+        hipLaunchKernelGGL(wgrad_fold_kernel, dim3((total / 4 + 255) / 256, nf), dim3(256), 0, st, (const float4*)part,
+                           nparts, per, total / 4, (float4*)fold);
+        part = fold;
+        nparts = nf;
+    }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, nparts, ci_pad, co_pad,
                        O_real, I_real, I_dst, alpha, dst);
     return hipGetLastError();
@@ -364,27 +395,6 @@ hipError_t launch_sgemm(hipStream_t st, int ta, int tb, int M, int N, int K, flo
 // =========================================================================================
 // spatial-broadcast layer parameter gradients
 // =========================================================================================
-// D[p][c] = sum_n dpre0[n][p][c]
-__global__ void sum_over_slots_kernel(const float4* __restrict__ dpre, float4* __restrict__ D, int N, size_t pc4)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pc4) return;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int n = 0; n < N; ++n) {
-        const float4 v = dpre[(size_t)n * pc4 + i];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    D[i] = s;
-}
-
-hipError_t launch_sum_over_slots(hipStream_t st, const float* dpre, float* D, int N, int P, int C)
-{
-    const size_t pc4 = (size_t)P * C / 4;
-    hipLaunchKernelGGL(sum_over_slots_kernel, dim3((unsigned)((pc4 + 255) / 256)), dim3(256), 0, st, (const float4*)dpre,
-                       (float4*)D, N, pc4);
-    return hipGetLastError();
-}
-
 // RT[n][tap][c] = sum over the border classes in which `tap` stays inside the image of Rc[n][cls][c]
 __global__ void l0_tap_sums_kernel(const float* __restrict__ Rc, float* __restrict__ RT, int N, int C)
 {

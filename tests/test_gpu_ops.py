@@ -102,3 +102,30 @@ def test_conv_tile_f16x3_forward_and_dgrad(C_, S, N, mode):
     refd = (F.conv_transpose2d(g.double(), w.double(), padding=1) * torch.where(a > 0, torch.ones_like(a), a + 1).double()).float()
     gotd = _conv_op(mode, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 1, 1, nhwc(refd).shape)
     assert rel_err(gotd, nhwc(refd)) < 3e-6, rel_err(gotd, nhwc(refd))
+
+
+@pytest.mark.parametrize('cin,cpad,cout,S,N', [(17, 20, 64, 32, 3), (64, 64, 64, 16, 5), (17, 20, 32, 16, 2),
+                                                (32, 32, 32, 8, 7), (64, 64, 64, 128, 1), (32, 32, 32, 4, 3),
+                                                (17, 20, 64, 128, 2), (64, 64, 64, 64, 9)])
+def test_conv_s2_f16x3_forward(cin, cpad, cout, S, N):
+    """split-fp16 stride-2 conv + bias + ELU of the refinement stack (parity sub-image decomposition)"""
+    x = _rand(N, cin, S, S, seed=30)
+    w = _rand(cout, cin, 3, 3, seed=31, scale=3.0 / (cin * 9) ** 0.5)
+    b = _rand(cout, seed=32, scale=0.5)
+    ref = nhwc(F.elu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1))).float()
+    xp = torch.full((N, S, S, cpad), 7.0)                      # pad channels hold garbage: weights there must be zero
+    xp[..., :cin] = nhwc(x)
+    got = _conv_op(5, xp, w, b, None, N, S, S, cout, cin, cpad, cout, 2, 0, 0, ref.shape)
+    assert rel_err(got, ref) < 3e-6, rel_err(got, ref)
+
+
+@pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 2), (64, 128, 1), (32, 4, 5), (64, 16, 40)])
+def test_conv_s2_f16x3_dgrad(C_, S, N):
+    """data gradient of the stride-2 conv times ELU'(saved activation); S = fine size, gradient is (S/2)^2"""
+    g = _rand(N, C_, S // 2, S // 2, seed=33, scale=1e-3)
+    w = _rand(C_, C_, 3, 3, seed=34, scale=3.0 / (C_ * 9) ** 0.5)
+    a = F.elu(_rand(N, C_, S, S, seed=35, scale=2.0))
+    refd = (F.conv_transpose2d(g.double(), w.double(), stride=2, padding=1, output_padding=1)
+            * torch.where(a > 0, torch.ones_like(a), a + 1).double()).float()
+    got = _conv_op(6, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 2, 1, 2, nhwc(refd).shape)
+    assert rel_err(got, nhwc(refd)) < 3e-6, rel_err(got, nhwc(refd))
