@@ -151,6 +151,11 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in_nhwc, const float*
                       int cout, int stride, int epi, int transpose_flip);
 int iodine_op_dec_out(void* stream, const float* in_nhwc, const float* w_oihw, const float* bias, float* out_nhwc4,
                       int n, int s, int c);
+/* weight + bias gradient of a 3x3 conv (kernel-level tests): in_nhwc [n][s][s][ci_pad] (ci_real of them meaningful),
+ * d_nhwc [n][so][so][co] with so = s (stride 1) or s/2 (stride 2); gw_oihw [co][ci_real][3][3] and gb [co] are
+ * ACCUMULATED into.  Split-fp16 kernels (stride 1: decoder stack, stride 2: refinement stack). */
+int iodine_op_conv3x3_wgrad(void* stream, const float* in_nhwc, const float* d_nhwc, float* gw_oihw, float* gb, int n,
+                            int s, int ci_pad, int ci_real, int co, int stride);
 
 #ifdef __cplusplus
 }

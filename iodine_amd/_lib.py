@@ -21,6 +21,7 @@ EXPORTS = (
     'iodine_param_info', 'iodine_set_params', 'iodine_workspace_bytes', 'iodine_set_workspace',
     'iodine_reconstruct', 'iodine_decode', 'iodine_train_forward', 'iodine_train_backward',
     'iodine_adam_step', 'iodine_ari_table', 'iodine_set_option', 'iodine_profile_read', 'iodine_debug_copy', 'iodine_linspace_host', 'iodine_op_conv3x3', 'iodine_op_dec_out',
+    'iodine_op_conv3x3_wgrad',
 )
 
 
@@ -85,6 +86,7 @@ def lib() -> C.CDLL:
     L.iodine_linspace_host.restype = None
     L.iodine_op_conv3x3.argtypes = [vp, ci] + [vp] * 5 + [ci] * 10
     L.iodine_op_dec_out.argtypes = [vp] + [vp] * 4 + [ci] * 3
+    L.iodine_op_conv3x3_wgrad.argtypes = [vp] + [vp] * 4 + [ci] * 6
     if L.iodine_abi_version() != 1:
         raise RuntimeError('libiodine_hip.so ABI version mismatch')
     _lib = L

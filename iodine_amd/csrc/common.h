@@ -15,6 +15,43 @@ IOD_DEVINL float elu1(float v) { return v > 0.f ? v : expm1f(v); }
 IOD_DEVINL float elu1_grad_from_out(float a) { return a > 0.f ? 1.f : a + 1.f; }
 IOD_DEVINL float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
+// ---- helpers of the split-fp16 weight-gradient kernels (transposing stagers) ----------
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+// out[e] = in[(e + r) & 3] with conditional moves only (a runtime-indexed vector would be demoted to scratch)
+IOD_DEVINL float4 rot4(const float4 v, int r)
+{
+    const bool b0 = r & 1, b1 = r & 2;
+    float4 t;
+    t.x = b0 ? v.y : v.x; t.y = b0 ? v.z : v.y; t.z = b0 ? v.w : v.z; t.w = b0 ? v.x : v.w;
+    float4 o;
+    o.x = b1 ? t.z : t.x; o.y = b1 ? t.w : t.y; o.z = b1 ? t.x : t.z; o.w = b1 ? t.y : t.w;
+    return o;
+}
+
+IOD_DEVINL unsigned pack_hi_lo(float x0, float x1, unsigned& lo_out)
+{
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+    unsigned short uh0, uh1, ul0, ul1;
+    __builtin_memcpy(&uh0, &h0, 2); __builtin_memcpy(&uh1, &h1, 2);
+    __builtin_memcpy(&ul0, &l0, 2); __builtin_memcpy(&ul1, &l1, 2);
+    lo_out = (unsigned)ul0 | ((unsigned)ul1 << 16);
+    return (unsigned)uh0 | ((unsigned)uh1 << 16);
+}
+
+// power-of-two scale for a tile with max |x| = mx, keeping the current one while mx*cur stays in [2^9, 2^14.5)
+IOD_DEVINL float tile_scale(float mx, float cur)
+{
+    if (!(mx > 0.f) || !(mx < 3.0e38f)) return cur;
+    const float t = mx * cur;
+    if (t >= 512.f && t < 23170.f) return cur;
+    const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu) - 127;
+    int se = 12 - e;
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    return __uint_as_float((unsigned)(127 + se) << 23);
+}
+
 // ---- packed conv-weight geometry (shared by host packer and kernels) ------------------
 // A 3x3 conv with CIN (padded) input channels is cut into chunks of CC channels.  Inside a
 // chunk the reduction index is organised in "quads" q = tap * (CC/4) + cig: 4 consecutive
@@ -130,3 +167,5 @@ hipError_t launch_conv3x3_s2_f16x3(hipStream_t st, const float* in, const void* 
                                    float* out, int N, int S, int cin_real, int cout);
 hipError_t launch_conv3x3_s2_dgrad_f16x3(hipStream_t st, const float* d, const void* wpk, const float* wmeta, const float* aux,
                                          float* out, int N, int S, int c);
+hipError_t launch_conv3x3_s2_wgrad_f16x3(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
+                                         int S, int ci_real, int nco, int* nparts, int* cipad, int* nbias_parts);

@@ -818,12 +818,20 @@ int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, floa
             const float* in = l == 0 ? b.enc[i] : b.ract[i][l - 1];
             const int cip = l == 0 ? 20 : Cr, ireal = l == 0 ? 17 : Cr;
             int nparts = 0, cipad = 0;
-            PROF(h, st, "refine_wgrad", launch_conv3x3_wgrad_gather(st, in, b.rdpre[l], b.wg_part, N, sz[l], sz[l], cip, Cr, 2,
-                                                                    &nparts, &cipad));
             const std::string base = "refine.mlc.layers." + std::to_string(l);
-            HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, G(base + ".weight"), b.wg_fold));
-            PROF(h, st, "refine_bias_grad", launch_colsum_tall(st, b.rdpre[l], N * sz[l + 1] * sz[l + 1], Cr, 1.f,
-                                                               G(base + ".bias"), b.wg_part_b, (size_t)512 * 64));
+            if (h->precision == 1 && refine_f16_ok(h)) {
+                int nb = 0;
+                PROF(h, st, "refine_wgrad", launch_conv3x3_s2_wgrad_f16x3(st, in, b.rdpre[l], b.wg_part, b.wg_part_b, N, sz[l],
+                                                                          cip, Cr, &nparts, &cipad, &nb));
+                HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, G(base + ".weight"), b.wg_fold));
+                HIPCHK(h, launch_colsum(st, b.wg_part_b, nb, Cr, Cr, 1.f, G(base + ".bias")));
+            } else {
+                PROF(h, st, "refine_wgrad", launch_conv3x3_wgrad_gather(st, in, b.rdpre[l], b.wg_part, N, sz[l], sz[l], cip, Cr, 2,
+                                                                        &nparts, &cipad));
+                HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, G(base + ".weight"), b.wg_fold));
+                PROF(h, st, "refine_bias_grad", launch_colsum_tall(st, b.rdpre[l], N * sz[l + 1] * sz[l + 1], Cr, 1.f,
+                                                                   G(base + ".bias"), b.wg_part_b, (size_t)512 * 64));
+            }
             if (l > 0) {
                 if (h->precision == 1 && refine_f16_ok(h))
                     PROF(h, st, "refine_dgrad", launch_conv3x3_s2_dgrad_f16x3(st, b.rdpre[l], h->ref_wb16[l], h->ref_wmeta[l] + 2,
@@ -999,6 +1007,32 @@ int iodine_op_dec_out(void* stream, const float* in, const float* w, const float
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(wk);
     if (e != hipSuccess) { g_create_error = std::string("iodine_op_dec_out: ") + hipGetErrorString(e); return IODINE_ERR_HIP; }
+    return IODINE_OK;
+}
+
+int iodine_op_conv3x3_wgrad(void* stream, const float* in, const float* d, float* gw, float* gb, int n, int s, int ci_pad,
+                            int ci_real, int co, int stride)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int cmax = std::max(std::max(ci_pad, co), 32);
+    const size_t part_elems = (size_t)512 * 4 * 9 * cmax * cmax, fold_elems = (size_t)WGRAD_FOLD * 9 * cmax * cmax;
+    float* buf = nullptr;
+    if (hipMalloc((void**)&buf, (part_elems + fold_elems + (size_t)512 * 64) * sizeof(float)) != hipSuccess) return IODINE_ERR_HIP;
+    float *part = buf, *fold = buf + part_elems, *part_b = fold + fold_elems;
+    int nparts = 0, cip = 0, nb = 0;
+    hipError_t e;
+    if (stride == 1) {
+        e = launch_conv3x3_wgrad_f16x3(st, in, d, part, part_b, n, s, ci_pad, co, &nparts, &cip, &nb);
+        // stride-1 partial tiles are [9][ci][co padded to 32]
+        if (e == hipSuccess) e = launch_wgrad_reduce(st, part, nparts, ci_pad, cip, co, ci_real, ci_real, 1.f, gw, fold);
+    } else {
+        e = launch_conv3x3_s2_wgrad_f16x3(st, in, d, part, part_b, n, s, ci_pad, co, &nparts, &cip, &nb);
+        if (e == hipSuccess) e = launch_wgrad_reduce(st, part, nparts, cip, co, co, ci_real, ci_real, 1.f, gw, fold);
+    }
+    if (e == hipSuccess) e = launch_colsum(st, part_b, nb, co, co, 1.f, gb);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    if (e != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3_wgrad: ") + hipGetErrorString(e); return IODINE_ERR_HIP; }
     return IODINE_OK;
 }
 

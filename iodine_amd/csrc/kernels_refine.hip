@@ -315,3 +315,251 @@ hipError_t launch_conv3x3_s2_dgrad_f16x3(hipStream_t st, const float* d, const v
     if (c == 32) return launch_s2_inst<32, 32, 32, 1>(st, d, wpk, wmeta, nullptr, aux, out, N, S / 2);
     return hipErrorInvalidValue;
 }
+
+// =========================================================================================
+// Weight gradient of the stride-2 conv, split-fp16:  dW[tap][ci][co] = sum_px a[2oy+ky-1][2ox+kx-1][ci] * d[oy][ox][co]
+//   M = ci, N = co, K = coarse pixels (16 per MFMA = one coarse tile row), as in the stride-1 kernel of
+//   kernels_train.hip; the fine input is staged TRANSPOSED (one fp16 plane per channel) and DE-INTERLEAVED by column
+//   parity, so that the K-consecutive operand of every tap is contiguous:
+//     kx = 1 -> even plane at X,  kx = 2 -> odd plane at X,  kx = 0 -> odd plane at X-1 (register shift, v_alignbit)
+//   plane row (20 dwords, 2 px each): [3] = odd (X=-2,-1) | [4..11] odd X=0..15 | [12..19] even X=0..15
+//   tile = TH x 16 coarse pixels (fine halo 2TH+1 rows), persistent blocks, one partial tile set per (block, K-split).
+// =========================================================================================
+namespace {
+
+template <int CI_REAL, int CI, int NCO, int TH>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_s2_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __restrict__ d, float* __restrict__ part,
+                                   float* __restrict__ part_b, int Sc, int ntiles, int tiles_x, int tiles_y)
+{
+    constexpr int MT = CI / 32, NTT = NCO / 32, KS = 4 / (MT * NTT);
+    static_assert(TH % KS == 0, "tile rows must split evenly over the K-split waves");
+    constexpr int RW = TH / KS;
+    constexpr int HR = 2 * TH + 1;
+    constexpr int APL = HR * 20, DPL = TH * 8 + 4;       // dwords per channel plane (APL/4, DPL/4 odd: conflict-free b128)
+    static_assert((APL / 4) % 2 == 1 && (DPL / 4) % 2 == 1, "plane strides");
+    constexpr int A4 = CI_REAL / 4, D4 = NCO / 4;
+    constexpr int NA_UNITS = HR * 17 * A4, ND_UNITS = TH * 8 * D4;
+    constexpr int NAU = (NA_UNITS + 255) / 256, NDU = (ND_UNITS + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned smem_w2[];
+    unsigned* s_a = smem_w2;                             // [2][CI][APL]
+    unsigned* s_d = smem_w2 + 2 * CI * APL;              // [2][NCO][DPL]
+    float* s_max = reinterpret_cast<float*>(s_d + 2 * NCO * DPL);     // [8]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, kh = lane >> 5, li = lane & 31;
+    const int mi = wv % MT, ni = (wv / MT) % NTT, ks = wv / (MT * NTT);
+    const int ci = mi * 32 + li, co = ni * 32 + li;
+    const int Sf = 2 * Sc;
+
+    if (CI_REAL < CI) {                                  // planes of the pad channels stay zero for the whole kernel
+        for (int i = tid; i < 2 * CI * APL; i += 256) s_a[i] = 0u;
+    }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sa = 1.f, sd = 1.f, acc_prod = 1.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int n = t / tiles_y;
+        const float* a_n = a + (size_t)n * Sf * Sf * CI_REAL;
+        const float* d_n = d + (size_t)n * Sc * Sc * NCO;
+
+        float4 ra[NAU][2], rd[NDU][2];
+        float ma = 0.f, md = 0.f;
+#pragma unroll
+        for (int k = 0; k < NAU; ++k) {
+            const int u = tid + k * 256;
+            const int c4 = u % A4, tt = u / A4, slot = tt % 17, row = tt / 17;
+            const int par = slot <= 8 ? 1 : 0;
+            const int j = slot == 0 ? -1 : (slot <= 8 ? slot - 1 : slot - 9);
+            const int fy = 2 * ty * TH - 1 + row;
+            const int fx0 = 2 * (tx * 16 + 2 * j) + par, fx1 = fx0 + 2;
+            ra[k][0] = ra[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < NA_UNITS && fy >= 0 && fy < Sf) {
+                if (fx0 >= 0 && fx0 < Sf) ra[k][0] = *reinterpret_cast<const float4*>(a_n + ((size_t)fy * Sf + fx0) * CI_REAL + c4 * 4);
+                if (fx1 >= 0 && fx1 < Sf) ra[k][1] = *reinterpret_cast<const float4*>(a_n + ((size_t)fy * Sf + fx1) * CI_REAL + c4 * 4);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                ma = fmaxf(ma, fmaxf(fmaxf(fabsf(ra[k][q].x), fabsf(ra[k][q].y)), fmaxf(fabsf(ra[k][q].z), fabsf(ra[k][q].w))));
+        }
+#pragma unroll
+        for (int k = 0; k < NDU; ++k) {
+            const int u = tid + k * 256;
+            const int c4 = u % D4, tt = u / D4, p = tt % 8, row = tt / 8;
+            const int gy = ty * TH + row, gx = tx * 16 + 2 * p;
+            rd[k][0] = rd[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < ND_UNITS && gy < Sc) {
+                if (gx < Sc) rd[k][0] = *reinterpret_cast<const float4*>(d_n + ((size_t)gy * Sc + gx) * NCO + c4 * 4);
+                if (gx + 1 < Sc) rd[k][1] = *reinterpret_cast<const float4*>(d_n + ((size_t)gy * Sc + gx + 1) * NCO + c4 * 4);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                md = fmaxf(md, fmaxf(fmaxf(fabsf(rd[k][q].x), fabsf(rd[k][q].y)), fmaxf(fabsf(rd[k][q].z), fabsf(rd[k][q].w))));
+                bsum.x += rd[k][q].x; bsum.y += rd[k][q].y; bsum.z += rd[k][q].z; bsum.w += rd[k][q].w;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ma = fmaxf(ma, __shfl_xor(ma, off, 64));
+            md = fmaxf(md, __shfl_xor(md, off, 64));
+        }
+        if (lane == 0) { s_max[wv] = ma; s_max[4 + wv] = md; }
+        __syncthreads();                                   // every wave is also done with the previous tile's planes
+        ma = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        md = fmaxf(fmaxf(s_max[4], s_max[5]), fmaxf(s_max[6], s_max[7]));
+        sa = tile_scale(ma, sa);
+        sd = tile_scale(md, sd);
+        const float prod = sa * sd;
+        if (prod != acc_prod) {                            // block-uniform; exact (powers of two)
+            const float r = prod / acc_prod;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[tp][q] *= r;
+            acc_prod = prod;
+        }
+
+#pragma unroll
+        for (int k = 0; k < NAU; ++k) {
+            const int u = tid + k * 256;
+            if (u < NA_UNITS) {
+                const int c4 = u % A4, tt = u / A4, slot = tt % 17, row = tt / 17;
+                const int rot = c4 & 3;
+                const float4 q0 = rot4(ra[k][0], rot), q1 = rot4(ra[k][1], rot);
+                const float x0[4] = {q0.x, q0.y, q0.z, q0.w}, x1[4] = {q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned lo;
+                    const unsigned hi = pack_hi_lo(x0[e] * sa, x1[e] * sa, lo);
+                    const int ch = c4 * 4 + ((e + rot) & 3);
+                    s_a[(0 * CI + ch) * APL + row * 20 + slot + 3] = hi;
+                    s_a[(1 * CI + ch) * APL + row * 20 + slot + 3] = lo;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NDU; ++k) {
+            const int u = tid + k * 256;
+            if (u < ND_UNITS) {
+                const int c4 = u % D4, tt = u / D4, p = tt % 8, row = tt / 8;
+                const int rot = c4 & 3;
+                const float4 q0 = rot4(rd[k][0], rot), q1 = rot4(rd[k][1], rot);
+                const float x0[4] = {q0.x, q0.y, q0.z, q0.w}, x1[4] = {q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned lo;
+                    const unsigned hi = pack_hi_lo(x0[e] * sd, x1[e] * sd, lo);
+                    const int ch = c4 * 4 + ((e + rot) & 3);
+                    s_d[(0 * NCO + ch) * DPL + row * 8 + p] = hi;
+                    s_d[(1 * NCO + ch) * DPL + row * 8 + p] = lo;
+                }
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int r = ks * RW + rr;
+            h16x8 bh, bl;
+            {
+                const uint4 vb_h = *reinterpret_cast<const uint4*>(s_d + (0 * NCO + co) * DPL + r * 8 + 4 * kh);
+                const uint4 vb_l = *reinterpret_cast<const uint4*>(s_d + (1 * NCO + co) * DPL + r * 8 + 4 * kh);
+                __builtin_memcpy(&bh, &vb_h, 16); __builtin_memcpy(&bl, &vb_l, 16);
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                h16x8 A[2][3];                               // [term][kx]
+#pragma unroll
+                for (int term = 0; term < 2; ++term) {
+                    const unsigned* pl = s_a + (term * CI + ci) * APL + (2 * r + ky) * 20;
+                    const uint4 vo = *reinterpret_cast<const uint4*>(pl + 4 + 4 * kh);         // odd plane X = 8kh .. 8kh+7
+                    const uint4 ve = *reinterpret_cast<const uint4*>(pl + 12 + 4 * kh);        // even plane
+                    const unsigned prev = pl[3 + 4 * kh] & 0xffff0000u;                        // odd X = 8kh-1 in the high half
+                    uint4 m1;
+                    m1.x = __builtin_amdgcn_alignbit(vo.x, prev, 16);
+                    m1.y = __builtin_amdgcn_alignbit(vo.y, vo.x, 16);
+                    m1.z = __builtin_amdgcn_alignbit(vo.z, vo.y, 16);
+                    m1.w = __builtin_amdgcn_alignbit(vo.w, vo.z, 16);
+                    __builtin_memcpy(&A[term][0], &m1, 16);
+                    __builtin_memcpy(&A[term][1], &ve, 16);
+                    __builtin_memcpy(&A[term][2], &vo, 16);
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int tap = ky * 3 + kx;
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][kx], bh, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][kx], bl, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][kx], bh, acc[tap], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const float inv = 1.f / acc_prod;
+    float* pw = part + ((size_t)(blockIdx.x * KS + ks) * 9) * CI * NCO;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            pw[((size_t)tap * CI + cr) * NCO + ni * 32 + li] = acc[tap][r] * inv;
+        }
+    __syncthreads();
+    float4* s_red = reinterpret_cast<float4*>(smem_w2);
+    s_red[tid] = bsum;
+    __syncthreads();
+    if (tid < D4) {
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = tid; j < 256; j += D4) { const float4 v = s_red[j]; t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w; }
+        *reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * NCO + tid * 4) = t4;
+    }
+}
+
+template <int CI_REAL, int CI, int NCO, int TH>
+hipError_t launch_s2_wgrad_inst(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N, int Sc,
+                                int* nparts, int* cipad, int* nbias_parts)
+{
+    constexpr int MT = CI / 32, NTT = NCO / 32, KS = 4 / (MT * NTT);
+    constexpr size_t lds = (size_t)(2 * CI * (2 * TH + 1) * 20 + 2 * NCO * (TH * 8 + 4)) * 4 + 32;
+    static_assert(lds >= 256 * 16, "bias reduction reuses the planes");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_s2_wgrad_f16x3_kernel<CI_REAL, CI, NCO, TH>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles_x = (Sc + 15) / 16, tiles_y = (Sc + TH - 1) / TH, ntiles = N * tiles_x * tiles_y;
+    const int blocks = ntiles < 512 ? ntiles : 512;
+    hipLaunchKernelGGL((conv3x3_s2_wgrad_f16x3_kernel<CI_REAL, CI, NCO, TH>), dim3(blocks), dim3(256), lds, st, a, d, part,
+                       part_b, Sc, ntiles, tiles_x, tiles_y);
+    *nparts = blocks * KS;
+    *cipad = CI;
+    *nbias_parts = blocks;
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// part: nparts x [9][cipad][nco] partial tiles (reduce with launch_wgrad_reduce), part_b: nbias_parts x [nco] bias partials.
+// S = fine (input) size, even.
+hipError_t launch_conv3x3_s2_wgrad_f16x3(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
+                                         int S, int ci_real, int nco, int* nparts, int* cipad, int* nbias_parts)
+{
+    if (S % 2 != 0 || S < 2) return hipErrorInvalidValue;
+#define S2W_CASE(CR, CP, CO, TH) \
+    if (ci_real == CR && nco == CO) return launch_s2_wgrad_inst<CR, CP, CO, TH>(st, a, d, part, part_b, N, S / 2, nparts, cipad, nbias_parts);
+    S2W_CASE(64, 64, 64, 2) S2W_CASE(20, 32, 64, 4) S2W_CASE(32, 32, 32, 4) S2W_CASE(20, 32, 32, 4)
+#undef S2W_CASE
+    return hipErrorInvalidValue;
+}

@@ -606,42 +606,6 @@ hipError_t launch_pool_bwd(hipStream_t st, const float* dpooled, const float* ac
 //   Range: each tile is scaled by powers of two chosen from its max |a|, max |d| (block-local, with hysteresis);
 //   the accumulators are rescaled exactly when the product of scales changes.
 // =========================================================================================
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-
-// out[e] = in[(e + r) & 3] with conditional moves only (a runtime-indexed vector would be demoted to scratch)
-IOD_DEVINL float4 rot4(const float4 v, int r)
-{
-    const bool b0 = r & 1, b1 = r & 2;
-    float4 t;
-    t.x = b0 ? v.y : v.x; t.y = b0 ? v.z : v.y; t.z = b0 ? v.w : v.z; t.w = b0 ? v.x : v.w;
-    float4 o;
-    o.x = b1 ? t.z : t.x; o.y = b1 ? t.w : t.y; o.z = b1 ? t.x : t.z; o.w = b1 ? t.y : t.w;
-    return o;
-}
-
-IOD_DEVINL unsigned pack_hi_lo(float x0, float x1, unsigned& lo_out)
-{
-    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
-    unsigned short uh0, uh1, ul0, ul1;
-    __builtin_memcpy(&uh0, &h0, 2); __builtin_memcpy(&uh1, &h1, 2);
-    __builtin_memcpy(&ul0, &l0, 2); __builtin_memcpy(&ul1, &l1, 2);
-    lo_out = (unsigned)ul0 | ((unsigned)ul1 << 16);
-    return (unsigned)uh0 | ((unsigned)uh1 << 16);
-}
-
-// power-of-two scale for a tile with max |x| = mx, keeping the current one while mx*cur stays in [2^9, 2^14.5)
-IOD_DEVINL float tile_scale(float mx, float cur)
-{
-    if (!(mx > 0.f) || !(mx < 3.0e38f)) return cur;
-    const float t = mx * cur;
-    if (t >= 512.f && t < 23170.f) return cur;
-    const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu) - 127;
-    int se = 12 - e;
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    return __uint_as_float((unsigned)(127 + se) << 23);
-}
-
 template <int CI, int NCO>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __restrict__ d, float* __restrict__ part,

@@ -129,3 +129,34 @@ def test_conv_s2_f16x3_dgrad(C_, S, N):
             * torch.where(a > 0, torch.ones_like(a), a + 1).double()).float()
     got = _conv_op(6, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 2, 1, 2, nhwc(refd).shape)
     assert rel_err(got, nhwc(refd)) < 3e-6, rel_err(got, nhwc(refd))
+
+
+def _wgrad_op(x_nhwc, d_nhwc, n, s, ci_pad, ci_real, co, stride):
+    L = _lib.lib()
+    gw = torch.zeros(co, ci_real, 3, 3, device=DEV)
+    gb = torch.zeros(co, device=DEV)
+    xs, ds = x_nhwc.to(DEV).contiguous(), d_nhwc.to(DEV).contiguous()
+    _lib.check(L.iodine_op_conv3x3_wgrad(None, _lib.ptr(xs), _lib.ptr(ds), _lib.ptr(gw), _lib.ptr(gb), n, s, ci_pad,
+                                         ci_real, co, stride), None, 'iodine_op_conv3x3_wgrad')
+    torch.cuda.synchronize()
+    return gw.cpu(), gb.cpu()
+
+
+@pytest.mark.parametrize('cin,cpad,cout,S,N,stride', [
+    (64, 64, 64, 32, 3, 1), (32, 32, 32, 16, 5, 1), (64, 64, 64, 128, 1, 1),
+    (17, 20, 64, 32, 3, 2), (64, 64, 64, 16, 5, 2), (17, 20, 32, 16, 2, 2), (32, 32, 32, 8, 7, 2),
+    (64, 64, 64, 128, 1, 2), (32, 32, 32, 4, 3, 2), (17, 20, 64, 128, 2, 2), (64, 64, 64, 64, 9, 2)])
+def test_conv_wgrad_f16x3(cin, cpad, cout, S, N, stride):
+    """split-fp16 weight/bias gradients of the stride-1 (decoder) and stride-2 (refinement) convs vs autograd in fp64"""
+    x = _rand(N, cin, S, S, seed=40).double()
+    So = S // stride
+    d = _rand(N, cout, So, So, seed=41, scale=1e-2).double()
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, w, b, stride=stride, padding=1)
+    (y * d).sum().backward()
+    xp = torch.full((N, S, S, cpad), 7.0)
+    xp[..., :cin] = nhwc(x.float())
+    gw, gb = _wgrad_op(xp, nhwc(d.float()), N, S, cpad, cin, cout, stride)
+    assert rel_err(gw, w.grad.float()) < 3e-6, rel_err(gw, w.grad.float())
+    assert rel_err(gb, b.grad.float()) < 3e-6, rel_err(gb, b.grad.float())
