@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libiodine_hip.so')
+# IODINE_HIP_LIB selects another build of the same library (tools/ab_libs.sh: same-box A/B of two builds)
+LIB_PATH = os.environ.get('IODINE_HIP_LIB') or os.path.join(_HERE, 'libiodine_hip.so')
 
 ENC_ORDER = ('posterior', 'grad_post', 'image', 'means', 'mask', 'mask_logits', 'mask_posterior',
              'grad_means', 'grad_mask', 'likelihood', 'leave_one_out_likelihood', 'coordinate')

@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, 'libiodine_hip.so')
 SOURCES = ['kernels_conv.hip', 'kernels_pixel.hip', 'kernels_misc.hip', 'kernels_train.hip', 'kernels_refine.hip', 'iodine_api.cpp']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(ROOT, 'include', 'iodine_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-         '-Wno-unused-result']
+         '-Wno-unused-result'] + os.environ.get('IODINE_EXTRA_HIPCC_FLAGS', '').split()   # e.g. -DIODINE_TILE_PROF (tools only)
 
 
 def _hipcc() -> str:

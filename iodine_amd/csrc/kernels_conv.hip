@@ -8,6 +8,7 @@
 #include "common.h"
 #include <cstdlib>
 #include <cstdio>
+#include <vector>
 #include <type_traits>
 
 // =========================================================================================
@@ -488,6 +489,27 @@ hipError_t launch_pack_conv_weights_f16(hipStream_t st, const float* src, int O,
 
 IOD_DEVINL float elu1_fast(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
 
+// Phase timing (tools/tile_phase_prof.py; build with IODINE_EXTRA_HIPCC_FLAGS=-DIODINE_TILE_PROF): wave 0 of every block
+// adds the s_memtime deltas between phase boundaries to g_tile_prof[slot]; compiled out of the product library.
+#ifdef IODINE_TILE_PROF
+constexpr int TP_MAXBLK = 16384;
+__device__ unsigned g_tile_prof[TP_MAXBLK * 8];
+#define TP_DECL unsigned long long tp_last = __builtin_amdgcn_s_memtime(); unsigned tp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TP_STAMP(slot)                                                                      \
+    do {                                                                                    \
+        const unsigned long long tp_now = __builtin_amdgcn_s_memtime();                     \
+        tp_acc[slot] += (unsigned)(tp_now - tp_last);                                       \
+        tp_last = tp_now;                                                                   \
+    } while (0)
+#define TP_FLUSH                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < TP_MAXBLK)                                         \
+        for (int i_ = 0; i_ < 8; ++i_) g_tile_prof[blockIdx.x * 8 + i_] = tp_acc[i_]
+#else
+#define TP_DECL
+#define TP_STAMP(slot)
+#define TP_FLUSH
+#endif
+
 template <int CIN, int COUT, int EPI>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
@@ -508,6 +530,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     uint4* s_w = reinterpret_cast<uint4*>(smem_b + IN_BYTES);
     float* s_max = reinterpret_cast<float*>(smem_b + IN_BYTES + W_U4 * 16);
 
+    TP_DECL;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, kh = lane >> 5, li = lane & 31;
     const int prow = li >> 4, pcol = li & 15;
@@ -571,8 +594,10 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        TP_STAMP(1);                                         // [1] wait for the chunk's global loads + max
         if (lane == 0) s_max[wv] = m;
         __syncthreads();                                     // also: every wave is done reading the previous chunk
+        TP_STAMP(2);                                         // [2] barrier 1
         const float mb = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
         const int e = (int)((__float_as_uint(mb) >> 23) & 0xffu) - 127;      // floor(log2(mb)) for normal mb
         int se = 12 - e;                                     // mb * 2^se in [2^12, 2^13)
@@ -602,7 +627,9 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             const int idx = tid + k * 256;
             if (idx < W_U4) s_w[idx] = rw[k];
         }
+        TP_STAMP(3);                                         // [3] scale, split, LDS writes
         __syncthreads();
+        TP_STAMP(4);                                         // [4] barrier 2
         return scale;
     };
     auto rescale = [&](float new_scale) {
@@ -648,17 +675,17 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[nt], f.al[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[nt], f.ah[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[nt], f.ah[mt], acc[mt][nt], 0, 0, 0);
     };
     using std::integral_constant;
 #define IOD_STEP(T, FCUR, FNEXT)                                                                  \
@@ -671,11 +698,14 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     __builtin_amdgcn_sched_barrier(0);
 
     auto compute = [&]() {
+        TP_STAMP(5);                                         // [5] issue of the next prefetches (between commit and compute)
         Frag f0, f1;
         LOADF(integral_constant<int, 0>{}, f0);
         IOD_STEP(0, f0, f1) IOD_STEP(1, f1, f0) IOD_STEP(2, f0, f1) IOD_STEP(3, f1, f0) IOD_STEP(4, f0, f1)
         IOD_STEP(5, f1, f0) IOD_STEP(6, f0, f1) IOD_STEP(7, f1, f0) IOD_STEP(8, f0, f1)
+        TP_STAMP(6);                                         // [6] 9 taps of LDS fragment reads + MFMA
     };
+    TP_STAMP(0);                                             // [0] block start: index arithmetic
     prefetch_in(0, rinA);
     prefetch_w(0);
     if (NCHUNK > 1) prefetch_in(1, rinB);
@@ -702,31 +732,42 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 #undef IOD_STEP
 
     const float inv_ws = wmeta[1] / cur_scale;
+    // The MFMAs are issued as (weights, activations): D = W^T A^T, so a lane's accumulator rows are CHANNELS - lane
+    // (li, kh) holds pixel li of the 32-pixel tile and channels 8g + 4kh .. +3 in registers 4g .. 4g+3: the epilogue
+    // moves float4s of 4 consecutive channels (16 instead of 64 memory instructions per thread).
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt) {
+        const int gy = ty * 16 + 4 * wv + 2 * mt + (li >> 4);
+        const int gx = tx * 16 + (li & 15);
+        const int pix = (n * S + gy) * S + gx;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = nt * 32 + li;
-            float bv = 0.f;
-            if (EPI == EPI_BIAS_ELU) bv = bias[co];
-            if (EPI == EPI_OUT4) bv = li < 4 ? bias[li] : 0.f;
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int gy = ty * 16 + 4 * wv + 2 * mt + (m >> 4);
-                const int gx = tx * 16 + (m & 15);
-                const int pix = (n * S + gy) * S + gx;
-                float v = acc[mt][nt][r] * inv_ws;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c0 = nt * 32 + 8 * g4 + 4 * kh;
+                float4 v = make_float4(acc[mt][nt][4 * g4] * inv_ws, acc[mt][nt][4 * g4 + 1] * inv_ws,
+                                       acc[mt][nt][4 * g4 + 2] * inv_ws, acc[mt][nt][4 * g4 + 3] * inv_ws);
                 if (EPI == EPI_OUT4) {                   // decoder output conv: 4 real channels, out is [N][P][4]
-                    if (li < 4) out[(size_t)pix * 4 + li] = v + bv;
+                    if (c0 == 0) {
+                        const float4 bv = *reinterpret_cast<const float4*>(bias);
+                        *reinterpret_cast<float4*>(out + (size_t)pix * 4) = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
+                    }
                     continue;
                 }
-                const size_t o = (size_t)pix * COUT + co;
-                if (EPI == EPI_BIAS_ELU) v = elu1_fast(v + bv);
-                else if (EPI == EPI_MUL_ELUGRAD) v *= elu1_grad_from_out(aux[o]);
-                out[o] = v;
+                const size_t o = (size_t)pix * COUT + c0;
+                if (EPI == EPI_BIAS_ELU) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+                    v = make_float4(elu1_fast(v.x + bv.x), elu1_fast(v.y + bv.y), elu1_fast(v.z + bv.z), elu1_fast(v.w + bv.w));
+                } else if (EPI == EPI_MUL_ELUGRAD) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(aux + o);
+                    v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
+                    v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
+                }
+                *reinterpret_cast<float4*>(out + o) = v;
             }
-        }
+    }
+    TP_STAMP(7);                                             // [7] epilogue (issue of the stores)
+    TP_FLUSH;
 }
 
 template <int CIN, int COUT, int EPI>
@@ -744,6 +785,22 @@ static hipError_t launch_tile_f16x3_inst(hipStream_t st, const float* in, const 
     const int tiles = S / 16;
     hipLaunchKernelGGL((conv3x3_tile_f16x3_kernel<CIN, COUT, EPI>), dim3(N * tiles * tiles), dim3(256), lds, st, in,
                        reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, S, tiles);
+#ifdef IODINE_TILE_PROF
+    {
+        const int nb = std::min(N * tiles * tiles, TP_MAXBLK);
+        std::vector<unsigned> hp((size_t)nb * 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(g_tile_prof), hp.size() * sizeof(unsigned));
+        static const char* names[8] = {"start", "load-wait+max", "barrier1", "split+lds-write", "barrier2", "prefetch-issue",
+                                       "taps(lds-read+mfma)", "epilogue"};
+        double sum[8] = {0}, tot = 0;
+        for (int b2 = 0; b2 < nb; ++b2) for (int i = 0; i < 8; ++i) sum[i] += hp[(size_t)b2 * 8 + i];
+        for (int i = 0; i < 8; ++i) tot += sum[i] / nb;
+        fprintf(stderr, "[tile prof] memtime ticks per block (wave 0), total %.0f:", tot);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f |", names[i], sum[i] / nb);
+        fprintf(stderr, "\n");
+    }
+#endif
     return hipGetLastError();
 }
 

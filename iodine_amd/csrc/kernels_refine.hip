@@ -205,9 +205,9 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], al[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
                 }
         }
     };
@@ -228,27 +228,33 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
     });
 
     const float inv_ws = wmeta[1] / cur_scale;
+    // MFMAs are issued as (weights, activations): accumulator rows are channels, lane li = pixel li of the 32-px tile,
+    // registers 4g..4g+3 = channels 8g + 4kh .. +3 -> float4 epilogue traffic
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt) {
+        const int Y = ty * 16 + 4 * wv + 2 * mt + (li >> 4);
+        const int X = tx * 16 + (li & 15);
+        if (Y >= Sc || X >= Sc) continue;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = nt * 32 + li;
-            const float bv = MODE == 0 ? bias[co] : 0.f;
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int Y = ty * 16 + 4 * wv + 2 * mt + (m >> 4);
-                const int X = tx * 16 + (m & 15);
-                if (Y >= Sc || X >= Sc) continue;
-                float v = acc[mt][nt][r] * inv_ws;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c0 = nt * 32 + 8 * g4 + 4 * kh;
+                float4 v = make_float4(acc[mt][nt][4 * g4] * inv_ws, acc[mt][nt][4 * g4 + 1] * inv_ws,
+                                       acc[mt][nt][4 * g4 + 2] * inv_ws, acc[mt][nt][4 * g4 + 3] * inv_ws);
                 if (MODE == 0) {
-                    out[(size_t)((n * Sc + Y) * Sc + X) * COUT + co] = elu1_fast_r(v + bv);
+                    const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+                    *reinterpret_cast<float4*>(out + (size_t)((n * Sc + Y) * Sc + X) * COUT + c0) =
+                        make_float4(elu1_fast_r(v.x + bv.x), elu1_fast_r(v.y + bv.y), elu1_fast_r(v.z + bv.z), elu1_fast_r(v.w + bv.w));
                 } else {
-                    const size_t o = (size_t)((n * Sf + 2 * Y + (SBT >> 1)) * Sf + 2 * X + (SBT & 1)) * COUT + co;
-                    out[o] = v * elu1_grad_from_out(aux[o]);
+                    const size_t o = (size_t)((n * Sf + 2 * Y + (SBT >> 1)) * Sf + 2 * X + (SBT & 1)) * COUT + c0;
+                    const float4 a4 = *reinterpret_cast<const float4*>(aux + o);
+                    v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
+                    v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
+                    *reinterpret_cast<float4*>(out + o) = v;
                 }
             }
-        }
+    }
 }
 
 // MODE 0: in = fine [N][2Sc][2Sc][CIN_REAL] -> out = coarse [N][Sc][Sc][COUT], bias + ELU
