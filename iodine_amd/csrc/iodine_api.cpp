@@ -364,15 +364,18 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
     PROF(h, st, "dec_out_dgrad", launch_conv3x3_tile(st, b.g, h->dec_out_wb, nullptr, b.act[Dd - 1], b.dpre[cur], N,
                                                      h->S, 4, Cd, EPI_MUL_ELUGRAD));
     if (train_alpha != 0.f) {
-        if (h->precision == 1)
-            PROF(h, st, "dec_out_wgrad", launch_conv3x3_wgrad_f16x3(st, b.act[Dd - 1], b.g, b.wg_part, b.wg_part_b, N,
-                                                                     h->S, Cd, 4, &nparts, &ncop, &nb));
-        else
+        const int wi = param_index(h, "decoder.conv.weight"), bi = param_index(h, "decoder.conv.bias");
+        if (h->precision == 1) {                           // GEMM form: rows (tap, co), no N = 4 -> 32 padding
+            PROF(h, st, "dec_out_wgrad", launch_dec_out_wgrad_gemm_f16x3(st, b.act[Dd - 1], b.g, b.wg_part, b.wg_part_b, N, h->S,
+                                                                          Cd, &nparts, &nb));
+            HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, Cd, 4, 4, Cd, Cd, train_alpha, h->gacc[wi], b.wg_fold));
+            HIPCHK(h, launch_colsum(st, b.wg_part_b, nb, 4, 4, train_alpha, h->gacc[bi]));
+        } else {
             PROF(h, st, "dec_out_wgrad", launch_conv3x3_wgrad_tile(st, b.act[Dd - 1], b.g, b.wg_part, b.wg_part_b, N,
                                                                     h->S, Cd, 4, &nparts, &ncop, &nb));
-        rc = reduce_wgrad(h, st, nparts, Cd, ncop, 4, Cd, Cd, train_alpha, param_index(h, "decoder.conv.weight"),
-                          param_index(h, "decoder.conv.bias"), nb);
-        if (rc) return rc;
+            rc = reduce_wgrad(h, st, nparts, Cd, ncop, 4, Cd, Cd, train_alpha, wi, bi, nb);
+            if (rc) return rc;
+        }
     }
     for (int l = Dd - 1; l >= 1; --l) {
         if (train_alpha != 0.f) {
@@ -1021,7 +1024,10 @@ int iodine_op_conv3x3_wgrad(void* stream, const float* in, const float* d, float
     float *part = buf, *fold = buf + part_elems, *part_b = fold + fold_elems;
     int nparts = 0, cip = 0, nb = 0;
     hipError_t e;
-    if (stride == 1) {
+    if (stride == 1 && co == 4) {
+        e = launch_dec_out_wgrad_gemm_f16x3(st, in, d, part, part_b, n, s, ci_pad, &nparts, &nb);
+        if (e == hipSuccess) e = launch_wgrad_reduce(st, part, nparts, ci_pad, 4, 4, ci_real, ci_real, 1.f, gw, fold);
+    } else if (stride == 1) {
         e = launch_conv3x3_wgrad_f16x3(st, in, d, part, part_b, n, s, ci_pad, co, &nparts, &cip, &nb);
         // stride-1 partial tiles are [9][ci][co padded to 32]
         if (e == hipSuccess) e = launch_wgrad_reduce(st, part, nparts, ci_pad, cip, co, ci_real, ci_real, 1.f, gw, fold);

@@ -843,3 +843,195 @@ hipError_t launch_conv3x3_wgrad_f16x3(hipStream_t st, const float* a, const floa
     if (ci == 32 && nco == 4) return launch_wgrad_f16_inst<32, 4>(st, a, d, part, part_b, N, S, nparts, ncop);
     return hipErrorInvalidValue;
 }
+
+// =========================================================================================
+// Weight gradient of the decoder OUTPUT conv (C -> 4, lib/modeling/iodine.py:422) in GEMM form, split-fp16.
+//   dW[co][ci][tap] = sum_q a[q][ci] * g[q - off(tap)][co]        (q = p + off(tap): the shift is moved onto g)
+// is ONE [36 x pixels] . [pixels x C] product per tile with rows j = tap*4 + co (36 of 64 used) instead of nine
+// products with N = 4 padded to 32: 4.5x fewer MFMAs, and the 64-channel operand needs no halo (the 4-channel g does).
+//   A operand (rows j): lane (j, kh) reads its 8 K-consecutive pixels from the fp16 plane of channel co = j & 3 at the
+//     row / column offset of tap = j >> 2 (5 dwords + v_alignbit with a per-lane shift)
+//   B operand (cols ci): transposed fp16 planes of the activation tile, aligned b128 reads
+//   tile = 4 x 16 pixels, K = 16 per MFMA = one tile row; persistent blocks, fixed-order partial tiles [tap][ci][4].
+// =========================================================================================
+template <int C>
+__global__ __launch_bounds__(256, 4)
+void dec_out_wgrad_gemm_f16x3_kernel(const float* __restrict__ a, const float* __restrict__ g, float* __restrict__ part,
+                                     float* __restrict__ part_b, int S, int ntiles, int tiles_x, int tiles_y)
+{
+    constexpr int NTT = C / 32;                          // ci tiles
+    constexpr int KS = 2 / NTT;                          // waves = 2 (j tiles) x NTT x KS
+    constexpr int TH = 4, RW = TH / KS;
+    constexpr int BPL = TH * 8 + 4;                      // dwords per activation channel plane (BPL/4 odd)
+    constexpr int GROW = 12, GPL = (TH + 2) * GROW;      // g planes: 6 halo rows x (18 columns = 9 dwords, padded to 12)
+    constexpr int A4 = C / 4;
+    constexpr int NB_UNITS = TH * 8 * A4, NBU = NB_UNITS / 256;
+    constexpr int NG_UNITS = (TH + 2) * 9;
+    static_assert(NB_UNITS % 256 == 0, "activation tile units");
+
+    __shared__ __attribute__((aligned(16))) unsigned s_b[2 * C * BPL];
+    __shared__ __attribute__((aligned(16))) unsigned s_g[2 * 4 * GPL];
+    __shared__ float s_max[8];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, kh = lane >> 5, li = lane & 31;
+    const int mj = wv & 1, ni = (wv >> 1) % NTT, ks = wv / (2 * NTT);
+    const int j = mj * 32 + li, tap = j >> 2, co = j & 3;
+    const bool j_ok = tap < 9;
+    const int ky = j_ok ? tap / 3 : 1, kx = j_ok ? tap % 3 : 1;
+    const int h0 = 8 * kh + 2 - kx;                      // first half-word (column + 1) of this lane's 8 pixels
+    const unsigned sh = (h0 & 1) * 16;
+    const int g_base = co * GPL + (2 - ky) * GROW + (h0 >> 1);
+    const int ci = ni * 32 + li;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sa = 1.f, sd = 1.f, acc_prod = 1.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int n = t / tiles_y;
+        const float* a_n = a + (size_t)n * S * S * C;
+        const float4* g_n = reinterpret_cast<const float4*>(g) + (size_t)n * S * S;
+
+        float4 rb[NBU][2], rg[2];
+        float ma = 0.f, md = 0.f;
+#pragma unroll
+        for (int k = 0; k < NBU; ++k) {
+            const int u = tid + k * 256;
+            const int c4 = u % A4, tt = u / A4, p = tt % 8, row = tt / 8;
+            const float* src = a_n + ((size_t)(ty * TH + row) * S + tx * 16 + 2 * p) * C + c4 * 4;
+            rb[k][0] = *reinterpret_cast<const float4*>(src);
+            rb[k][1] = *reinterpret_cast<const float4*>(src + C);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                ma = fmaxf(ma, fmaxf(fmaxf(fabsf(rb[k][q].x), fabsf(rb[k][q].y)), fmaxf(fabsf(rb[k][q].z), fabsf(rb[k][q].w))));
+        }
+        rg[0] = rg[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < NG_UNITS) {                              // g halo tile: pixel pairs (columns 2p-1, 2p), one float4 = 4 channels
+            const int p = tid % 9, row = tid / 9;
+            const int gy = ty * TH - 1 + row, gx = tx * 16 - 1 + 2 * p;
+            if (gy >= 0 && gy < S) {
+                if (gx >= 0 && gx < S) rg[0] = g_n[(size_t)gy * S + gx];
+                if (gx + 1 < S) rg[1] = g_n[(size_t)gy * S + gx + 1];
+            }
+            const bool rin = row >= 1 && row <= TH;        // bias gradient: interior pixels only (each pixel once per launch)
+            if (rin && p >= 1) { bsum.x += rg[0].x; bsum.y += rg[0].y; bsum.z += rg[0].z; bsum.w += rg[0].w; }
+            if (rin && p <= 7) { bsum.x += rg[1].x; bsum.y += rg[1].y; bsum.z += rg[1].z; bsum.w += rg[1].w; }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                md = fmaxf(md, fmaxf(fmaxf(fabsf(rg[q].x), fabsf(rg[q].y)), fmaxf(fabsf(rg[q].z), fabsf(rg[q].w))));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ma = fmaxf(ma, __shfl_xor(ma, off, 64));
+            md = fmaxf(md, __shfl_xor(md, off, 64));
+        }
+        if (lane == 0) { s_max[wv] = ma; s_max[4 + wv] = md; }
+        __syncthreads();                                   // every wave is also done with the previous tile's planes
+        ma = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        md = fmaxf(fmaxf(s_max[4], s_max[5]), fmaxf(s_max[6], s_max[7]));
+        sa = tile_scale(ma, sa);
+        sd = tile_scale(md, sd);
+        const float prod = sa * sd;
+        if (prod != acc_prod) {                            // block-uniform; exact (powers of two)
+            const float r = prod / acc_prod;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] *= r;
+            acc_prod = prod;
+        }
+#pragma unroll
+        for (int k = 0; k < NBU; ++k) {
+            const int u = tid + k * 256;
+            const int c4 = u % A4, tt = u / A4, p = tt % 8, row = tt / 8;
+            const int rot = c4 & 3;
+            const float4 q0 = rot4(rb[k][0], rot), q1 = rot4(rb[k][1], rot);
+            const float x0[4] = {q0.x, q0.y, q0.z, q0.w}, x1[4] = {q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned lo;
+                const unsigned hi = pack_hi_lo(x0[e] * sa, x1[e] * sa, lo);
+                const int ch = c4 * 4 + ((e + rot) & 3);
+                s_b[(0 * C + ch) * BPL + row * 8 + p] = hi;
+                s_b[(1 * C + ch) * BPL + row * 8 + p] = lo;
+            }
+        }
+        if (tid < NG_UNITS) {
+            const int p = tid % 9, row = tid / 9;
+            const float x0[4] = {rg[0].x, rg[0].y, rg[0].z, rg[0].w}, x1[4] = {rg[1].x, rg[1].y, rg[1].z, rg[1].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned lo;
+                const unsigned hi = pack_hi_lo(x0[e] * sd, x1[e] * sd, lo);
+                s_g[(0 * 4 + e) * GPL + row * GROW + p] = hi;
+                s_g[(1 * 4 + e) * GPL + row * GROW + p] = lo;
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int r = ks * RW + rr;
+            h16x8 A[2], B[2];
+#pragma unroll
+            for (int term = 0; term < 2; ++term) {
+                const unsigned* pg = s_g + term * 4 * GPL + g_base + r * GROW;
+                const unsigned v0 = pg[0], v1 = pg[1], v2 = pg[2], v3 = pg[3], v4 = pg[4];
+                uint4 m;
+                m.x = __builtin_amdgcn_alignbit(v1, v0, sh);
+                m.y = __builtin_amdgcn_alignbit(v2, v1, sh);
+                m.z = __builtin_amdgcn_alignbit(v3, v2, sh);
+                m.w = __builtin_amdgcn_alignbit(v4, v3, sh);
+                if (!j_ok) m = make_uint4(0u, 0u, 0u, 0u);
+                __builtin_memcpy(&A[term], &m, 16);
+                const uint4 vb = *reinterpret_cast<const uint4*>(s_b + (term * C + ci) * BPL + r * 8 + 4 * kh);
+                __builtin_memcpy(&B[term], &vb, 16);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], B[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[0], acc, 0, 0, 0);
+        }
+    }
+
+    // rows of the accumulator are j = tap*4 + co: registers 4q .. 4q+3 of a lane are the 4 output channels of one tap
+    const float inv = 1.f / acc_prod;
+    float* pw = part + (size_t)(blockIdx.x * KS + ks) * 9 * C * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tp = mj * 8 + 2 * q + kh;
+        if (tp < 9)
+            *reinterpret_cast<float4*>(pw + ((size_t)tp * C + ci) * 4) =
+                make_float4(acc[4 * q] * inv, acc[4 * q + 1] * inv, acc[4 * q + 2] * inv, acc[4 * q + 3] * inv);
+    }
+    __syncthreads();
+    float4* s_red = reinterpret_cast<float4*>(s_b);
+    s_red[tid] = bsum;
+    __syncthreads();
+    if (tid == 0) {
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 256; ++q) { const float4 v = s_red[q]; t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w; }
+        *reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * 4) = t4;
+    }
+}
+
+// part: nparts x [9][c][4], part_b: nbias_parts x [4]
+hipError_t launch_dec_out_wgrad_gemm_f16x3(hipStream_t st, const float* a, const float* g, float* part, float* part_b, int N,
+                                           int S, int c, int* nparts, int* nbias_parts)
+{
+    if (S % 16 != 0 || (c != 64 && c != 32)) return hipErrorInvalidValue;
+    const int tiles_x = S / 16, tiles_y = S / 4, ntiles = N * tiles_x * tiles_y;
+    const int blocks = ntiles < 1024 ? ntiles : 1024;
+    if (c == 64)
+        hipLaunchKernelGGL((dec_out_wgrad_gemm_f16x3_kernel<64>), dim3(blocks), dim3(256), 0, st, a, g, part, part_b, S, ntiles,
+                           tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL((dec_out_wgrad_gemm_f16x3_kernel<32>), dim3(blocks), dim3(256), 0, st, a, g, part, part_b, S, ntiles,
+                           tiles_x, tiles_y);
+    *nparts = blocks * (c == 64 ? 1 : 2);
+    *nbias_parts = blocks;
+    return hipGetLastError();
+}

@@ -144,6 +144,7 @@ def _wgrad_op(x_nhwc, d_nhwc, n, s, ci_pad, ci_real, co, stride):
 
 @pytest.mark.parametrize('cin,cpad,cout,S,N,stride', [
     (64, 64, 64, 32, 3, 1), (32, 32, 32, 16, 5, 1), (64, 64, 64, 128, 1, 1),
+    (64, 64, 4, 32, 3, 1), (32, 32, 4, 16, 5, 1), (64, 64, 4, 128, 2, 1), (32, 32, 4, 64, 3, 1),      # output conv: GEMM form
     (17, 20, 64, 32, 3, 2), (64, 64, 64, 16, 5, 2), (17, 20, 32, 16, 2, 2), (32, 32, 32, 8, 7, 2),
     (64, 64, 64, 128, 1, 2), (32, 32, 32, 4, 3, 2), (17, 20, 64, 128, 2, 2), (64, 64, 64, 64, 9, 2)])
 def test_conv_wgrad_f16x3(cin, cpad, cout, S, N, stride):
