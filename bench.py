@@ -225,7 +225,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, (xc, ec, ref_elbos) = cpu_baseline(args, arch, params, args.mode)
         out['cpu_baseline'] = cb
-        # parity of this very run against the oracle on the CPU sample (gate 1e-3, north_star)
+        # parity of this very run against the oracle on the CPU sample (gate 1e-3, north_star); the timed training
+        # steps moved the weights (Adam), so the initial ones - what the oracle was given - are loaded back first
+        with torch.no_grad():
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
         if args.mode == 'infer':
             model.reconstruct(xc.to(device), ec.to(device))
         else:
