@@ -15,6 +15,28 @@ IOD_DEVINL float elu1(float v) { return v > 0.f ? v : expm1f(v); }
 IOD_DEVINL float elu1_grad_from_out(float a) { return a > 0.f ? 1.f : a + 1.f; }
 IOD_DEVINL float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
+// Phase timing of the tile / weight-gradient kernels (tools/tile_phase_prof.md; build with IODINE_EXTRA_HIPCC_FLAGS=-DIODINE_TILE_PROF): thread 0 of every
+// block accumulates the s_memtime deltas between phase boundaries and writes them to a per-kernel __device__ buffer
+// [block][8]; compiled out of the product library.
+#ifdef IODINE_TILE_PROF
+constexpr int TP_MAXBLK = 16384;
+#define TP_DECL unsigned long long tp_last = __builtin_amdgcn_s_memtime(); unsigned tp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TP_STAMP(slot)                                                                      \
+    do {                                                                                    \
+        const unsigned long long tp_now = __builtin_amdgcn_s_memtime();                     \
+        tp_acc[slot] += (unsigned)(tp_now - tp_last);                                       \
+        tp_last = tp_now;                                                                   \
+    } while (0)
+#define TP_FLUSH(buf)                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < TP_MAXBLK)                                         \
+        for (int i_ = 0; i_ < 8; ++i_) buf[blockIdx.x * 8 + i_] = tp_acc[i_]
+#else
+#define TP_DECL
+#define TP_STAMP(slot)
+#define TP_FLUSH(buf)
+#endif
+
+
 // ---- helpers of the split-fp16 weight-gradient kernels (transposing stagers) ----------
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
@@ -29,15 +51,16 @@ IOD_DEVINL float4 rot4(const float4 v, int r)
     return o;
 }
 
+// (x0, x1) -> packed fp16 pairs hi, lo with x = hi + lo: hi = x truncated to 11 significant bits (mask; exact in fp16 for
+// the scaled range), lo = x - hi (exact in fp32), each pair packed by one v_cvt_pkrtz (same scheme as the tile kernels)
 IOD_DEVINL unsigned pack_hi_lo(float x0, float x1, unsigned& lo_out)
 {
-    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
-    unsigned short uh0, uh1, ul0, ul1;
-    __builtin_memcpy(&uh0, &h0, 2); __builtin_memcpy(&uh1, &h1, 2);
-    __builtin_memcpy(&ul0, &l0, 2); __builtin_memcpy(&ul1, &l1, 2);
-    lo_out = (unsigned)ul0 | ((unsigned)ul1 << 16);
-    return (unsigned)uh0 | ((unsigned)uh1 << 16);
+    typedef __fp16 h2_ __attribute__((ext_vector_type(2)));
+    const float h0 = __uint_as_float(__float_as_uint(x0) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(x1) & 0xffffe000u);
+    const h2_ hi = __builtin_amdgcn_cvt_pkrtz(h0, h1), lo = __builtin_amdgcn_cvt_pkrtz(x0 - h0, x1 - h1);
+    unsigned uh;
+    __builtin_memcpy(&uh, &hi, 4); __builtin_memcpy(&lo_out, &lo, 4);
+    return uh;
 }
 
 // power-of-two scale for a tile with max |x| = mx, keeping the current one while mx*cur stays in [2^9, 2^14.5)

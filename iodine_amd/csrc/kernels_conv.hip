@@ -489,25 +489,8 @@ hipError_t launch_pack_conv_weights_f16(hipStream_t st, const float* src, int O,
 
 IOD_DEVINL float elu1_fast(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
 
-// Phase timing (tools/tile_phase_prof.py; build with IODINE_EXTRA_HIPCC_FLAGS=-DIODINE_TILE_PROF): wave 0 of every block
-// adds the s_memtime deltas between phase boundaries to g_tile_prof[slot]; compiled out of the product library.
 #ifdef IODINE_TILE_PROF
-constexpr int TP_MAXBLK = 16384;
 __device__ unsigned g_tile_prof[TP_MAXBLK * 8];
-#define TP_DECL unsigned long long tp_last = __builtin_amdgcn_s_memtime(); unsigned tp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define TP_STAMP(slot)                                                                      \
-    do {                                                                                    \
-        const unsigned long long tp_now = __builtin_amdgcn_s_memtime();                     \
-        tp_acc[slot] += (unsigned)(tp_now - tp_last);                                       \
-        tp_last = tp_now;                                                                   \
-    } while (0)
-#define TP_FLUSH                                                                            \
-    if (threadIdx.x == 0 && blockIdx.x < TP_MAXBLK)                                         \
-        for (int i_ = 0; i_ < 8; ++i_) g_tile_prof[blockIdx.x * 8 + i_] = tp_acc[i_]
-#else
-#define TP_DECL
-#define TP_STAMP(slot)
-#define TP_FLUSH
 #endif
 
 template <int CIN, int COUT, int EPI>
@@ -767,7 +750,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             }
     }
     TP_STAMP(7);                                             // [7] epilogue (issue of the stores)
-    TP_FLUSH;
+    TP_FLUSH(g_tile_prof);
 }
 
 template <int CIN, int COUT, int EPI>

@@ -10,6 +10,8 @@
 // the refinement network is back-propagated through time afterwards (inputs are detached,
 // iodine.py:343; lambda is detached before the additive update, iodine.py:642-643).
 #include "common.h"
+#include <vector>
+#include <cstdio>
 
 // =========================================================================================
 // stride-1 3x3 weight gradient, LDS-tiled:  dW[tap][ci][co] = sum_{n,p} a[n, p+tap, ci] * d[n, p, co]
@@ -606,6 +608,10 @@ hipError_t launch_pool_bwd(hipStream_t st, const float* dpooled, const float* ac
 //   Range: each tile is scaled by powers of two chosen from its max |a|, max |d| (block-local, with hysteresis);
 //   the accumulators are rescaled exactly when the product of scales changes.
 // =========================================================================================
+#ifdef IODINE_TILE_PROF
+__device__ unsigned g_wgrad_prof[TP_MAXBLK * 8];
+#endif
+
 template <int CI, int NCO>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __restrict__ d, float* __restrict__ part,
@@ -640,6 +646,7 @@ void conv3x3_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __rest
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     float sa = 1.f, sd = 1.f, acc_prod = 1.f;
+    TP_DECL;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int t = tile;
@@ -687,8 +694,10 @@ void conv3x3_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __rest
             ma = fmaxf(ma, __shfl_xor(ma, off, 64));
             md = fmaxf(md, __shfl_xor(md, off, 64));
         }
+        TP_STAMP(0);                                       // [0] tile loads issued, arrived, max
         if (lane == 0) { s_max[wv] = ma; s_max[4 + wv] = md; }
         __syncthreads();                                   // every wave is also done with the previous tile's planes
+        TP_STAMP(1);                                       // [1] barrier 1
         ma = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
         md = fmaxf(fmaxf(s_max[4], s_max[5]), fmaxf(s_max[6], s_max[7]));
         sa = tile_scale(ma, sa);
@@ -740,7 +749,9 @@ void conv3x3_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __rest
                 }
             }
         }
+        TP_STAMP(2);                                       // [2] scale, split, transposed LDS writes
         __syncthreads();
+        TP_STAMP(3);                                       // [3] barrier 2
 
         // ---- MFMA: one K=16 step per tile row; taps = 3 halo rows x 3 register-shifted column variants ----
 #pragma unroll
@@ -786,7 +797,9 @@ void conv3x3_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __rest
                 }
             }
         }
+        TP_STAMP(4);                                       // [4] LDS fragment reads + shifts + 27 MFMAs per tile row
     }
+    TP_FLUSH(g_wgrad_prof);
 
     const float inv = 1.f / acc_prod;
     float* pw = part + ((size_t)(blockIdx.x * KS + ks) * 9) * CI * NCOP;
@@ -827,6 +840,21 @@ static hipError_t launch_wgrad_f16_inst(hipStream_t st, const float* a, const fl
     const int blocks = wgrad_f16_blocks(N, S);
     hipLaunchKernelGGL((conv3x3_wgrad_f16x3_kernel<CI, NCO>), dim3(blocks), dim3(256), lds, st, a, d, part, part_b, S,
                        ntiles, tiles_x, tiles_y);
+#ifdef IODINE_TILE_PROF
+    {
+        std::vector<unsigned> hp((size_t)blocks * 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(g_wgrad_prof), hp.size() * sizeof(unsigned));
+        static const char* names[5] = {"loads+max", "barrier1", "split+transposed-lds-write", "barrier2", "taps(lds-read+shift+mfma)"};
+        double sum[5] = {0}, tot = 0;
+        for (int b2 = 0; b2 < blocks; ++b2) for (int i = 0; i < 5; ++i) sum[i] += hp[(size_t)b2 * 8 + i];
+        const double per = (double)blocks * ((double)ntiles / blocks);
+        for (int i = 0; i < 5; ++i) tot += sum[i] / per;
+        fprintf(stderr, "[wgrad prof <%d,%d>] memtime ticks per TILE (thread 0), total %.0f:", CI, NCO, tot);
+        for (int i = 0; i < 5; ++i) fprintf(stderr, " %s %.0f |", names[i], sum[i] / per);
+        fprintf(stderr, "\n");
+    }
+#endif
     *nparts = blocks * KS;
     *ncop = NTT * 32;
     return hipGetLastError();
