@@ -10,6 +10,7 @@
 // the refinement network is back-propagated through time afterwards (inputs are detached,
 // iodine.py:343; lambda is detached before the additive update, iodine.py:642-643).
 #include "common.h"
+#include <type_traits>
 #include <vector>
 #include <cstdio>
 
@@ -1062,4 +1063,351 @@ hipError_t launch_dec_out_wgrad_gemm_f16x3(hipStream_t st, const float* a, const
     *nparts = blocks * (c == 64 ? 1 : 2);
     *nbias_parts = blocks;
     return hipGetLastError();
+}
+
+// =========================================================================================
+// Warp-specialised form of conv3x3_wgrad_f16x3_kernel (same arithmetic, same partial-tile output).
+// The one-role kernel spends 42 % of a tile waiting for its global loads and 31 % splitting / transposing them into
+// LDS; only 21 % is MFMA (tools/tile_phase_prof.md), and its 144 accumulator registers leave no room to prefetch.
+// Here 512 threads = one block per CU:
+//   waves 0-3  CONSUMERS  hold the 9 x 32x32 accumulators, read fragments from plane buffer (t & 1), 108 MFMAs per tile
+//   waves 4-7  PRODUCERS  tile t+3 in flight (three register sets), tile t+1 split + transposed into buffer ((t+1) & 1),
+//                         max |a|, max |d| of tile t+2 published for the scale choice of the next step
+// One s_barrier per tile.  The tile loop is unrolled by three so that the register sets are named, not indexed.
+// =========================================================================================
+// out-of-image / idle lanes of the producers load from here instead of selecting 0 after the load: a select would make
+// hipcc wait for the load right where it is issued, i.e. un-prefetch it
+__device__ float4 g_zero4[1];
+
+template <int CI, int NCO>
+__global__ __launch_bounds__(512, 2)
+void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __restrict__ d, float* __restrict__ part,
+                                   float* __restrict__ part_b, int S, int ntiles, int tiles_x, int tiles_y)
+{
+    constexpr int MT = CI / 32, NTT = NCO / 32, KS = 4 / (MT * NTT);
+    constexpr int TH = 4, HH = TH + 2;
+    constexpr int APL = 76, DPL = 36;
+    constexpr int A4 = CI / 4, D4 = NCO / 4;
+    constexpr int NA_UNITS = HH * 10 * A4, ND_UNITS = TH * 8 * D4;
+    constexpr int NAU = (NA_UNITS + 255) / 256, NDU = (ND_UNITS + 255) / 256;
+    constexpr int RW = TH / KS;
+    constexpr int BUF_DW = 2 * CI * APL + 2 * NCO * DPL;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned smem_ws[];
+    float* s_max = reinterpret_cast<float*>(smem_ws + 2 * BUF_DW);          // [3][8]
+    float* s_scale = s_max + 24;                                            // [2]: sa * sd of the tile in buffer b
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, kh = lane >> 5, li = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nq = my_tiles;
+
+    if (wv >= 4) {
+        // ------------------------------------------------------------------ PRODUCERS ----
+        const int ptid = tid - 256, pw = wv - 4;
+        float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sa = 1.f, sd = 1.f;
+        struct Set { f32x4 ra[NAU][2]; f32x4 rd[NDU][2]; };     // native vectors: they are inline-asm operands
+#define GLOAD4(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#define VM_WAIT(n) do { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+        // the wait names every register of the set as read-write, so no use of the loaded values can be placed above it
+        auto wait_set = [&](auto nc, Set& r) {
+            constexpr int n = decltype(nc)::value;
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory");
+#pragma unroll
+            for (int k = 0; k < NAU; ++k) { asm volatile("" : "+v"(r.ra[k][0])); asm volatile("" : "+v"(r.ra[k][1])); }
+#pragma unroll
+            for (int k = 0; k < NDU; ++k) { asm volatile("" : "+v"(r.rd[k][0])); asm volatile("" : "+v"(r.rd[k][1])); }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using std::integral_constant;
+        auto G = [&](int q_, Set& r) {
+            const int q = q_ < nq ? q_ : nq - 1;                            // steps past the end re-read the last tile
+            int t = blockIdx.x + q * gridDim.x;
+            const int tx = t % tiles_x; t /= tiles_x;
+            const int ty = t % tiles_y;
+            const int n = t / tiles_y;
+            const float* a_n = a + (size_t)n * S * S * CI;
+            const float* d_n = d + (size_t)n * S * S * NCO;
+#pragma unroll
+            for (int k = 0; k < NAU; ++k) {
+                const int u = ptid + k * 256;
+                const int c4 = u % A4, tt = u / A4, p = tt % 10, row = tt / 10;
+                const int gy = ty * TH - 1 + row, gx = tx * 16 + 2 * p - 2;
+                const bool rok = u < NA_UNITS && gy >= 0 && gy < S;
+                const bool ok0 = rok && gx >= 0 && gx < S, ok1 = rok && gx + 1 >= 0 && gx + 1 < S;
+                const float* src = a_n + ((size_t)gy * S + gx) * CI + c4 * 4;
+                const float* z = reinterpret_cast<const float*>(g_zero4);
+                GLOAD4(r.ra[k][0], ok0 ? src : z);
+                GLOAD4(r.ra[k][1], ok1 ? src + CI : z);
+            }
+#pragma unroll
+            for (int k = 0; k < NDU; ++k) {
+                const int u = ptid + k * 256;
+                const int c4 = u % D4, tt = u / D4, p = tt % 8, row = tt / 8;
+                const bool ok = u < ND_UNITS;
+                const float* src = d_n + ((size_t)(ty * TH + row) * S + tx * 16 + 2 * p) * NCO + c4 * 4;
+                const float* z = reinterpret_cast<const float*>(g_zero4);
+                GLOAD4(r.rd[k][0], ok ? src : z);
+                GLOAD4(r.rd[k][1], ok ? src + NCO : z);
+            }
+        };
+        // The loads are inline asm, so hipcc does not count them: its own vmcnt bookkeeping would drain vmcnt(0) at the
+        // loop header (every third tile) and expose the latency the three register sets are there to hide.  Loads return
+        // in order; a set is (2 NAU + 2 NDU) loads, so "at most n younger sets outstanding" = vmcnt(n * SET_LOADS).
+        constexpr int SET_LOADS = 2 * NAU + 2 * NDU;
+        auto MAXPUB = [&](int q, int slot, const Set& r) {
+            float ma = 0.f, md = 0.f;
+#pragma unroll
+            for (int k = 0; k < NAU; ++k)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    ma = fmaxf(ma, fmaxf(fmaxf(fabsf(r.ra[k][j].x), fabsf(r.ra[k][j].y)), fmaxf(fabsf(r.ra[k][j].z), fabsf(r.ra[k][j].w))));
+            const bool real = q < nq;                                       // block-uniform: the bias sums count each tile once
+#pragma unroll
+            for (int k = 0; k < NDU; ++k)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    md = fmaxf(md, fmaxf(fmaxf(fabsf(r.rd[k][j].x), fabsf(r.rd[k][j].y)), fmaxf(fabsf(r.rd[k][j].z), fabsf(r.rd[k][j].w))));
+                    if (real) { bsum.x += r.rd[k][j].x; bsum.y += r.rd[k][j].y; bsum.z += r.rd[k][j].z; bsum.w += r.rd[k][j].w; }
+                }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                ma = fmaxf(ma, __shfl_xor(ma, off, 64));
+                md = fmaxf(md, __shfl_xor(md, off, 64));
+            }
+            if (lane == 0) { s_max[slot * 8 + pw] = ma; s_max[slot * 8 + 4 + pw] = md; }
+        };
+        auto WIN = [&](int q, int slot, const Set& r) {
+            const float* m = s_max + slot * 8;
+            const float ma = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])), md = fmaxf(fmaxf(m[4], m[5]), fmaxf(m[6], m[7]));
+            sa = tile_scale(ma, sa);
+            sd = tile_scale(md, sd);
+            if (ptid == 0) s_scale[q & 1] = sa * sd;
+            unsigned* s_a = smem_ws + (q & 1) * BUF_DW;
+            unsigned* s_d = s_a + 2 * CI * APL;
+#pragma unroll
+            for (int k = 0; k < NAU; ++k) {
+                const int u = ptid + k * 256;
+                if (u < NA_UNITS) {
+                    const int c4 = u % A4, tt = u / A4, p = tt % 10, row = tt / 10;
+                    const int rot = c4 & 3;
+                    const f32x4 w0 = r.ra[k][0], w1 = r.ra[k][1];
+                    const float4 q0 = rot4(make_float4(w0.x, w0.y, w0.z, w0.w), rot), q1 = rot4(make_float4(w1.x, w1.y, w1.z, w1.w), rot);
+                    const float x0[4] = {q0.x, q0.y, q0.z, q0.w}, x1[4] = {q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        unsigned lo;
+                        const unsigned hi = pack_hi_lo(x0[e] * sa, x1[e] * sa, lo);
+                        const int ch = c4 * 4 + ((e + rot) & 3);
+                        s_a[(0 * CI + ch) * APL + row * 12 + p + 3] = hi;
+                        s_a[(1 * CI + ch) * APL + row * 12 + p + 3] = lo;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NDU; ++k) {
+                const int u = ptid + k * 256;
+                if (u < ND_UNITS) {
+                    const int c4 = u % D4, tt = u / D4, p = tt % 8, row = tt / 8;
+                    const int rot = c4 & 3;
+                    const f32x4 w0 = r.rd[k][0], w1 = r.rd[k][1];
+                    const float4 q0 = rot4(make_float4(w0.x, w0.y, w0.z, w0.w), rot), q1 = rot4(make_float4(w1.x, w1.y, w1.z, w1.w), rot);
+                    const float x0[4] = {q0.x, q0.y, q0.z, q0.w}, x1[4] = {q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        unsigned lo;
+                        const unsigned hi = pack_hi_lo(x0[e] * sd, x1[e] * sd, lo);
+                        const int ch = c4 * 4 + ((e + rot) & 3);
+                        s_d[(0 * NCO + ch) * DPL + row * 8 + p] = hi;
+                        s_d[(1 * NCO + ch) * DPL + row * 8 + p] = lo;
+                    }
+                }
+            }
+        };
+        Set R0, R1, R2;
+        TP_DECL;
+        G(0, R0); G(1, R1); G(2, R2);
+        wait_set(integral_constant<int, 2 * SET_LOADS>{}, R0);
+        MAXPUB(0, 0, R0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                 // lgkmcnt(0): own LDS writes retired
+        __builtin_amdgcn_s_barrier();                                       // P1: max(0) visible
+        WIN(0, 0, R0);
+        wait_set(integral_constant<int, SET_LOADS>{}, R1);
+        MAXPUB(1, 1, R1);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();                                       // P2: tile 0 staged, max(1) visible
+        // iteration q: request tile q+3, stage tile q+1, publish max(q+2)
+        auto iteration = [&](int q, int sl, Set& Rnext, Set& Rmax, Set& Rload) {
+            TP_STAMP(7);
+            G(q + 3, Rload);
+            TP_STAMP(2);                                                    // [2] producer: issue of the tile loads
+            wait_set(integral_constant<int, 2 * SET_LOADS>{}, Rnext);        // (tile q+1 arrived during the previous step)
+            WIN(q + 1, (sl + 1) % 3, Rnext);
+            TP_STAMP(3);                                                    // [3] producer: split + transposed LDS writes
+            wait_set(integral_constant<int, SET_LOADS>{}, Rmax);             // tile q+2: requested two steps ago
+            MAXPUB(q + 2, (sl + 2) % 3, Rmax);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            TP_STAMP(4);                                                    // [4] producer: wait for tile q+2, max
+            __builtin_amdgcn_s_barrier();
+            TP_STAMP(5);                                                    // [5] producer: barrier wait
+        };
+        for (int q = 0; q < nq; q += 3) {
+            iteration(q, 0, R1, R2, R0);
+            if (q + 1 < nq) iteration(q + 1, 1, R2, R0, R1);
+            if (q + 2 < nq) iteration(q + 2, 2, R0, R1, R2);
+        }
+#ifdef IODINE_TILE_PROF
+        if (ptid == 0 && blockIdx.x < TP_MAXBLK) for (int i_ = 2; i_ < 8; ++i_) g_wgrad_prof[blockIdx.x * 8 + i_] = tp_acc[i_];
+#endif
+        VM_WAIT(0);
+#undef GLOAD4
+#undef VM_WAIT
+        __builtin_amdgcn_s_barrier();                                       // F1: consumers are done with the planes
+        reinterpret_cast<float4*>(smem_ws)[ptid] = bsum;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();                                       // F2
+        return;
+    }
+
+    // ---------------------------------------------------------------------- CONSUMERS ----
+    const int mi = wv % MT, ni = (wv / MT) % NTT, ks = wv / (MT * NTT);
+    const int ci = mi * 32 + li, co = ni * 32 + li;
+    const bool co_ok = NCO >= 32 || li < NCO;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float acc_prod = 1.f;
+    __builtin_amdgcn_s_barrier();                                           // P1
+    __builtin_amdgcn_s_barrier();                                           // P2
+    TP_DECL;
+    for (int q = 0; q < nq; ++q) {
+        const unsigned* s_a = smem_ws + (q & 1) * BUF_DW;
+        const unsigned* s_d = s_a + 2 * CI * APL;
+        const float prod = s_scale[q & 1];
+        if (prod != acc_prod) {                                             // block-uniform; exact (powers of two)
+            const float r = prod / acc_prod;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[tp][e] *= r;
+            acc_prod = prod;
+        }
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int r = ks * RW + rr;
+            h16x8 bh, bl;
+            {
+                uint4 vb_h = make_uint4(0, 0, 0, 0), vb_l = make_uint4(0, 0, 0, 0);
+                if (co_ok) {
+                    vb_h = *reinterpret_cast<const uint4*>(s_d + (0 * NCO + co) * DPL + r * 8 + 4 * kh);
+                    vb_l = *reinterpret_cast<const uint4*>(s_d + (1 * NCO + co) * DPL + r * 8 + 4 * kh);
+                }
+                __builtin_memcpy(&bh, &vb_h, 16); __builtin_memcpy(&bl, &vb_l, 16);
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                h16x8 A[2][3];
+#pragma unroll
+                for (int term = 0; term < 2; ++term) {
+                    const unsigned* pl = s_a + (term * CI + ci) * APL + (r + dy) * 12;
+                    const uint4 v = *reinterpret_cast<const uint4*>(pl + 4 + 4 * kh);
+                    const unsigned prev = pl[3 + 4 * kh] & 0xffff0000u;
+                    const unsigned next = pl[8 + 4 * kh] & 0x0000ffffu;
+                    uint4 m1, p1;
+                    m1.x = __builtin_amdgcn_alignbit(v.x, prev, 16);
+                    m1.y = __builtin_amdgcn_alignbit(v.y, v.x, 16);
+                    m1.z = __builtin_amdgcn_alignbit(v.z, v.y, 16);
+                    m1.w = __builtin_amdgcn_alignbit(v.w, v.z, 16);
+                    p1.x = __builtin_amdgcn_alignbit(v.y, v.x, 16);
+                    p1.y = __builtin_amdgcn_alignbit(v.z, v.y, 16);
+                    p1.z = __builtin_amdgcn_alignbit(v.w, v.z, 16);
+                    p1.w = __builtin_amdgcn_alignbit(next, v.w, 16);
+                    __builtin_memcpy(&A[term][0], &m1, 16);
+                    __builtin_memcpy(&A[term][1], &v, 16);
+                    __builtin_memcpy(&A[term][2], &p1, 16);
+                }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int tap = dy * 3 + dx;
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][dx], bh, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][dx], bl, acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][dx], bh, acc[tap], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        TP_STAMP(0);                                                        // [0] consumer: fragment reads + MFMAs of a tile
+        __builtin_amdgcn_s_barrier();
+        TP_STAMP(1);                                                        // [1] consumer: barrier wait
+    }
+#ifdef IODINE_TILE_PROF
+    if (tid == 0 && blockIdx.x < TP_MAXBLK) for (int i_ = 0; i_ < 2; ++i_) g_wgrad_prof[blockIdx.x * 8 + i_] = tp_acc[i_];
+#endif
+    constexpr int NCOP = NTT * 32;
+    const float inv = 1.f / acc_prod;
+    float* pw = part + ((size_t)(blockIdx.x * KS + ks) * 9) * CI * NCOP;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            pw[((size_t)tap * CI + cr) * NCOP + ni * 32 + li] = nq > 0 ? acc[tap][r] * inv : 0.f;
+        }
+    __builtin_amdgcn_s_barrier();                                           // F1
+    __builtin_amdgcn_s_barrier();                                           // F2: producers' bias sums are in LDS
+    if (tid < D4) {
+        const float4* s_red = reinterpret_cast<const float4*>(smem_ws);
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = tid; j < 256; j += D4) { const float4 v = s_red[j]; t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w; }
+        *reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * NCO + tid * 4) = t4;
+    }
+}
+
+template <int CI, int NCO>
+static hipError_t launch_wgrad_f16_ws_inst(hipStream_t st, const float* a, const float* d, float* part, float* part_b,
+                                           int N, int S, int* nparts, int* ncop, int* nbias)
+{
+    constexpr int MT = CI / 32, NTT = NCO / 32, KS = 4 / (MT * NTT);
+    constexpr size_t lds = (size_t)2 * (2 * CI * 76 + 2 * NCO * 36) * 4 + 26 * 4 + 32;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_f16x3_ws_kernel<CI, NCO>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles_x = S / 16, tiles_y = S / 4, ntiles = N * tiles_x * tiles_y;
+    const int blocks = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL((conv3x3_wgrad_f16x3_ws_kernel<CI, NCO>), dim3(blocks), dim3(512), lds, st, a, d, part, part_b, S,
+                       ntiles, tiles_x, tiles_y);
+#ifdef IODINE_TILE_PROF
+    {
+        std::vector<unsigned> hp((size_t)blocks * 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(g_wgrad_prof), hp.size() * sizeof(unsigned));
+        static const char* names[8] = {"C:mfma-phase", "C:barrier", "P:load-issue", "P:split+lds-write", "P:load-wait+max", "P:barrier", "-", "P:loop-edge"};
+        double sum[8] = {0};
+        for (int b2 = 0; b2 < blocks; ++b2) for (int i = 0; i < 8; ++i) sum[i] += hp[(size_t)b2 * 8 + i];
+        fprintf(stderr, "[wgrad ws prof <%d,%d>] memtime ticks per TILE:", CI, NCO);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f |", names[i], sum[i] / (double)ntiles);
+        fprintf(stderr, "\n");
+    }
+#endif
+    *nparts = blocks * KS;
+    *ncop = NTT * 32;
+    *nbias = blocks;
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_wgrad_f16x3_ws(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
+                                         int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts)
+{
+    if (S % 16 != 0) return hipErrorInvalidValue;
+    if (ci == 64 && nco == 64) return launch_wgrad_f16_ws_inst<64, 64>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts);
+    if (ci == 32 && nco == 32) return launch_wgrad_f16_ws_inst<32, 32>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts);
+    return hipErrorInvalidValue;
 }
