@@ -1122,35 +1122,61 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
             __builtin_amdgcn_sched_barrier(0);
         };
         using std::integral_constant;
+        // Tile loads are raw BUFFER loads: one descriptor per (tensor, slot-image) with num_records = one image, so rows
+        // above / below the image are out of range and return 0 in hardware; only the two halo columns left / right of
+        // the image need an explicit invalid offset.  Per load: one v_add (tile offset + the thread's constant unit
+        // offset) and, for the edge columns, one v_cndmask - instead of ~15 VALU of 64-bit address arithmetic each.
+        typedef int i32x4_ __attribute__((ext_vector_type(4)));
+        auto make_rsrc = [&](const float* base, unsigned bytes) {
+            const unsigned long long p = (unsigned long long)base;
+            i32x4_ r;
+            r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+            r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));          // stride 0, no swizzle
+            r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+            r.w = 0x00020000;                                                         // raw dword buffer (gfx9 / CDNA)
+            return r;
+        };
+#define BLOAD4(dst, voff, rsrc, imm) \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(dst) : "v"(voff), "s"(rsrc), "n"(imm) : "memory")
+        unsigned aoff[NAU], doff[NDU];                     // the thread's constant byte offsets inside a tile (pixel j = 0)
+        bool a_left[NAU], a_right[NAU];
+#pragma unroll
+        for (int k = 0; k < NAU; ++k) {
+            const int u = ptid + k * 256;
+            const int c4 = u % A4, tt = u / A4, p = tt % 10, row = tt / 10;
+            aoff[k] = u < NA_UNITS ? (unsigned)(((row * S + 2 * p) * CI + c4 * 4) * 4) : 0x80000000u;
+            a_left[k] = p == 0; a_right[k] = p == 9;
+        }
+#pragma unroll
+        for (int k = 0; k < NDU; ++k) {
+            const int u = ptid + k * 256;
+            const int c4 = u % D4, tt = u / D4, p = tt % 8, row = tt / 8;
+            doff[k] = u < ND_UNITS ? (unsigned)(((row * S + 2 * p) * NCO + c4 * 4) * 4) : 0x80000000u;
+        }
         auto G = [&](int q_, Set& r) {
             const int q = q_ < nq ? q_ : nq - 1;                            // steps past the end re-read the last tile
             int t = blockIdx.x + q * gridDim.x;
             const int tx = t % tiles_x; t /= tiles_x;
             const int ty = t % tiles_y;
             const int n = t / tiles_y;
-            const float* a_n = a + (size_t)n * S * S * CI;
-            const float* d_n = d + (size_t)n * S * S * NCO;
+            const i32x4_ ra_rsrc = make_rsrc(a + (size_t)n * S * S * CI, (unsigned)(S * S * CI * 4));
+            const i32x4_ rd_rsrc = make_rsrc(d + (size_t)n * S * S * NCO, (unsigned)(S * S * NCO * 4));
+            // first halo pixel of the tile is (ty*TH - 1, tx*16 - 2); negative offsets wrap above num_records -> 0
+            const unsigned a_tile = (unsigned)(((ty * TH - 1) * S + tx * 16 - 2) * CI * 4);
+            const unsigned d_tile = (unsigned)(((ty * TH) * S + tx * 16) * NCO * 4);
+            const bool at_left = tx == 0, at_right = tx == tiles_x - 1;     // block-uniform
 #pragma unroll
             for (int k = 0; k < NAU; ++k) {
-                const int u = ptid + k * 256;
-                const int c4 = u % A4, tt = u / A4, p = tt % 10, row = tt / 10;
-                const int gy = ty * TH - 1 + row, gx = tx * 16 + 2 * p - 2;
-                const bool rok = u < NA_UNITS && gy >= 0 && gy < S;
-                const bool ok0 = rok && gx >= 0 && gx < S, ok1 = rok && gx + 1 >= 0 && gx + 1 < S;
-                const float* src = a_n + ((size_t)gy * S + gx) * CI + c4 * 4;
-                const float* z = reinterpret_cast<const float*>(g_zero4);
-                GLOAD4(r.ra[k][0], ok0 ? src : z);
-                GLOAD4(r.ra[k][1], ok1 ? src + CI : z);
+                const bool bad = (a_left[k] && at_left) || (a_right[k] && at_right);
+                const unsigned vo = bad ? 0x80000000u : aoff[k] + a_tile;   // both pixels of an edge unit are outside
+                BLOAD4(r.ra[k][0], vo, ra_rsrc, 0);
+                BLOAD4(r.ra[k][1], vo, ra_rsrc, CI * 4);
             }
 #pragma unroll
             for (int k = 0; k < NDU; ++k) {
-                const int u = ptid + k * 256;
-                const int c4 = u % D4, tt = u / D4, p = tt % 8, row = tt / 8;
-                const bool ok = u < ND_UNITS;
-                const float* src = d_n + ((size_t)(ty * TH + row) * S + tx * 16 + 2 * p) * NCO + c4 * 4;
-                const float* z = reinterpret_cast<const float*>(g_zero4);
-                GLOAD4(r.rd[k][0], ok ? src : z);
-                GLOAD4(r.rd[k][1], ok ? src + NCO : z);
+                const unsigned vo = doff[k] + d_tile;
+                BLOAD4(r.rd[k][0], vo, rd_rsrc, 0);
+                BLOAD4(r.rd[k][1], vo, rd_rsrc, NCO * 4);
             }
         };
         // The loads are inline asm, so hipcc does not count them: its own vmcnt bookkeeping would drain vmcnt(0) at the
@@ -1264,6 +1290,7 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
         VM_WAIT(0);
 #undef GLOAD4
 #undef VM_WAIT
+#undef BLOAD4
         __builtin_amdgcn_s_barrier();                                       // F1: consumers are done with the planes
         reinterpret_cast<float4*>(smem_ws)[ptid] = bsum;
         __builtin_amdgcn_s_waitcnt(0xc07f);
