@@ -1153,12 +1153,32 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
             const int c4 = u % D4, tt = u / D4, p = tt % 8, row = tt / 8;
             doff[k] = u < ND_UNITS ? (unsigned)(((row * S + 2 * p) * NCO + c4 * 4) * 4) : 0x80000000u;
         }
-        auto G = [&](int q_, Set& r) {
-            const int q = q_ < nq ? q_ : nq - 1;                            // steps past the end re-read the last tile
-            int t = blockIdx.x + q * gridDim.x;
-            const int tx = t % tiles_x; t /= tiles_x;
-            const int ty = t % tiles_y;
-            const int n = t / tiles_y;
+        // tile coordinates of the load stream advance by gridDim.x per step: carried additions instead of two integer
+        // divisions per tile (those were ~1 k ticks of a 6 k-tick step)
+        int ltx, lty, ln, lq = 0;
+        {
+            int t = blockIdx.x;
+            ltx = t % tiles_x; t /= tiles_x;
+            lty = t % tiles_y; ln = t / tiles_y;
+        }
+        int gsx, gsy, gsn;
+        {
+            int t = gridDim.x;
+            gsx = t % tiles_x; t /= tiles_x;
+            gsy = t % tiles_y; gsn = t / tiles_y;
+        }
+        auto G = [&](int, Set& r) {                                         // called for steps 0, 1, 2, ... in order
+            const int tx = ltx, ty = lty, n = ln;
+            if (lq + 1 < nq) {                                              // steps past the end re-read the last tile
+                ltx += gsx;
+                const int cx = ltx >= tiles_x ? 1 : 0;
+                ltx -= cx ? tiles_x : 0;
+                lty += gsy + cx;
+                const int cy = lty >= tiles_y ? 1 : 0;
+                lty -= cy ? tiles_y : 0;
+                ln += gsn + cy;
+            }
+            ++lq;
             const i32x4_ ra_rsrc = make_rsrc(a + (size_t)n * S * S * CI, (unsigned)(S * S * CI * 4));
             const i32x4_ rd_rsrc = make_rsrc(d + (size_t)n * S * S * NCO, (unsigned)(S * S * NCO * 4));
             // first halo pixel of the tile is (ty*TH - 1, tx*16 - 2); negative offsets wrap above num_records -> 0
