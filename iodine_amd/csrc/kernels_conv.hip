@@ -514,6 +514,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     float* s_max = reinterpret_cast<float*>(smem_b + IN_BYTES + W_U4 * 16);
 
     TP_DECL;
+    using std::integral_constant;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, kh = lane >> 5, li = lane & 31;
     const int prow = li >> 4, pcol = li & 15;
@@ -523,16 +524,39 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     const int ty = bid % tiles;
     const int n = bid / tiles;
 
-    // element offsets of this thread's halo float4s (32-bit: tensors are < 2^31 floats); -1 = outside the image / idle
-    int goff[NIN];
+    // Global traffic goes through RAW BUFFER loads issued as inline asm:
+    //   * one descriptor per tensor (input: this block's slot-image, num_records = one image; packed weights), byte
+    //     offsets in a VGPR, the chunk offset in the scalar offset operand -> no 64-bit address arithmetic per load;
+    //   * halo pixels outside the image and idle lanes carry the offset 0x80000000 (>= num_records): the hardware returns
+    //     0, there is no select after the load;
+    //   * hipcc does not count asm loads, so the waits below are explicit counted vmcnt (loads return in order).
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    auto make_rsrc = [&](const void* base, unsigned bytes) {
+        const unsigned long long p = (unsigned long long)base;
+        i32x4_ r;
+        r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+        r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));          // stride 0, no swizzle
+        r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+        r.w = 0x00020000;                                                         // raw dword buffer (gfx9 / CDNA)
+        return r;
+    };
+    const i32x4_ rsrc_in = make_rsrc(in + (size_t)n * S * S * CIN, (unsigned)(S * S * CIN * 4));
+    const i32x4_ rsrc_w = make_rsrc(wpk, (unsigned)(NCHUNK * W_U4 * 16));
+#define IOD_BLOAD4(dst, voff, rsrc, soff) \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory")
+    unsigned goff[NIN];                                  // byte offsets of this thread's halo float4s inside the slot-image
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
         const int idx = tid + k * 256;
         const int px = idx >> 2, cq = idx & 3;
         const int gy = ty * 16 - 1 + px / HALO, gx = tx * 16 - 1 + px % HALO;
         const bool ok = idx < NPX * 4 && gy >= 0 && gy < S && gx >= 0 && gx < S;
-        goff[k] = ok ? ((n * S + gy) * S + gx) * CIN + cq * 4 : -1;
+        goff[k] = ok ? (unsigned)(((gy * S + gx) * CIN + cq * 4) * 4) : 0x80000000u;
     }
+    unsigned woff[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) woff[k] = tid + k * 256 < W_U4 ? (unsigned)((tid + k * 256) * 16) : 0x80000000u;
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -545,34 +569,38 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     // The chunk loop is fully unrolled (straight-line code keeps hipcc's vmcnt waits COUNTED: a loop back-edge makes it
     // drain vmcnt(0), i.e. wait for the prefetch it has just issued).  Input chunks are fetched two steps ahead into two
     // alternating register sets, the (L2-resident) packed weights one step ahead.
-    float4 rinA[NIN], rinB[NIN];
-    uint4 rw[NW];
-    auto prefetch_in = [&](int chunk, float4 (&rin)[NIN]) {
-        const float* base = in + chunk * 16;
+    f32x4 rinA[NIN], rinB[NIN];                          // native vectors: they are inline-asm operands
+    u32x4_ rw[NW];
+    auto prefetch_in = [&](int chunk, f32x4 (&rin)[NIN]) {
+        const int soff = chunk * 64;                         // 16 channels
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) {
-            const bool ok = goff[k] >= 0;
-            const float4 v = *reinterpret_cast<const float4*>(base + (ok ? goff[k] : 0));
-            rin[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int k = 0; k < NIN; ++k) IOD_BLOAD4(rin[k], goff[k], rsrc_in, soff);
     };
     auto prefetch_w = [&](int chunk) {
-        const uint4* wsrc = wpk + (size_t)chunk * W_U4;
+        const int soff = chunk * (W_U4 * 16);
 #pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const int idx = tid + k * 256;
-            rw[k] = idx < W_U4 ? wsrc[idx] : make_uint4(0u, 0u, 0u, 0u);    // (a clamped index here sends rw to scratch)
-        }
+        for (int k = 0; k < NW; ++k) IOD_BLOAD4(rw[k], woff[k], rsrc_w, soff);
+    };
+    // wait until at most `nc` younger loads are outstanding; the registers are named as read-write operands so that no
+    // use of the loaded values can be scheduled above the wait
+    auto vm_wait = [&](auto nc, f32x4 (&rin)[NIN]) {
+        constexpr int nleft = decltype(nc)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(nleft) : "memory");
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) asm volatile("" : "+v"(rin[k]));
+#pragma unroll
+        for (int k = 0; k < NW; ++k) asm volatile("" : "+v"(rw[k]));
+        __builtin_amdgcn_sched_barrier(0);
     };
     // Block-local dynamic range: before a chunk is split into fp16 (hi, lo) it is multiplied by a power of two
     // chosen from the chunk tile's max |x| (so that small-magnitude tensors such as gradients keep their lo parts
     // out of the fp16 subnormal range); the accumulators are rescaled (exactly) when the scale changes.
     float cur_scale = 1.f;
-    auto commit = [&](const float4 (&rin)[NIN]) -> float {
+    auto commit = [&](const f32x4 (&rin)[NIN]) -> float {
         float m = 0.f;
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
-            const float4 v = rin[k];
+            const f32x4 v = rin[k];
             m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         }
 #pragma unroll
@@ -590,7 +618,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         for (int k = 0; k < NIN; ++k) {
             const int idx = tid + k * 256;
             const int px = idx < NPX * 4 ? idx >> 2 : NPX, cq = idx & 3;          // idle lanes write the dump slot
-            float4 v = rin[k];
+            f32x4 v = rin[k];
             v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
             // hi = v truncated to fp16 precision (mask the 13 low mantissa bits: exact in fp16 for the scaled range),
             // lo = v - hi (exact in fp32); both packed with v_cvt_pkrtz (two values per instruction)
@@ -608,7 +636,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
             const int idx = tid + k * 256;
-            if (idx < W_U4) s_w[idx] = rw[k];
+            if (idx < W_U4) s_w[idx] = make_uint4(rw[k].x, rw[k].y, rw[k].z, rw[k].w);
         }
         TP_STAMP(3);                                         // [3] scale, split, LDS writes
         __syncthreads();
@@ -670,7 +698,6 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[nt], f.ah[mt], acc[mt][nt], 0, 0, 0);
     };
-    using std::integral_constant;
 #define IOD_STEP(T, FCUR, FNEXT)                                                                  \
     if constexpr (T + 1 < 9) LOADF(integral_constant<int, (T + 1 < 9 ? T + 1 : 8)>{}, FNEXT);       \
     if constexpr (T + 1 < 9) { if (NT == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      \
@@ -692,27 +719,32 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     prefetch_in(0, rinA);
     prefetch_w(0);
     if (NCHUNK > 1) prefetch_in(1, rinB);
-    cur_scale = commit(rinA);                                // chunk 0 staged (waits for rinA + rw only)
+    vm_wait(integral_constant<int, (NCHUNK > 1 ? NIN : 0)>{}, rinA);      // chunk 0 + weights 0 arrived (chunk 1 may be in flight)
+    cur_scale = commit(rinA);                                // chunk 0 staged
     if (NCHUNK > 1) prefetch_w(1);
     if (NCHUNK > 2) prefetch_in(2, rinA);
     compute();                                               // chunk 0
     if constexpr (NCHUNK > 1) {
+        vm_wait(integral_constant<int, (NCHUNK > 2 ? NIN : 0)>{}, rinB);
         rescale(commit(rinB));                               // chunk 1 staged
         if (NCHUNK > 2) prefetch_w(2);
         if (NCHUNK > 3) prefetch_in(3, rinB);
         compute();                                           // chunk 1
     }
     if constexpr (NCHUNK > 2) {
+        vm_wait(integral_constant<int, (NCHUNK > 3 ? NIN : 0)>{}, rinA);
         rescale(commit(rinA));
         if (NCHUNK > 3) prefetch_w(3);
         compute();                                           // chunk 2
     }
     if constexpr (NCHUNK > 3) {
+        vm_wait(integral_constant<int, 0>{}, rinB);
         rescale(commit(rinB));
         compute();                                           // chunk 3
     }
     static_assert(NCHUNK <= 4, "chunk schedule is unrolled for at most 64 input channels");
 #undef IOD_STEP
+#undef IOD_BLOAD4
 
     const float inv_ws = wmeta[1] / cur_scale;
     // The MFMAs are issued as (weights, activations): D = W^T A^T, so a lane's accumulator rows are CHANNELS - lane
