@@ -543,8 +543,12 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     };
     const i32x4_ rsrc_in = make_rsrc(in + (size_t)n * S * S * CIN, (unsigned)(S * S * CIN * 4));
     const i32x4_ rsrc_w = make_rsrc(wpk, (unsigned)(NCHUNK * W_U4 * 16));
+// (IOD_SGPR_SETTLE before a group of asm memory instructions: an SGPR written by the SALU needs 5 wait states before a
+//  VMEM instruction reads it, and hipcc's hazard recognizer does not look inside inline asm; naming the SGPR operands as
+//  inputs of the s_nop puts their producers in front of it)
 #define IOD_BLOAD4(dst, voff, rsrc, soff) \
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory")
+#define IOD_SGPR_SETTLE(rsrc, soff) asm volatile("s_nop 4" :: "s"(rsrc), "s"(soff) : "memory")
     unsigned goff[NIN];                                  // byte offsets of this thread's halo float4s inside the slot-image
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
@@ -573,11 +577,13 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     u32x4_ rw[NW];
     auto prefetch_in = [&](int chunk, f32x4 (&rin)[NIN]) {
         const int soff = chunk * 64;                         // 16 channels
+        IOD_SGPR_SETTLE(rsrc_in, soff);
 #pragma unroll
         for (int k = 0; k < NIN; ++k) IOD_BLOAD4(rin[k], goff[k], rsrc_in, soff);
     };
     auto prefetch_w = [&](int chunk) {
         const int soff = chunk * (W_U4 * 16);
+        IOD_SGPR_SETTLE(rsrc_w, soff);
 #pragma unroll
         for (int k = 0; k < NW; ++k) IOD_BLOAD4(rw[k], woff[k], rsrc_w, soff);
     };
@@ -744,45 +750,88 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     }
     static_assert(NCHUNK <= 4, "chunk schedule is unrolled for at most 64 input channels");
 #undef IOD_STEP
-#undef IOD_BLOAD4
 
     const float inv_ws = wmeta[1] / cur_scale;
     // The MFMAs are issued as (weights, activations): D = W^T A^T, so a lane's accumulator rows are CHANNELS - lane
     // (li, kh) holds pixel li of the 32-pixel tile and channels 8g + 4kh .. +3 in registers 4g .. 4g+3: the epilogue
-    // moves float4s of 4 consecutive channels (16 instead of 64 memory instructions per thread).
+    // moves float4s of 4 consecutive channels.  Stores (and the ELU' operand of the data-gradient form) are raw buffer
+    // operations on the slot-image: one byte offset per 32-pixel tile and lane, channel group in the scalar offset.
+    if constexpr (EPI == EPI_OUT4) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int gy = ty * 16 + 4 * wv + 2 * mt + (li >> 4);
-        const int gx = tx * 16 + (li & 15);
-        const int pix = (n * S + gy) * S + gx;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int c0 = nt * 32 + 8 * g4 + 4 * kh;
-                float4 v = make_float4(acc[mt][nt][4 * g4] * inv_ws, acc[mt][nt][4 * g4 + 1] * inv_ws,
-                                       acc[mt][nt][4 * g4 + 2] * inv_ws, acc[mt][nt][4 * g4 + 3] * inv_ws);
-                if (EPI == EPI_OUT4) {                   // decoder output conv: 4 real channels, out is [N][P][4]
-                    if (c0 == 0) {
-                        const float4 bv = *reinterpret_cast<const float4*>(bias);
-                        *reinterpret_cast<float4*>(out + (size_t)pix * 4) = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
-                    }
-                    continue;
-                }
-                const size_t o = (size_t)pix * COUT + c0;
-                if (EPI == EPI_BIAS_ELU) {
-                    const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
-                    v = make_float4(elu1_fast(v.x + bv.x), elu1_fast(v.y + bv.y), elu1_fast(v.z + bv.z), elu1_fast(v.w + bv.w));
-                } else if (EPI == EPI_MUL_ELUGRAD) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(aux + o);
-                    v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
-                    v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
-                }
-                *reinterpret_cast<float4*>(out + o) = v;
+        for (int mt = 0; mt < 2; ++mt) {
+            const int gy = ty * 16 + 4 * wv + 2 * mt + (li >> 4), gx = tx * 16 + (li & 15);
+            if (kh == 0) {                               // decoder output conv: 4 real channels = registers 0..3 of nt 0
+                const float4 bv = *reinterpret_cast<const float4*>(bias);
+                *reinterpret_cast<float4*>(out + (size_t)((n * S + gy) * S + gx) * 4) =
+                    make_float4(acc[mt][0][0] * inv_ws + bv.x, acc[mt][0][1] * inv_ws + bv.y, acc[mt][0][2] * inv_ws + bv.z,
+                                acc[mt][0][3] * inv_ws + bv.w);
             }
+        }
+    } else {
+        const i32x4_ rsrc_out = make_rsrc(out + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
+        unsigned voff[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int gy = ty * 16 + 4 * wv + 2 * mt + (li >> 4), gx = tx * 16 + (li & 15);
+            voff[mt] = (unsigned)(((gy * S + gx) * COUT + 4 * kh) * 4);
+        }
+        f32x4 bv[NT][4], ax[2][NT][4];
+        if constexpr (EPI == EPI_BIAS_ELU) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 t = *reinterpret_cast<const float4*>(bias + nt * 32 + 8 * g4 + 4 * kh);
+                    bv[nt][g4] = f32x4{t.x, t.y, t.z, t.w};
+                }
+        }
+        if constexpr (EPI == EPI_MUL_ELUGRAD) {
+            const i32x4_ rsrc_aux = make_rsrc(aux + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int soff = (nt * 32 + 8 * g4) * 4;
+                        IOD_SGPR_SETTLE(rsrc_aux, soff);
+                        IOD_BLOAD4(ax[mt][nt][g4], voff[mt], rsrc_aux, soff);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(ax[mt][nt][g4]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 v = f32x4{acc[mt][nt][4 * g4] * inv_ws, acc[mt][nt][4 * g4 + 1] * inv_ws,
+                                    acc[mt][nt][4 * g4 + 2] * inv_ws, acc[mt][nt][4 * g4 + 3] * inv_ws};
+                    if constexpr (EPI == EPI_BIAS_ELU) {
+                        const f32x4 b4 = bv[nt][g4];
+                        v = f32x4{elu1_fast(v.x + b4.x), elu1_fast(v.y + b4.y), elu1_fast(v.z + b4.z), elu1_fast(v.w + b4.w)};
+                    } else if constexpr (EPI == EPI_MUL_ELUGRAD) {
+                        const f32x4 a4 = ax[mt][nt][g4];
+                        v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
+                        v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
+                    }
+                    const int soff = (nt * 32 + 8 * g4) * 4;
+                    // (the s_nop covers the ">64-bit store data, then VALU write of those VGPRs" hazard that hipcc's
+                    // hazard recognizer would handle for its own stores but cannot see inside inline asm)
+                    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v), "v"(voff[mt]), "s"(rsrc_out), "s"(soff) : "memory");
+                }
     }
     TP_STAMP(7);                                             // [7] epilogue (issue of the stores)
     TP_FLUSH(g_tile_prof);
+#undef IOD_BLOAD4
+#undef IOD_SGPR_SETTLE
 }
 
 template <int CIN, int COUT, int EPI>

@@ -1185,6 +1185,9 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
             const unsigned a_tile = (unsigned)(((ty * TH - 1) * S + tx * 16 - 2) * CI * 4);
             const unsigned d_tile = (unsigned)(((ty * TH) * S + tx * 16) * NCO * 4);
             const bool at_left = tx == 0, at_right = tx == tiles_x - 1;     // block-uniform
+            // SGPRs written by the SALU need 5 wait states before a VMEM instruction reads them; hipcc's hazard recognizer
+            // does not look inside inline asm
+            asm volatile("s_nop 4" :: "s"(ra_rsrc), "s"(rd_rsrc) : "memory");
 #pragma unroll
             for (int k = 0; k < NAU; ++k) {
                 const bool bad = (a_left[k] && at_left) || (a_right[k] && at_right);
