@@ -784,6 +784,12 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
                     const float4 t = *reinterpret_cast<const float4*>(bias + nt * 32 + 8 * g4 + 4 * kh);
                     bv[nt][g4] = f32x4{t.x, t.y, t.z, t.w};
                 }
+            // pin the bias values in registers HERE: a compiler-generated vmcnt wait for one of these loads placed between
+            // the asm stores below would also wait for every store issued before it (stores count in vmcnt on gfx9)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(bv[nt][g4]));
         }
         if constexpr (EPI == EPI_MUL_ELUGRAD) {
             const i32x4_ rsrc_aux = make_rsrc(aux + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
