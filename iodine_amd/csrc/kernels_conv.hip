@@ -721,6 +721,31 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         IOD_STEP(5, f1, f0) IOD_STEP(6, f0, f1) IOD_STEP(7, f1, f0) IOD_STEP(8, f0, f1)
         TP_STAMP(6);                                         // [6] 9 taps of LDS fragment reads + MFMA
     };
+    // data-gradient form: the ELU' operand (the saved activation of the layer below, one float4 per accumulator quad) is
+    // requested right after the LAST chunk has been staged - its input / weight registers are free by then - and arrives
+    // under the last 108 MFMAs instead of being waited for in the epilogue
+    f32x4 ax[2][NT][4];
+    unsigned voff[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int gy = ty * 16 + 4 * wv + 2 * mt + (li >> 4), gx = tx * 16 + (li & 15);
+        voff[mt] = (unsigned)(((gy * S + gx) * COUT + 4 * kh) * 4);
+    }
+    auto prefetch_aux = [&]() {
+        if constexpr (EPI == EPI_MUL_ELUGRAD) {
+            const i32x4_ rsrc_aux = make_rsrc(aux + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int soff = (nt * 32 + 8 * g4) * 4;
+                        IOD_SGPR_SETTLE(rsrc_aux, soff);
+                        IOD_BLOAD4(ax[mt][nt][g4], voff[mt], rsrc_aux, soff);
+                    }
+        }
+    };
     TP_STAMP(0);                                             // [0] block start: index arithmetic
     prefetch_in(0, rinA);
     prefetch_w(0);
@@ -735,17 +760,20 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         rescale(commit(rinB));                               // chunk 1 staged
         if (NCHUNK > 2) prefetch_w(2);
         if (NCHUNK > 3) prefetch_in(3, rinB);
+        if (NCHUNK == 2) prefetch_aux();
         compute();                                           // chunk 1
     }
     if constexpr (NCHUNK > 2) {
         vm_wait(integral_constant<int, (NCHUNK > 3 ? NIN : 0)>{}, rinA);
         rescale(commit(rinA));
         if (NCHUNK > 3) prefetch_w(3);
+        if (NCHUNK == 3) prefetch_aux();
         compute();                                           // chunk 2
     }
     if constexpr (NCHUNK > 3) {
         vm_wait(integral_constant<int, 0>{}, rinB);
         rescale(commit(rinB));
+        prefetch_aux();
         compute();                                           // chunk 3
     }
     static_assert(NCHUNK <= 4, "chunk schedule is unrolled for at most 64 input channels");
@@ -769,13 +797,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         }
     } else {
         const i32x4_ rsrc_out = make_rsrc(out + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
-        unsigned voff[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int gy = ty * 16 + 4 * wv + 2 * mt + (li >> 4), gx = tx * 16 + (li & 15);
-            voff[mt] = (unsigned)(((gy * S + gx) * COUT + 4 * kh) * 4);
-        }
-        f32x4 bv[NT][4], ax[2][NT][4];
+        f32x4 bv[NT][4];
         if constexpr (EPI == EPI_BIAS_ELU) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -792,17 +814,6 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
                 for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(bv[nt][g4]));
         }
         if constexpr (EPI == EPI_MUL_ELUGRAD) {
-            const i32x4_ rsrc_aux = make_rsrc(aux + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int soff = (nt * 32 + 8 * g4) * 4;
-                        IOD_SGPR_SETTLE(rsrc_aux, soff);
-                        IOD_BLOAD4(ax[mt][nt][g4], voff[mt], rsrc_aux, soff);
-                    }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
