@@ -1010,33 +1010,51 @@ void conv3x3_tile_f16x3_v3_kernel(const float* __restrict__ in, const uint4* __r
         // ------------------------------------------------------------ INPUT PRODUCERS ----
         // per-thread element offsets of its NIN halo float4s inside the current look-ahead tile (32-bit: tensors are
         // < 2^31 floats), recomputed only when the look-ahead step enters a new tile; -1 = outside the image / idle
-        int goff[NIN];
+        // raw buffer loads (inline asm, explicit counted vmcnt): one descriptor per slot-image, halo pixels outside the
+        // image / idle lanes carry an out-of-range offset and come back as 0, the chunk offset is the scalar operand
+        typedef int i32x4_ __attribute__((ext_vector_type(4)));
+        auto make_rsrc = [&](const void* base, unsigned bytes) {
+            const unsigned long long p = (unsigned long long)base;
+            i32x4_ r;
+            r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+            r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+            r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+            r.w = 0x00020000;
+            return r;
+        };
+        unsigned goff[NIN];
+        i32x4_ rsrc_in = make_rsrc(in, 0u);
         auto tile_offsets = [&](int q) {
             int n, ty, tx;
             tile_coords(q, n, ty, tx);
             const int y0 = ty * 16 - 1, x0 = tx * 16 - 1;
-            const int nbase = n * S * S;
+            rsrc_in = make_rsrc(in + (size_t)n * S * S * CIN, (unsigned)(S * S * CIN * 4));
 #pragma unroll
             for (int k = 0; k < NIN; ++k) {
                 const int idx = ptid + k * NPT;
                 const int px = idx >> 2, cq = idx & 3;
                 const int gy = y0 + px / HALO, gx = x0 + px % HALO;
                 const bool ok = idx < NPX * 4 && gy >= 0 && gy < S && gx >= 0 && gx < S;
-                goff[k] = ok ? (nbase + gy * S + gx) * CIN + cq * 4 : -1;
+                goff[k] = ok ? (unsigned)(((gy * S + gx) * CIN + cq * 4) * 4) : 0x80000000u;
             }
         };
-        auto G = [&](int q_, float4 (&r)[NIN]) {
+        auto G = [&](int q_, f32x4 (&r)[NIN]) {
             const int q = q_ < nq ? q_ : nq - 1;
             if (q % NCHUNK == 0 || q_ <= 2) tile_offsets(q);            // block-uniform
-            const float* base = in + (q % NCHUNK) * 16;
+            const int soff = (q % NCHUNK) * 64;
+            asm volatile("s_nop 4" :: "s"(rsrc_in), "s"(soff) : "memory");
 #pragma unroll
-            for (int k = 0; k < NIN; ++k) {
-                const bool ok = goff[k] >= 0 && !(flags & 2);
-                const float4 v = *reinterpret_cast<const float4*>(base + (ok ? goff[k] : 0));
-                r[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int k = 0; k < NIN; ++k)
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r[k]) : "v"(goff[k]), "s"(rsrc_in), "s"(soff) : "memory");
         };
-        auto MAXPUB = [&](int slot, const float4 (&r)[NIN]) {
+        auto wait_set = [&](auto nc, f32x4 (&r)[NIN]) {
+            constexpr int nleft = decltype(nc)::value;
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(nleft) : "memory");
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) asm volatile("" : "+v"(r[k]));
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto MAXPUB = [&](int slot, const f32x4 (&r)[NIN]) {
             if (flags & 8) return;
             float m = 0.f;
 #pragma unroll
@@ -1046,14 +1064,14 @@ void conv3x3_tile_f16x3_v3_kernel(const float* __restrict__ in, const uint4* __r
             for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
             if (lane == 0) s_max[slot * 4 + (wv - 4)] = m;
         };
-        auto WIN = [&](int q, const float4 (&r)[NIN], float scale) {
+        auto WIN = [&](int q, const f32x4 (&r)[NIN], float scale) {
             if (flags & 32) return;
             unsigned char* s_in = smem_b + (q & 1) * IN_BYTES;
 #pragma unroll
             for (int k = 0; k < NIN; ++k) {
                 const int idx = ptid + k * NPT;
                 const int px = idx < NPX * 4 ? idx >> 2 : NPX, cq = idx & 3;      // idle lanes write the dump slot
-                float4 v = r[k];
+                f32x4 v = r[k];
                 v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
                 // hi = v truncated to fp16 precision (mask the 13 low mantissa bits: exact in fp16 for the scaled
                 // range), lo = v - hi (exact in fp32), both packed with v_cvt_pkrtz (2 values per instruction)
@@ -1070,20 +1088,25 @@ void conv3x3_tile_f16x3_v3_kernel(const float* __restrict__ in, const uint4* __r
             }
         };
 
-        float4 R0[NIN], R1[NIN], R2[NIN];
+        f32x4 R0[NIN], R1[NIN], R2[NIN];
+        using std::integral_constant;
         // prologue: stage chunk 0, chunks 1 and 2 in flight, max(1) published
         G(0, R0);
         G(1, R1); G(2, R2);
+        wait_set(integral_constant<int, 2 * NIN>{}, R0);
         MAXPUB(0, R0);
         block_barrier();                                    // P1: max(0) visible
         WIN(0, R0, SCALE(0));
+        wait_set(integral_constant<int, NIN>{}, R1);
         MAXPUB(1, R1);
         block_barrier();                                    // P2: chunk 0 staged, max(1) visible
 
         // iteration q: fetch input q+3, stage input q+1, publish max(q+2)
-        auto iteration = [&](int q, int sl, float4 (&Rnext)[NIN], float4 (&Rmax)[NIN], float4 (&Rload)[NIN]) {
+        auto iteration = [&](int q, int sl, f32x4 (&Rnext)[NIN], f32x4 (&Rmax)[NIN], f32x4 (&Rload)[NIN]) {
             G(q + 3, Rload);
+            wait_set(integral_constant<int, 2 * NIN>{}, Rnext);          // (arrived during the previous step)
             WIN(q + 1, Rnext, SCALE((sl + 1) % 3));
+            wait_set(integral_constant<int, NIN>{}, Rmax);               // requested two steps ago
             MAXPUB((sl + 2) % 3, Rmax);
             block_barrier();
         };
@@ -1092,6 +1115,7 @@ void conv3x3_tile_f16x3_v3_kernel(const float* __restrict__ in, const uint4* __r
             if (q + 1 < nq) iteration(q + 1, 1, R2, R0, R1);
             if (q + 2 < nq) iteration(q + 2, 2, R0, R1, R2);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         prof_flush(1);
         return;
     }
@@ -1144,17 +1168,17 @@ void conv3x3_tile_f16x3_v3_kernel(const float* __restrict__ in, const uint4* __r
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[nt], f.al[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[nt], f.ah[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[nt], f.ah[mt], acc[mt][nt], 0, 0, 0);
         };
         Frag f0, f1;
         using std::integral_constant;
@@ -1174,32 +1198,99 @@ void conv3x3_tile_f16x3_v3_kernel(const float* __restrict__ in, const uint4* __r
             int n, ty, tx;
             tile_coords(q, n, ty, tx);
             const float inv = inv_ws / cur_scale;
+            // accumulator rows are channels (MFMAs issued as (weights, activations)): float4 buffer stores, see the
+            // one-tile-per-block kernel above
+            typedef int i32x4_ __attribute__((ext_vector_type(4)));
+            auto make_rsrc = [&](const void* base, unsigned bytes) {
+                const unsigned long long p = (unsigned long long)base;
+                i32x4_ r;
+                r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+                r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+                r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+                r.w = 0x00020000;
+                return r;
+            };
+            if constexpr (EPI == EPI_OUT4) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int gy = ty * 16 + 4 * cwv + 2 * mt + (li >> 4), gx = tx * 16 + (li & 15);
+                    if (kh == 0) {
+                        const float4 bv = *reinterpret_cast<const float4*>(bias);
+                        *reinterpret_cast<float4*>(out + (size_t)((n * S + gy) * S + gx) * 4) =
+                            make_float4(acc[mt][0][0] * inv + bv.x, acc[mt][0][1] * inv + bv.y, acc[mt][0][2] * inv + bv.z,
+                                        acc[mt][0][3] * inv + bv.w);
+                    }
+                }
+            } else {
+                const i32x4_ rsrc_out = make_rsrc(out + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
+                unsigned voff[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int gy = ty * 16 + 4 * cwv + 2 * mt + (li >> 4), gx = tx * 16 + (li & 15);
+                    voff[mt] = (unsigned)(((gy * S + gx) * COUT + 4 * kh) * 4);
+                }
+                f32x4 bv[NT][4], ax[2][NT][4];
+                if constexpr (EPI == EPI_BIAS_ELU) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const float4 t = *reinterpret_cast<const float4*>(bias + nt * 32 + 8 * g4 + 4 * kh);
+                            bv[nt][g4] = f32x4{t.x, t.y, t.z, t.w};
+                        }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(bv[nt][g4]));
+                }
+                if constexpr (EPI == EPI_MUL_ELUGRAD) {
+                    const i32x4_ rsrc_aux = make_rsrc(aux + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                const int soff = (nt * 32 + 8 * g4) * 4;
+                                asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen"
+                                             : "=v"(ax[mt][nt][g4]) : "v"(voff[mt]), "s"(rsrc_aux), "s"(soff) : "memory");
+                            }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(ax[mt][nt][g4]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            f32x4 v = f32x4{acc[mt][nt][4 * g4] * inv, acc[mt][nt][4 * g4 + 1] * inv,
+                                            acc[mt][nt][4 * g4 + 2] * inv, acc[mt][nt][4 * g4 + 3] * inv};
+                            if constexpr (EPI == EPI_BIAS_ELU) {
+                                const f32x4 b4 = bv[nt][g4];
+                                v = f32x4{elu1_fast(v.x + b4.x), elu1_fast(v.y + b4.y), elu1_fast(v.z + b4.z), elu1_fast(v.w + b4.w)};
+                            } else if constexpr (EPI == EPI_MUL_ELUGRAD) {
+                                const f32x4 a4 = ax[mt][nt][g4];
+                                v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
+                                v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
+                            }
+                            const int soff = (nt * 32 + 8 * g4) * 4;
+                            asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1"
+                                         :: "v"(v), "v"(voff[mt]), "s"(rsrc_out), "s"(soff) : "memory");
+                        }
+            }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int co = nt * 32 + li;
-                    float bv = 0.f;
-                    if (EPI == EPI_BIAS_ELU) bv = bias[co];
-                    if (EPI == EPI_OUT4) bv = li < 4 ? bias[li] : 0.f;
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                        const int gy = ty * 16 + 4 * cwv + 2 * mt + (m >> 4);
-                        const int gx = tx * 16 + (m & 15);
-                        float v = acc[mt][nt][r] * inv;
-                        acc[mt][nt][r] = 0.f;
-                        if (flags & 16) continue;
-                        if (EPI == EPI_OUT4) {
-                            if (li < 4) out[(((size_t)n * S + gy) * S + gx) * 4 + li] = v + bv;
-                            continue;
-                        }
-                        const size_t o = (((size_t)n * S + gy) * S + gx) * COUT + co;
-                        if (EPI == EPI_BIAS_ELU) v = elu1_fast(v + bv);
-                        else if (EPI == EPI_MUL_ELUGRAD) v *= elu1_grad_from_out(aux[o]);
-                        out[o] = v;
-                    }
-                }
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
             cur_scale = sc_next;
         } else if (sc_next != cur_scale) {
             const float r = sc_next / cur_scale;
