@@ -79,7 +79,7 @@ struct iodine_handle {
     std::vector<float*> dec_wf, dec_wb, dec_b;  // packed fwd / dgrad weights + bias copies for layers 1..Dd-1
     std::vector<float*> dec_wf16, dec_wb16, dec_wmeta;   // split-fp16 packs (+ {scale, 1/scale, scale_b, 1/scale_b})
     int precision = 1;                          // 0: exact fp32 MFMA, 1: 3 x fp16 MFMA split (fp32-class accuracy)
-    int wgrad_ws = 1;                           // decoder 64->64 weight gradient: 1 = warp-specialised producer/consumer kernel, 0 = one-role kernel
+    int wgrad_ws = 2;                           // decoder 64->64 weight gradient: 0 one-role kernel, 1 warp-specialised (transposing stagers + v_alignbit), 2 warp-specialised with ds_read_b64_tr_b16
     int variant = 1;                            // split-fp16 tile conv: 1 = one tile per block (2 blocks/CU), 3 = warp-specialised persistent (experimental)
     float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr, *dec_out_w16 = nullptr, *dec_out_meta = nullptr;
     std::vector<float*> ref_w, ref_b;
@@ -382,7 +382,7 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         if (train_alpha != 0.f) {
             if (h->precision == 1 && h->wgrad_ws)
                 PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_f16x3_ws(st, b.act[l - 1], b.dpre[cur], b.wg_part,
-                                                                              b.wg_part_b, N, h->S, Cd, Cd, &nparts, &ncop, &nb));
+                                                                              b.wg_part_b, N, h->S, Cd, Cd, &nparts, &ncop, &nb, h->wgrad_ws));
             else if (h->precision == 1)
                 PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_f16x3(st, b.act[l - 1], b.dpre[cur], b.wg_part,
                                                                            b.wg_part_b, N, h->S, Cd, Cd, &nparts, &ncop, &nb));
@@ -672,7 +672,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!h || !key) return IODINE_ERR_INVALID;
     if (!strcmp(key, "stop_after_iters")) { h->stop_after = (int)value; return IODINE_OK; }
     if (!strcmp(key, "profile")) { h->profile = value != 0; return IODINE_OK; }
-    if (!strcmp(key, "wgrad_ws")) { h->wgrad_ws = value != 0; return IODINE_OK; }
+    if (!strcmp(key, "wgrad_ws")) { h->wgrad_ws = (int)value; return IODINE_OK; }   // 0 one-role, 1 ws + alignbit, 2 ws + transposing LDS reads
     if (!strcmp(key, "conv_variant")) {
         if (value != 1 && value != 3) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1 or 3");
         h->variant = (int)value;
@@ -1035,7 +1035,8 @@ int iodine_op_conv3x3_wgrad(void* stream, const float* in, const float* d, float
     } else if (stride == 1) {
         const char* ws = getenv("IODINE_WGRAD_WS");                 // kernel-level tests cover both forms
         e = (ws && ws[0] == '0') ? launch_conv3x3_wgrad_f16x3(st, in, d, part, part_b, n, s, ci_pad, co, &nparts, &cip, &nb)
-                                 : launch_conv3x3_wgrad_f16x3_ws(st, in, d, part, part_b, n, s, ci_pad, co, &nparts, &cip, &nb);
+                                 : launch_conv3x3_wgrad_f16x3_ws(st, in, d, part, part_b, n, s, ci_pad, co, &nparts, &cip, &nb,
+                                                                 ws ? atoi(ws) : 2);
         // stride-1 partial tiles are [9][ci][co padded to 32]
         if (e == hipSuccess) e = launch_wgrad_reduce(st, part, nparts, ci_pad, cip, co, ci_real, ci_real, 1.f, gw, fold);
     } else {

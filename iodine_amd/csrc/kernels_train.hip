@@ -11,6 +11,7 @@
 // iodine.py:343; lambda is detached before the additive update, iodine.py:642-643).
 #include "common.h"
 #include <type_traits>
+#include <utility>
 #include <vector>
 #include <cstdio>
 
@@ -1075,11 +1076,22 @@ hipError_t launch_dec_out_wgrad_gemm_f16x3(hipStream_t st, const float* a, const
 //                         max |a|, max |d| of tile t+2 published for the scale choice of the next step
 // One s_barrier per tile.  The tile loop is unrolled by three so that the register sets are named, not indexed.
 // =========================================================================================
+template <class F, int... Is>
+IOD_DEVINL void iod_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+IOD_DEVINL void iod_static_for(F&& f) { iod_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // out-of-image / idle lanes of the producers load from here instead of selecting 0 after the load: a select would make
 // hipcc wait for the load right where it is issued, i.e. un-prefetch it
 __device__ float4 g_zero4[1];
 
-template <int CI, int NCO>
+// TR = true: the producers write the split tile in NATURAL order (per pixel: 64 hi channels | 64 lo channels, 8-byte
+// stores, no rotation) and the consumers fetch K-major fragments with the gfx950 transposing LDS read
+// ds_read_b64_tr_b16 (tools/experiments/tr_b16_probe.hip: in a 16-lane group lane i supplies row i/4, columns 4(i%4)..+3
+// of a 4x16 halfword matrix, lane c receives column c): lane = channel, 4 consecutive pixels per read, the +-1 column
+// taps are plain address offsets (no v_alignbit, no neighbour reads).  Pixel slots are padded to a stride of 64 mod 256
+// bytes so that the 4 pixels x 64 bytes of one read fall into different bank quarters.
+template <int CI, int NCO, bool TR>
 __global__ __launch_bounds__(512, 2)
 void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __restrict__ d, float* __restrict__ part,
                                    float* __restrict__ part_b, int S, int ntiles, int tiles_x, int tiles_y)
@@ -1091,7 +1103,10 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
     constexpr int NA_UNITS = HH * 10 * A4, ND_UNITS = TH * 8 * D4;
     constexpr int NAU = (NA_UNITS + 255) / 256, NDU = (ND_UNITS + 255) / 256;
     constexpr int RW = TH / KS;
-    constexpr int BUF_DW = 2 * CI * APL + 2 * NCO * DPL;
+    constexpr int AST = 2 * CI * 2 + 64, DST = 2 * NCO * 2 + 64;            // TR: bytes per pixel slot (hi | lo | pad)
+    constexpr int A_BYTES = HH * 20 * AST, D_BYTES = TH * 16 * DST;
+    static_assert(AST % 256 == 64 || AST % 256 == 192, "TR pixel stride must be an odd multiple of 64 bytes");
+    constexpr int BUF_DW = TR ? (A_BYTES + D_BYTES) / 4 : 2 * CI * APL + 2 * NCO * DPL;
 
     extern __shared__ __attribute__((aligned(16))) unsigned smem_ws[];
     float* s_max = reinterpret_cast<float*>(smem_ws + 2 * BUF_DW);          // [3][8]
@@ -1234,6 +1249,43 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
             sa = tile_scale(ma, sa);
             sd = tile_scale(md, sd);
             if (ptid == 0) s_scale[q & 1] = sa * sd;
+            if constexpr (TR) {
+                unsigned char* sb = reinterpret_cast<unsigned char*>(smem_ws + (q & 1) * BUF_DW);
+                auto split_store = [&](const f32x4 w, float scale, unsigned char* dst, int lo_off) {
+                    const float x = w.x * scale, y = w.y * scale, z = w.z * scale, t = w.w * scale;
+                    const float hx = __uint_as_float(__float_as_uint(x) & 0xffffe000u), hy = __uint_as_float(__float_as_uint(y) & 0xffffe000u);
+                    const float hz = __uint_as_float(__float_as_uint(z) & 0xffffe000u), hw = __uint_as_float(__float_as_uint(t) & 0xffffe000u);
+                    typedef __fp16 h2_ __attribute__((ext_vector_type(2)));
+                    const h2_ h01 = __builtin_amdgcn_cvt_pkrtz(hx, hy), h23 = __builtin_amdgcn_cvt_pkrtz(hz, hw);
+                    const h2_ l01 = __builtin_amdgcn_cvt_pkrtz(x - hx, y - hy), l23 = __builtin_amdgcn_cvt_pkrtz(z - hz, t - hw);
+                    uint2 hi, lo;
+                    __builtin_memcpy(&hi.x, &h01, 4); __builtin_memcpy(&hi.y, &h23, 4);
+                    __builtin_memcpy(&lo.x, &l01, 4); __builtin_memcpy(&lo.y, &l23, 4);
+                    *reinterpret_cast<uint2*>(dst) = hi;
+                    *reinterpret_cast<uint2*>(dst + lo_off) = lo;
+                };
+#pragma unroll
+                for (int k = 0; k < NAU; ++k) {
+                    const int u = ptid + k * 256;
+                    if (u < NA_UNITS) {
+                        const int c4 = u % A4, tt = u / A4, p = tt % 10, row = tt / 10;
+                        unsigned char* dst = sb + (row * 20 + 2 * p) * AST + c4 * 8;
+                        split_store(r.ra[k][0], sa, dst, CI * 2);
+                        split_store(r.ra[k][1], sa, dst + AST, CI * 2);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NDU; ++k) {
+                    const int u = ptid + k * 256;
+                    if (u < ND_UNITS) {
+                        const int c4 = u % D4, tt = u / D4, p = tt % 8, row = tt / 8;
+                        unsigned char* dst = sb + A_BYTES + (row * 16 + 2 * p) * DST + c4 * 8;
+                        split_store(r.rd[k][0], sd, dst, NCO * 2);
+                        split_store(r.rd[k][1], sd, dst + DST, NCO * 2);
+                    }
+                }
+                return;
+            }
             unsigned* s_a = smem_ws + (q & 1) * BUF_DW;
             unsigned* s_d = s_a + 2 * CI * APL;
 #pragma unroll
@@ -1346,6 +1398,114 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
                 for (int e = 0; e < 16; ++e) acc[tp][e] *= r;
             acc_prod = prod;
         }
+        if constexpr (TR) {
+            // lane -> (16-lane group g: K half kh = g >> 1, channel half g & 1; i = lane & 15: pixel i >> 2, channel quad i & 3)
+            typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+            const int g = lane >> 4, i16 = lane & 15;
+            const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)smem_ws + (q & 1) * BUF_DW * 4;
+            const int row0 = RW == 1 ? ks : 0;                          // RW == 1: this wave's single row through the base address
+            const unsigned a_addr = lds0 + (row0 * 20 + 8 * (g >> 1) + (i16 >> 2)) * AST + (mi * 32 + 16 * (g & 1) + 4 * (i16 & 3)) * 2;
+            const unsigned d_addr = lds0 + A_BYTES + (row0 * 16 + 8 * (g >> 1) + (i16 >> 2)) * DST + (ni * 32 + 16 * (g & 1) + 4 * (i16 & 3)) * 2;
+            struct FragA { u32x2_ v[2][3][2]; };                         // [term][dx][pixel half]
+            struct FragB { u32x2_ v[2][2]; };                            // [term][pixel half]
+#define IOD_TRR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+            auto loadA = [&, a_addr](auto rc, auto dyc, FragA& f) {
+                constexpr int rrow = decltype(rc)::value + decltype(dyc)::value;
+                const unsigned aa = a_addr;
+#pragma unroll
+                for (int term = 0; term < 2; ++term)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            // (constant-folded after unrolling: the offset must be an immediate)
+                            switch (term * 6 + dx * 2 + h) {
+#define IOD_CASE(T_, DX_, H_) case T_ * 6 + DX_ * 2 + H_: IOD_TRR(f.v[T_][DX_][H_], aa, (rrow * 20 + DX_ + 1 + 4 * H_) * AST + T_ * CI * 2); break;
+                                IOD_CASE(0, 0, 0) IOD_CASE(0, 0, 1) IOD_CASE(0, 1, 0) IOD_CASE(0, 1, 1) IOD_CASE(0, 2, 0) IOD_CASE(0, 2, 1)
+                                IOD_CASE(1, 0, 0) IOD_CASE(1, 0, 1) IOD_CASE(1, 1, 0) IOD_CASE(1, 1, 1) IOD_CASE(1, 2, 0) IOD_CASE(1, 2, 1)
+#undef IOD_CASE
+                            }
+                        }
+            };
+            auto loadB = [&, d_addr](auto rc, FragB& f) {
+                constexpr int rrow = decltype(rc)::value;
+                const unsigned da = d_addr;
+                IOD_TRR(f.v[0][0], da, (rrow * 16) * DST);
+                IOD_TRR(f.v[0][1], da, (rrow * 16 + 4) * DST);
+                IOD_TRR(f.v[1][0], da, (rrow * 16) * DST + NCO * 2);
+                IOD_TRR(f.v[1][1], da, (rrow * 16 + 4) * DST + NCO * 2);
+            };
+#undef IOD_TRR
+            auto mma = [&](auto dyc, FragA& fa, FragB& fb) {
+                constexpr int dy = decltype(dyc)::value;
+                h16x8 B[2], A[2][3];
+#pragma unroll
+                for (int term = 0; term < 2; ++term) {
+                    const uint4 vb = make_uint4(fb.v[term][0].x, fb.v[term][0].y, fb.v[term][1].x, fb.v[term][1].y);
+                    __builtin_memcpy(&B[term], &vb, 16);
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const uint4 va = make_uint4(fa.v[term][dx][0].x, fa.v[term][dx][0].y, fa.v[term][dx][1].x, fa.v[term][dx][1].y);
+                        __builtin_memcpy(&A[term][dx], &va, 16);
+                    }
+                }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int tap = dy * 3 + dx;
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][dx], B[0], acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][dx], B[1], acc[tap], 0, 0, 0);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][dx], B[0], acc[tap], 0, 0, 0);
+                }
+            };
+            using std::integral_constant;
+            // fragments are double-buffered: the reads of step s+1 are issued before the MFMAs of step s; LDS returns in
+            // order, so waiting until only the newer step's reads are outstanding retires the older step's
+            FragA fa0, fa1;
+            FragB fb0, fb1;
+            auto wait_frags = [&](auto nc, FragA& fa, FragB& fb) {
+                constexpr int nleft = decltype(nc)::value;
+                asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(nleft) : "memory");
+#pragma unroll
+                for (int term = 0; term < 2; ++term) {
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) { asm volatile("" : "+v"(fa.v[term][dx][0])); asm volatile("" : "+v"(fa.v[term][dx][1])); }
+                    asm volatile("" : "+v"(fb.v[term][0])); asm volatile("" : "+v"(fb.v[term][1]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // rows of this wave: RW == 4: rows 0..3 (compile-time offsets); RW == 1: row ks through the base addresses
+            static_assert(RW == 4 || RW == 1, "rows per consumer wave");
+            // step list (row, dy): even steps use (fa0), odd steps (fa1); B fragments alternate per row
+            auto run = [&]() {
+                constexpr int NROW = RW;
+                loadB(integral_constant<int, 0>{}, fb0);
+                loadA(integral_constant<int, 0>{}, integral_constant<int, 0>{}, fa0);
+                iod_static_for<NROW>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    FragB& fbc = (r & 1) ? fb1 : fb0;
+                    FragB& fbn = (r & 1) ? fb0 : fb1;
+                    // dy = 0 (fa of parity (3r) & 1)
+                    auto& f_0 = ((3 * r) & 1) ? fa1 : fa0;
+                    auto& f_1 = ((3 * r + 1) & 1) ? fa1 : fa0;
+                    auto& f_2 = ((3 * r + 2) & 1) ? fa1 : fa0;
+                    loadA(rc, integral_constant<int, 1>{}, f_1);
+                    wait_frags(integral_constant<int, 12>{}, f_0, fbc);
+                    mma(integral_constant<int, 0>{}, f_0, fbc);
+                    loadA(rc, integral_constant<int, 2>{}, f_2);
+                    wait_frags(integral_constant<int, 12>{}, f_1, fbc);
+                    mma(integral_constant<int, 1>{}, f_1, fbc);
+                    if constexpr (r + 1 < NROW) {
+                        loadB(integral_constant<int, (r + 1 < NROW ? r + 1 : 0)>{}, fbn);
+                        loadA(integral_constant<int, (r + 1 < NROW ? r + 1 : 0)>{}, integral_constant<int, 0>{}, f_1);   // step 3r+3 has the parity of 3r+1
+                        wait_frags(integral_constant<int, 15>{}, f_2, fbc);   // (16 newer reads; lgkmcnt is a 4-bit counter)
+                    } else {
+                        wait_frags(integral_constant<int, 0>{}, f_2, fbc);
+                    }
+                    mma(integral_constant<int, 2>{}, f_2, fbc);
+                });
+            };
+            run();
+        } else
 #pragma unroll
         for (int rr = 0; rr < RW; ++rr) {
             const int r = ks * RW + rr;
@@ -1417,22 +1577,24 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
     }
 }
 
-template <int CI, int NCO>
+template <int CI, int NCO, bool TR>
 static hipError_t launch_wgrad_f16_ws_inst(hipStream_t st, const float* a, const float* d, float* part, float* part_b,
                                            int N, int S, int* nparts, int* ncop, int* nbias)
 {
     constexpr int MT = CI / 32, NTT = NCO / 32, KS = 4 / (MT * NTT);
-    constexpr size_t lds = (size_t)2 * (2 * CI * 76 + 2 * NCO * 36) * 4 + 26 * 4 + 32;
+    constexpr size_t buf = TR ? (size_t)6 * 20 * (2 * CI * 2 + 64) + (size_t)4 * 16 * (2 * NCO * 2 + 64)
+                              : (size_t)(2 * CI * 76 + 2 * NCO * 36) * 4;
+    constexpr size_t lds = 2 * buf + 26 * 4 + 32;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_f16x3_ws_kernel<CI, NCO>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_f16x3_ws_kernel<CI, NCO, TR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int tiles_x = S / 16, tiles_y = S / 4, ntiles = N * tiles_x * tiles_y;
     const int blocks = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL((conv3x3_wgrad_f16x3_ws_kernel<CI, NCO>), dim3(blocks), dim3(512), lds, st, a, d, part, part_b, S,
+    hipLaunchKernelGGL((conv3x3_wgrad_f16x3_ws_kernel<CI, NCO, TR>), dim3(blocks), dim3(512), lds, st, a, d, part, part_b, S,
                        ntiles, tiles_x, tiles_y);
 #ifdef IODINE_TILE_PROF
     {
@@ -1453,11 +1615,17 @@ static hipError_t launch_wgrad_f16_ws_inst(hipStream_t st, const float* a, const
     return hipGetLastError();
 }
 
+// variant 1: transposing stagers + v_alignbit shifts; variant 2: natural-order staging + ds_read_b64_tr_b16
 hipError_t launch_conv3x3_wgrad_f16x3_ws(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
-                                         int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts)
+                                         int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts, int variant)
 {
     if (S % 16 != 0) return hipErrorInvalidValue;
-    if (ci == 64 && nco == 64) return launch_wgrad_f16_ws_inst<64, 64>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts);
-    if (ci == 32 && nco == 32) return launch_wgrad_f16_ws_inst<32, 32>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts);
+    if (variant == 2) {
+        if (ci == 64 && nco == 64) return launch_wgrad_f16_ws_inst<64, 64, true>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts);
+        if (ci == 32 && nco == 32) return launch_wgrad_f16_ws_inst<32, 32, true>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts);
+    } else {
+        if (ci == 64 && nco == 64) return launch_wgrad_f16_ws_inst<64, 64, false>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts);
+        if (ci == 32 && nco == 32) return launch_wgrad_f16_ws_inst<32, 32, false>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts);
+    }
     return hipErrorInvalidValue;
 }
