@@ -190,7 +190,7 @@ def main():
         # the kernel executes SPLIT_PASSES f16 MFMAs per algorithmic (fp32-class) multiply-add: the peak for ALGORITHMIC
         # FLOPs is the dense f16 MFMA peak divided by the number of passes
         peak = PEAK_F16_MFMA_TFLOPS / SPLIT_PASSES
-        kname = (f'conv3x3_tile_f16x3_kernel<{C_},{C_}> + conv3x3_wgrad_f16x3_kernel<{C_},{C_}> (decoder 3x3 conv {C_}->{C_}: '
+        kname = (f'conv3x3_tile_f16x3_kernel<{C_},{C_}> + conv3x3_wgrad_f16x3_ws_kernel<{C_},{C_}> (decoder 3x3 conv {C_}->{C_}: '
                  f'fwd, dgrad, wgrad launches; fp32 in/out, operands split into f16 hi+lo, 3 f16 MFMAs, fp32 accumulate)')
     else:
         peak = PEAK_F32_MFMA_TFLOPS
