@@ -129,8 +129,13 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
 
 /* Options: "stop_after_iters" (debug: run only the first v refinement iterations of reconstruct, no final decode),
  * "profile" (1: bracket every kernel launch with HIP events on the launch stream),
- * "conv_precision" (decoder 3x3 convs: 0 = exact fp32 MFMA, 1 = fp32 operands split into fp16 hi+lo, 3 fp16 MFMAs,
- * fp32 accumulate -- default). */
+ * "conv_precision" (3x3 convs of the decoder and refinement stacks: 0 = exact fp32 MFMA, 1 = fp32 operands split into
+ * fp16 hi+lo, 3 fp16 MFMAs, fp32 accumulate -- default),
+ * "conv_variant" (split-fp16 stride-1 conv: 1 = one tile per block, two blocks per CU -- default; 3 = warp-specialised
+ * persistent kernel, experimental),
+ * "wgrad_ws" (split-fp16 64->64 / 32->32 weight gradient: 2 = warp-specialised, natural-order staging + transposing LDS
+ * reads -- default; 1 = warp-specialised with transposing stagers; 0 = one-role kernel).  All variants compute the same
+ * arithmetic; the non-default ones exist for same-box A/B timing (tools/ab_bench.py). */
 int iodine_set_option(iodine_handle* h, const char* key, double value);
 /* Sum of event-measured durations (ms) and number of launches of one kernel category since the last reset:
  * "conv_tile_fwd", "conv_tile_dgrad", "conv_tile_wgrad", "dec_out", "dec_out_dgrad", "dec_l0", "l0_reduce",
