@@ -1081,10 +1081,6 @@ IOD_DEVINL void iod_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { 
 template <int N, class F>
 IOD_DEVINL void iod_static_for(F&& f) { iod_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-// out-of-image / idle lanes of the producers load from here instead of selecting 0 after the load: a select would make
-// hipcc wait for the load right where it is issued, i.e. un-prefetch it
-__device__ float4 g_zero4[1];
-
 // TR = true: the producers write the split tile in NATURAL order (per pixel: 64 hi channels | 64 lo channels, 8-byte
 // stores, no rotation) and the consumers fetch K-major fragments with the gfx950 transposing LDS read
 // ds_read_b64_tr_b16 (tools/experiments/tr_b16_probe.hip: in a 16-lane group lane i supplies row i/4, columns 4(i%4)..+3
@@ -1124,7 +1120,6 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
         float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
         float sa = 1.f, sd = 1.f;
         struct Set { f32x4 ra[NAU][2]; f32x4 rd[NDU][2]; };     // native vectors: they are inline-asm operands
-#define GLOAD4(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 #define VM_WAIT(n) do { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
         // the wait names every register of the set as read-write, so no use of the loaded values can be placed above it
         auto wait_set = [&](auto nc, Set& r) {
@@ -1363,7 +1358,6 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
         if (ptid == 0 && blockIdx.x < TP_MAXBLK) for (int i_ = 2; i_ < 8; ++i_) g_wgrad_prof[blockIdx.x * 8 + i_] = tp_acc[i_];
 #endif
         VM_WAIT(0);
-#undef GLOAD4
 #undef VM_WAIT
 #undef BLOAD4
         __builtin_amdgcn_s_barrier();                                       // F1: consumers are done with the planes
