@@ -784,18 +784,8 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     // (li, kh) holds pixel li of the 32-pixel tile and channels 8g + 4kh .. +3 in registers 4g .. 4g+3: the epilogue
     // moves float4s of 4 consecutive channels.  Stores (and the ELU' operand of the data-gradient form) are raw buffer
     // operations on the slot-image: one byte offset per 32-pixel tile and lane, channel group in the scalar offset.
-    if constexpr (EPI == EPI_OUT4) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int gy = ty * 16 + 4 * wv + 2 * mt + (li >> 4), gx = tx * 16 + (li & 15);
-            if (kh == 0) {                               // decoder output conv: 4 real channels = registers 0..3 of nt 0
-                const float4 bv = *reinterpret_cast<const float4*>(bias);
-                *reinterpret_cast<float4*>(out + (size_t)((n * S + gy) * S + gx) * 4) =
-                    make_float4(acc[mt][0][0] * inv_ws + bv.x, acc[mt][0][1] * inv_ws + bv.y, acc[mt][0][2] * inv_ws + bv.z,
-                                acc[mt][0][3] * inv_ws + bv.w);
-            }
-        }
-    } else {
+    static_assert(EPI == EPI_BIAS_ELU || EPI == EPI_MUL_ELUGRAD, "the C -> 4 output conv has its own GEMM-form kernel");
+    {
         const i32x4_ rsrc_out = make_rsrc(out + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
         f32x4 bv[NT][4];
         if constexpr (EPI == EPI_BIAS_ELU) {
@@ -894,7 +884,6 @@ hipError_t launch_conv3x3_tile_f16x3(hipStream_t st, const float* in, const void
     if (cin == CI && cout == CO && epi == EP) return launch_tile_f16x3_inst<CI, CO, EP>(st, in, wpk, wmeta, bias, aux, out, N, S);
     T16_CASE(64, 64, EPI_BIAS_ELU) T16_CASE(64, 64, EPI_MUL_ELUGRAD)
     T16_CASE(32, 32, EPI_BIAS_ELU) T16_CASE(32, 32, EPI_MUL_ELUGRAD)
-    T16_CASE(64, 32, EPI_OUT4) T16_CASE(32, 32, EPI_OUT4)
 #undef T16_CASE
     return hipErrorInvalidValue;
 }
@@ -1210,18 +1199,7 @@ void conv3x3_tile_f16x3_v3_kernel(const float* __restrict__ in, const uint4* __r
                 r.w = 0x00020000;
                 return r;
             };
-            if constexpr (EPI == EPI_OUT4) {
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int gy = ty * 16 + 4 * cwv + 2 * mt + (li >> 4), gx = tx * 16 + (li & 15);
-                    if (kh == 0) {
-                        const float4 bv = *reinterpret_cast<const float4*>(bias);
-                        *reinterpret_cast<float4*>(out + (size_t)((n * S + gy) * S + gx) * 4) =
-                            make_float4(acc[mt][0][0] * inv + bv.x, acc[mt][0][1] * inv + bv.y, acc[mt][0][2] * inv + bv.z,
-                                        acc[mt][0][3] * inv + bv.w);
-                    }
-                }
-            } else {
+            {
                 const i32x4_ rsrc_out = make_rsrc(out + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
                 unsigned voff[2];
 #pragma unroll
@@ -1352,7 +1330,6 @@ hipError_t launch_conv3x3_tile_f16x3_v3(hipStream_t st, const float* in, const v
     if (cin == CI && cout == CO && epi == EP) return launch_tile_f16x3_v3_inst<CI, CO, EP>(st, in, wpk, wmeta, bias, aux, out, N, S);
     T16V3_CASE(64, 64, EPI_BIAS_ELU) T16V3_CASE(64, 64, EPI_MUL_ELUGRAD)
     T16V3_CASE(32, 32, EPI_BIAS_ELU) T16V3_CASE(32, 32, EPI_MUL_ELUGRAD)
-    T16V3_CASE(64, 32, EPI_OUT4) T16V3_CASE(32, 32, EPI_OUT4)
 #undef T16V3_CASE
     return hipErrorInvalidValue;
 }
