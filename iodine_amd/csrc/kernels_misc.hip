@@ -451,7 +451,7 @@ hipError_t launch_elbo(hipStream_t st, const float* pm, const float* plv, const 
 //   saved (training): pooled[n][C], s[n][H] (MLP pre-activation), gates[n][4H] (post-activation i,f,g,o),
 //   xin[n][H+4L] (LSTM input); the state buffers are per-iteration in training mode.
 // -----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(1024)
 void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, int C, int H, int L,
                         const float* __restrict__ mlp_wT /*[C][H]*/, const float* __restrict__ mlp_b,
                         const float* __restrict__ wihT /*[H+4L][4H]*/, const float* __restrict__ whhT /*[H][4H]*/,
@@ -471,16 +471,22 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
     float* s_h = s_x + H + 4 * L;       // H   (h_prev)
     float* s_c = s_h + H;               // H   (c1)
     float* s_red = s_c + H;             // 256
-    const int n = blockIdx.x, tid = threadIdx.x;
+    float* s_part = s_red + 256;        // [3][4H]: LSTM partial gate sums of the K slices 1..3
+    // 1024 threads: the LSTM reduction (H + 4L + H = 768 terms per gate) is split over 4 K slices (tid >> 8); everything
+    // else runs on the first 256 threads.  One block per slot: the serial depth of the gate loop set this kernel's time.
+    const int n = blockIdx.x, tid = threadIdx.x & 255, ksl = threadIdx.x >> 8;
+    const bool lead = ksl == 0;
 
     // global average pool over the PL pixels of the last conv layer (F.adaptive_avg_pool2d, iodine.py:481)
     {
         const int c = tid % C, g = tid / C, G = 256 / C;
         float s = 0.f;
-        for (int p = g; p < PL; p += G) s += feat[((size_t)n * PL + p) * C + c];
-        s_red[tid] = s;
+        if (lead) {
+            for (int p = g; p < PL; p += G) s += feat[((size_t)n * PL + p) * C + c];
+            s_red[tid] = s;
+        }
         __syncthreads();
-        if (tid < C) {
+        if (lead && tid < C) {
             float t = 0.f;
             for (int j = 0; j < G; ++j) t += s_red[j * C + tid];
             t /= (float)PL;
@@ -490,7 +496,7 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
         __syncthreads();
     }
     // MLP + double ELU
-    for (int j = tid; j < H; j += 256) {
+    for (int j = tid; lead && j < H; j += 256) {
         float s = mlp_b[j];
         for (int c = 0; c < C; ++c) s = fmaf(s_pool[c], mlp_wT[(size_t)c * H + j], s);
         const float u = elu1(elu1(s));
@@ -498,23 +504,47 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
         if (sv_s) sv_s[(size_t)n * H + j] = s;                   // pre-activation (training backward recomputes the ELUs)
         s_h[j] = h_prev[(size_t)n * H + j];
     }
-    for (int j = tid; j < 4 * L; j += 256) s_x[H + j] = latent[(size_t)n * 4 * L + j];
+    for (int j = tid; lead && j < 4 * L; j += 256) s_x[H + j] = latent[(size_t)n * 4 * L + j];
     __syncthreads();
-    if (sv_xin)
+    if (sv_xin && lead)
         for (int j = tid; j < H + 4 * L; j += 256) sv_xin[(size_t)n * (H + 4 * L) + j] = s_x[j];
     // LSTM cell, gate order i, f, g, o (torch.nn.LSTMCell)
     const int IN = H + 4 * L, H4 = 4 * H;
+    // partial sums of K slices 1..3 (fixed order: slice k takes terms i = k, k+4, ...; the lead slice adds them in order)
     for (int j = tid; j < H; j += 256) {
+        if (!lead) {
+            float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
+            for (int i = ksl; i < IN; i += 4) {
+                const float xv = s_x[i];
+                const float* w = wihT + (size_t)i * H4 + j;
+                gi = fmaf(xv, w[0], gi); gf = fmaf(xv, w[H], gf); gg = fmaf(xv, w[2 * H], gg); go = fmaf(xv, w[3 * H], go);
+            }
+            for (int i = ksl; i < H; i += 4) {
+                const float hv = s_h[i];
+                const float* w = whhT + (size_t)i * H4 + j;
+                gi = fmaf(hv, w[0], gi); gf = fmaf(hv, w[H], gf); gg = fmaf(hv, w[2 * H], gg); go = fmaf(hv, w[3 * H], go);
+            }
+            float* ps = s_part + (size_t)(ksl - 1) * H4;
+            ps[j] = gi; ps[H + j] = gf; ps[2 * H + j] = gg; ps[3 * H + j] = go;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; lead && j < H; j += 256) {
         float gi = lstm_b[j], gf = lstm_b[H + j], gg = lstm_b[2 * H + j], go = lstm_b[3 * H + j];
-        for (int i = 0; i < IN; ++i) {
+        for (int i = 0; i < IN; i += 4) {
             const float xv = s_x[i];
             const float* w = wihT + (size_t)i * H4 + j;
             gi = fmaf(xv, w[0], gi); gf = fmaf(xv, w[H], gf); gg = fmaf(xv, w[2 * H], gg); go = fmaf(xv, w[3 * H], go);
         }
-        for (int i = 0; i < H; ++i) {
+        for (int i = 0; i < H; i += 4) {
             const float hv = s_h[i];
             const float* w = whhT + (size_t)i * H4 + j;
             gi = fmaf(hv, w[0], gi); gf = fmaf(hv, w[H], gf); gg = fmaf(hv, w[2 * H], gg); go = fmaf(hv, w[3 * H], go);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float* ps = s_part + (size_t)q * H4;
+            gi += ps[j]; gf += ps[H + j]; gg += ps[2 * H + j]; go += ps[3 * H + j];
         }
         gi = sigmoidf_(gi); gf = sigmoidf_(gf); gg = tanhf(gg); go = sigmoidf_(go);
         const float c1 = gf * c_prev[(size_t)n * H + j] + gi * gg;
@@ -529,7 +559,7 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
     }
     __syncthreads();
     // posterior update from the cell state
-    for (int t = tid; t < 2 * L; t += 256) {
+    for (int t = tid; lead && t < 2 * L; t += 256) {
         const int l = t % L;
         const bool is_lv = t >= L;
         const float* w = (is_lv ? wvT : wmT) + l;
@@ -550,8 +580,9 @@ hipError_t launch_refine_head(hipStream_t st, const float* feat, int N, int PL, 
                               float* d_mean, float* d_logvar)
 {
     if (256 % C != 0) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(C + (H + 4 * L) + H + H + 256) * sizeof(float);
-    hipLaunchKernelGGL(refine_head_kernel, dim3(N), dim3(256), lds, st, feat, PL, C, H, L, mlp_wT, mlp_b, wihT, whhT,
+    if ((H + 4 * L) % 4 != 0 || H % 4 != 0) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(C + (H + 4 * L) + H + H + 256 + 3 * 4 * H) * sizeof(float);
+    hipLaunchKernelGGL(refine_head_kernel, dim3(N), dim3(1024), lds, st, feat, PL, C, H, L, mlp_wT, mlp_b, wihT, whhT,
                        lstm_b, wmT, bm, wvT, bv, latent, h_prev, c_prev, h_out, c_out, pm, plv, sv_pooled, sv_s,
                        sv_gates, sv_xin, d_mean, d_logvar);
     return hipGetLastError();
