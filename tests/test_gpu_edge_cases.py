@@ -1,0 +1,72 @@
+"""Edge cases of the hot path against the CPU oracle on the same seeded inputs (reference semantics:
+lib/modeling/iodine.py): one slot, the maximum slot count the pixel kernels are instantiated for, a single refinement
+iteration, batch of one, layer-norms switched off (ARCH.LAYERNORM, iodine.py:376-395), another likelihood sigma
+(ARCH.SIGMA, iodine.py:661-666), odd layer counts, and unsupported configurations failing loudly."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from iodine_amd import synth
+from oracle import iodine_oracle as O
+from util import make_hip_model, rel_err, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _case(arch, B, seed):
+    pn = synth.make_params(O.param_shapes(arch), seed=seed, dec_gain=3.0, posterior_scale=0.05)
+    params = {k: torch.from_numpy(v) for k, v in pn.items()}
+    imgs, _ = synth.make_images(B, arch.img_size, seed=seed + 1, kind='blobs')
+    x = torch.from_numpy(imgs)
+    eps = torch.from_numpy(synth.make_eps(arch.iters, B, arch.slots, arch.dim_latent, seed=seed + 2))
+    return params, x, eps
+
+
+CASES = {
+    'one_slot': (dataclasses.replace(O.tiny_arch(slots=1, iters=2)), 3),
+    'twelve_slots': (dataclasses.replace(O.tiny_arch(slots=12, iters=2)), 2),
+    'one_iteration_batch_one': (dataclasses.replace(O.tiny_arch(slots=3, iters=1)), 1),
+    'no_layernorm': (dataclasses.replace(O.tiny_arch(slots=3, iters=2), layernorm=False), 2),
+    'sigma_0p3': (dataclasses.replace(O.tiny_arch(slots=4, iters=2), sigma=0.3), 2),
+    'deeper_stacks_32px': (O.tiny_arch(slots=2, iters=2, img_size=32, ref_layers=3, dec_layers=3), 2),
+    'dsprites_k2_t1': (O.dsprites_arch(slots=2, iters=1), 1),
+}
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_reconstruct_and_train_step_match_oracle(name):
+    arch, B = CASES[name]
+    params, x, eps = _case(arch, B, seed=100 + sorted(CASES).index(name))
+    ref = O.reconstruct(x, eps, params, arch)
+    m = make_hip_model(arch, params)
+    pred, mask, mean = m.reconstruct(x.to(DEV), eps.to(DEV))
+    assert rel_err(m.elbo_terms.cpu()[:, 0], ref['elbos']) < 1e-4
+    assert rel_err(pred.cpu(), ref['pred']) < 2e-4 and rel_err(mask.cpu(), ref['mask']) < 2e-4
+    assert abs(float(mask.sum(1).mean()) - 1.0) < 1e-5                      # masks are a softmax over slots
+    out, grads = O.train_step_grads(x, eps, params, arch)
+    m.zero_grad(set_to_none=True)
+    loss = m(x.to(DEV), eps.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - out['loss'].item()) <= 1e-5 * abs(out['loss'].item())
+    bad = [(n, rel_l2(p.grad.cpu().numpy(), grads[n].numpy())) for n, p in m.named_parameters()
+           if not rel_l2(p.grad.cpu().numpy(), grads[n].numpy()) < 1e-3]
+    assert not bad, bad
+
+
+def test_unsupported_configurations_fail_loudly():
+    from iodine_amd import IODINE
+    from iodine_amd.model import arch_namespace
+    ok = arch_namespace(8, 2, 3, 16, (32, 2, 32), (32, 2))
+    IODINE(ok).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
+    with pytest.raises((RuntimeError, ValueError)):                          # 13 slots: beyond the instantiated kernels
+        IODINE(arch_namespace(8, 2, 13, 16, (32, 2, 32), (32, 2))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
+    with pytest.raises((RuntimeError, ValueError)):                          # channel counts other than 32 / 64
+        IODINE(arch_namespace(8, 2, 3, 16, (48, 2, 32), (48, 2))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
+    m = IODINE(ok).to(DEV)
+    with pytest.raises((RuntimeError, ValueError)):                          # wrong image size for this ARCH
+        m.reconstruct(torch.rand(1, 3, 32, 32, device=DEV))
+    with pytest.raises((RuntimeError, ValueError)):                          # CPU tensors: no fallback path
+        m.reconstruct(torch.rand(1, 3, 16, 16))
