@@ -23,3 +23,7 @@ int main()
     }
     return 0;
 }
+// build + run:  hipcc --offload-arch=gfx950 -O2 -o tools/experiments/tr_b16_probe tools/experiments/tr_b16_probe.hip && ./tools/experiments/tr_b16_probe
+// measured (MI355X): with contiguous 8-byte chunks per lane, lane l of 16-lane group g receives halfwords
+//   64 g + (l & 15) + 16 j, j = 0..3  - i.e. column (l & 15) of the group's 4x16 row-major matrix; in general lane i
+//   supplies row i / 4, columns 4 (i % 4) .. +3 (its own 8-byte chunk, anywhere in LDS) and lane c receives column c.
