@@ -2,7 +2,7 @@
 ``IODINE.forward / reconstruct`` module API.  Heavy imports are lazy so that
 ``iodine_amd.synth`` can be used without the HIP library being built."""
 
-__all__ = ['IODINE', 'synth', 'parallel', 'optim', 'ari', 'checkpoint', 'data']
+__all__ = ['IODINE', 'synth', 'parallel', 'optim', 'ari', 'checkpoint', 'data', 'engine']
 
 
 def __getattr__(name):
