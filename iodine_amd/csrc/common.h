@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -14,6 +15,26 @@ IOD_DEVINL float elu1(float v) { return v > 0.f ? v : expm1f(v); }
 // derivative of ELU expressed through its OUTPUT a = ELU(x): a > 0 ? 1 : a + 1
 IOD_DEVINL float elu1_grad_from_out(float a) { return a > 0.f ? 1.f : a + 1.f; }
 IOD_DEVINL float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+// max over the 64 lanes of a wave, returned to every lane.  DPP steps inside the 16-lane rows, row broadcasts across
+// them and one v_readlane - about a dozen VALU instructions; the __shfl_xor butterfly it replaces is six dependent
+// ds_bpermute round trips (~100 cycles each), which sat on the staging path of every tile chunk.
+IOD_DEVINL float wave_max_f32(float v)
+{
+    auto dpp = [](float x, auto ctrl, auto rmask) {
+        const int r = __builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value,
+                                                  decltype(rmask)::value, 0xf, false);
+        return __int_as_float(r);
+    };
+    using std::integral_constant;
+    v = fmaxf(v, dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{}));     // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{}));     // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{}));    // row_half_mirror
+    v = fmaxf(v, dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{}));    // row_mirror: row max in all 16 lanes
+    v = fmaxf(v, dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}));    // row_bcast:15 into rows 1, 3
+    v = fmaxf(v, dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}));    // row_bcast:31 into rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 
 // Phase timing of the tile / weight-gradient kernels (tools/tile_phase_prof.md; build with IODINE_EXTRA_HIPCC_FLAGS=-DIODINE_TILE_PROF): thread 0 of every
 // block accumulates the s_memtime deltas between phase boundaries and writes them to a per-kernel __device__ buffer

@@ -609,8 +609,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             const f32x4 v = rin[k];
             m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        m = wave_max_f32(m);
         TP_STAMP(1);                                         // [1] wait for the chunk's global loads + max
         if (lane == 0) s_max[wv] = m;
         __syncthreads();                                     // also: every wave is done reading the previous chunk
@@ -1049,8 +1048,7 @@ void conv3x3_tile_f16x3_v3_kernel(const float* __restrict__ in, const uint4* __r
 #pragma unroll
             for (int k = 0; k < NIN; ++k)
                 m = fmaxf(m, fmaxf(fmaxf(fabsf(r[k].x), fabsf(r[k].y)), fmaxf(fabsf(r[k].z), fabsf(r[k].w))));
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            m = wave_max_f32(m);
             if (lane == 0) s_max[slot * 4 + (wv - 4)] = m;
         };
         auto WIN = [&](int q, const f32x4 (&r)[NIN], float scale) {
@@ -1434,8 +1432,7 @@ void dec_out_gemm_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 #pragma unroll
         for (int k = 0; k < NIN; ++k)
             m = fmaxf(m, fmaxf(fmaxf(fabsf(rin[k].x), fabsf(rin[k].y)), fmaxf(fabsf(rin[k].z), fabsf(rin[k].w))));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        m = wave_max_f32(m);
         if (lane == 0) s_max[wv] = m;
         __syncthreads();
         const float mb = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));

@@ -134,8 +134,7 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
             const float4 v = r[k];
             m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        m = wave_max_f32(m);
         if (lane == 0) s_max[wv] = m;
         __syncthreads();                                     // also: every wave is done reading the previous stage
         const float mb = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
@@ -414,11 +413,8 @@ void conv3x3_s2_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __r
                 bsum.x += rd[k][q].x; bsum.y += rd[k][q].y; bsum.z += rd[k][q].z; bsum.w += rd[k][q].w;
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            ma = fmaxf(ma, __shfl_xor(ma, off, 64));
-            md = fmaxf(md, __shfl_xor(md, off, 64));
-        }
+        ma = wave_max_f32(ma);
+        md = wave_max_f32(md);
         if (lane == 0) { s_max[wv] = ma; s_max[4 + wv] = md; }
         __syncthreads();                                   // every wave is also done with the previous tile's planes
         ma = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));

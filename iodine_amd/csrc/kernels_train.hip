@@ -691,11 +691,8 @@ void conv3x3_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __rest
                 bsum.x += rd[k][j].x; bsum.y += rd[k][j].y; bsum.z += rd[k][j].z; bsum.w += rd[k][j].w;
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            ma = fmaxf(ma, __shfl_xor(ma, off, 64));
-            md = fmaxf(md, __shfl_xor(md, off, 64));
-        }
+        ma = wave_max_f32(ma);
+        md = wave_max_f32(md);
         TP_STAMP(0);                                       // [0] tile loads issued, arrived, max
         if (lane == 0) { s_max[wv] = ma; s_max[4 + wv] = md; }
         __syncthreads();                                   // every wave is also done with the previous tile's planes
@@ -956,11 +953,8 @@ void dec_out_wgrad_gemm_f16x3_kernel(const float* __restrict__ a, const float* _
             for (int q = 0; q < 2; ++q)
                 md = fmaxf(md, fmaxf(fmaxf(fabsf(rg[q].x), fabsf(rg[q].y)), fmaxf(fabsf(rg[q].z), fabsf(rg[q].w))));
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            ma = fmaxf(ma, __shfl_xor(ma, off, 64));
-            md = fmaxf(md, __shfl_xor(md, off, 64));
-        }
+        ma = wave_max_f32(ma);
+        md = wave_max_f32(md);
         if (lane == 0) { s_max[wv] = ma; s_max[4 + wv] = md; }
         __syncthreads();                                   // every wave is also done with the previous tile's planes
         ma = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
@@ -1231,11 +1225,8 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
                     md = fmaxf(md, fmaxf(fmaxf(fabsf(r.rd[k][j].x), fabsf(r.rd[k][j].y)), fmaxf(fabsf(r.rd[k][j].z), fabsf(r.rd[k][j].w))));
                     if (real) { bsum.x += r.rd[k][j].x; bsum.y += r.rd[k][j].y; bsum.z += r.rd[k][j].z; bsum.w += r.rd[k][j].w; }
                 }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                ma = fmaxf(ma, __shfl_xor(ma, off, 64));
-                md = fmaxf(md, __shfl_xor(md, off, 64));
-            }
+            ma = wave_max_f32(ma);
+            md = wave_max_f32(md);
             if (lane == 0) { s_max[slot * 8 + pw] = ma; s_max[slot * 8 + 4 + pw] = md; }
         };
         auto WIN = [&](int q, int slot, const Set& r) {
