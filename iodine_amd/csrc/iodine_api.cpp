@@ -480,6 +480,11 @@ int check_ready(iodine_handle* h, int batch)
     if (!h) return IODINE_ERR_INVALID;
     if (!h->params_set) return h->fail(IODINE_ERR_STATE, "iodine_set_params has not been called");
     if (batch < 1) return h->fail(IODINE_ERR_INVALID, "batch must be >= 1");
+    // several kernels index one activation tensor [N][P][C] with 32-bit element offsets
+    const size_t cmax = (size_t)std::max(std::max(h->Cd, h->Cr), 20);
+    if ((size_t)batch * h->K * h->P * cmax >= ((size_t)1 << 31))
+        return h->fail(IODINE_ERR_INVALID, "batch too large for one device: batch * slots * pixels * channels must stay below 2^31 "
+                                           "(shard the images over ranks, iodine_amd.parallel)");
     return IODINE_OK;
 }
 

@@ -70,3 +70,6 @@ def test_unsupported_configurations_fail_loudly():
         m.reconstruct(torch.rand(1, 3, 32, 32, device=DEV))
     with pytest.raises((RuntimeError, ValueError)):                          # CPU tensors: no fallback path
         m.reconstruct(torch.rand(1, 3, 16, 16))
+    big = IODINE(arch_namespace(64, 5, 7, 128, (64, 4, 256), (64, 4))).to(DEV)
+    with pytest.raises(RuntimeError, match='batch too large'):               # 32-bit element offsets: fail, do not wrap
+        big.reconstruct(torch.empty(300, 3, 128, 128, device=DEV))
