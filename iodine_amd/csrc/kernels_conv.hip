@@ -1197,7 +1197,7 @@ void conv3x3_tile_f16x3_v3_kernel(const float* __restrict__ in, const uint4* __r
                 r.w = 0x00020000;
                 return r;
             };
-            {
+            if (!(flags & 16)) {                                 // (timing experiment, conv_ablate: 16 = skip the epilogue)
                 const i32x4_ rsrc_out = make_rsrc(out + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
                 unsigned voff[2];
 #pragma unroll
