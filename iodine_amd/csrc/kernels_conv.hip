@@ -615,10 +615,10 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         __syncthreads();                                     // also: every wave is done reading the previous chunk
         TP_STAMP(2);                                         // [2] barrier 1
         const float mb = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-        const int e = (int)((__float_as_uint(mb) >> 23) & 0xffu) - 127;      // floor(log2(mb)) for normal mb
-        int se = 12 - e;                                     // mb * 2^se in [2^12, 2^13)
-        se = se > 100 ? 100 : (se < -100 ? -100 : se);
-        const float scale = (mb > 0.f && mb < 3.0e38f) ? __uint_as_float((unsigned)(127 + se) << 23) : 1.f;
+        // power-of-two scale with hysteresis (tile_scale: keep the current one while max * scale stays in [2^9, 2^14.5),
+        // else renormalise to [2^12, 2^13)): most chunks of a tile then share a scale and the 64 accumulator multiplies of
+        // a rescale are rare
+        const float scale = tile_scale(mb, cur_scale);
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
             const int idx = tid + k * 256;
