@@ -131,8 +131,10 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * "profile" (1: bracket every kernel launch with HIP events on the launch stream),
  * "conv_precision" (3x3 convs of the decoder and refinement stacks: 0 = exact fp32 MFMA, 1 = fp32 operands split into
  * fp16 hi+lo, 3 fp16 MFMAs, fp32 accumulate -- default),
- * "conv_variant" (split-fp16 stride-1 conv: 1 = one tile per block, two blocks per CU -- default; 3 = warp-specialised
- * persistent kernel, experimental),
+ * "conv_variant" (split-fp16 stride-1 conv: 1 = one tile per 4-wave block, two blocks per CU -- default; 3 = warp-specialised
+ * persistent kernel, 4 = one tile per 8-wave block, four waves per SIMD; both experimental, same results bit for bit),
+ * "zigzag" (1 -- default: odd decoder layers walk their tiles backwards so that a launch starts on what the previous one
+ * wrote last; 0 = every launch in ascending order; results identical),
  * "wgrad_ws" (split-fp16 64->64 / 32->32 weight gradient: 2 = warp-specialised, natural-order staging + transposing LDS
  * reads -- default; 1 = warp-specialised with transposing stagers; 0 = one-role kernel).  All variants compute the same
  * arithmetic; the non-default ones exist for same-box A/B timing (tools/ab_bench.py). */

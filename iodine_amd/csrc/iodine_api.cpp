@@ -80,6 +80,7 @@ struct iodine_handle {
     std::vector<float*> dec_wf16, dec_wb16, dec_wmeta;   // split-fp16 packs (+ {scale, 1/scale, scale_b, 1/scale_b})
     int precision = 1;                          // 0: exact fp32 MFMA, 1: 3 x fp16 MFMA split (fp32-class accuracy)
     int wgrad_ws = 2;                           // decoder 64->64 weight gradient: 0 one-role kernel, 1 warp-specialised (transposing stagers + v_alignbit), 2 warp-specialised with ds_read_b64_tr_b16
+    int zigzag = 1;                             // odd decoder layers walk the tiles backwards (Infinity Cache reuse)
     int variant = 1;                            // split-fp16 tile conv: 1 = one tile per block (2 blocks/CU), 3 = warp-specialised persistent (experimental)
     float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr, *dec_out_w16 = nullptr, *dec_out_meta = nullptr;
     std::vector<float*> ref_w, ref_b;
@@ -105,7 +106,7 @@ struct iodine_handle {
 namespace {
 
 hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, const void* wpk, const float* wmeta,
-                      const float* bias, const float* aux, float* out, int N, int S, int cin, int cout, int epi);
+                      const float* bias, const float* aux, float* out, int N, int S, int cin, int cout, int epi, int layer);
 
 #define HIPCHK(h, expr)                                                                          \
     do {                                                                                         \
@@ -134,10 +135,16 @@ hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, c
     } while (0)
 
 hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, const void* wpk, const float* wmeta,
-                      const float* bias, const float* aux, float* out, int N, int S, int cin, int cout, int epi)
+                      const float* bias, const float* aux, float* out, int N, int S, int cin, int cout, int epi, int layer)
 {
     if (h->variant == 3) return launch_conv3x3_tile_f16x3_v3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi);
-    return launch_conv3x3_tile_f16x3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi);
+    // zig-zag: odd decoder layers walk the slot-images backwards (forward pass: l0 writes forwards, layer 1 reads
+    // backwards, layer 2 forwards, ...; backward pass the same by layer), so a launch starts on the part of its input
+    // that the previous launch wrote last - still in the 256 MiB Infinity Cache - instead of the part written first.
+    // Tiles are independent: results do not depend on the order.  Measured -0.3 % on the cfg3 step (same-box A/B).
+    const int rev = h->zigzag ? (layer & 1) : 0;
+    if (h->variant == 4) return launch_conv3x3_tile8_f16x3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi, rev);
+    return launch_conv3x3_tile_f16x3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi, rev);
 }
 
 template <typename T>
@@ -330,7 +337,7 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N)
     for (int l = 1; l < h->Dd; ++l) {
         if (h->precision == 1)
             PROF(h, st, "conv_tile_fwd", conv_f16x3(h, st, b.act[l - 1], h->dec_wf16[l], h->dec_wmeta[l], h->dec_b[l],
-                                                    nullptr, b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
+                                                    nullptr, b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU, l));
         else
             PROF(h, st, "conv_tile_fwd", launch_conv3x3_tile(st, b.act[l - 1], h->dec_wf[l], h->dec_b[l], nullptr,
                                                              b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
@@ -396,7 +403,7 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         }
         if (h->precision == 1)
             PROF(h, st, "conv_tile_dgrad", conv_f16x3(h, st, b.dpre[cur], h->dec_wb16[l], h->dec_wmeta[l] + 2, nullptr,
-                                                      b.act[l - 1], b.dpre[cur ^ 1], N, h->S, Cd, Cd, EPI_MUL_ELUGRAD));
+                                                      b.act[l - 1], b.dpre[cur ^ 1], N, h->S, Cd, Cd, EPI_MUL_ELUGRAD, l));
         else
             PROF(h, st, "conv_tile_dgrad", launch_conv3x3_tile(st, b.dpre[cur], h->dec_wb[l], nullptr, b.act[l - 1],
                                                                b.dpre[cur ^ 1], N, h->S, Cd, Cd, EPI_MUL_ELUGRAD));
@@ -678,8 +685,9 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "stop_after_iters")) { h->stop_after = (int)value; return IODINE_OK; }
     if (!strcmp(key, "profile")) { h->profile = value != 0; return IODINE_OK; }
     if (!strcmp(key, "wgrad_ws")) { h->wgrad_ws = (int)value; return IODINE_OK; }   // 0 one-role, 1 ws + alignbit, 2 ws + transposing LDS reads
+    if (!strcmp(key, "zigzag")) { h->zigzag = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {
-        if (value != 1 && value != 3) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1 or 3");
+        if (value != 1 && value != 3 && value != 4) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1, 3 or 4");
         h->variant = (int)value;
         return IODINE_OK;
     }
@@ -983,7 +991,7 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, c
         if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(s2 f16x3): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
         return IODINE_OK;
     }
-    if (mode == 2 || mode == 4) {          // split-fp16 tile kernels (4 = warp-specialised persistent variant)
+    if (mode == 2 || mode == 4 || mode == 7) {   // split-fp16 tile kernels (4 = warp-specialised persistent, 7 = eight-wave form)
         float* meta = nullptr;
         const size_t bytes = (size_t)(cin_pad / 16) * 9 * 2 * 2 * cout * 16;
         if (hipMalloc((void**)&wpk, bytes + 64) != hipSuccess) return IODINE_ERR_HIP;
@@ -991,7 +999,8 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, c
         hipError_t e2 = launch_pack_conv_weights_f16(st, w, w_o, w_i, cin_pad, cout, tflip, meta, wpk);
         if (e2 == hipSuccess)
             e2 = mode == 2 ? launch_conv3x3_tile_f16x3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi)
-                           : launch_conv3x3_tile_f16x3_v3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi);
+                 : mode == 4 ? launch_conv3x3_tile_f16x3_v3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi)
+                             : launch_conv3x3_tile8_f16x3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
         (void)hipFree(wpk);
         if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(f16x3): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }

@@ -497,7 +497,7 @@ template <int CIN, int COUT, int EPI>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
                                const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
-                               int S, int tiles)
+                               int S, int tiles, int rev)
 {
     constexpr int NCHUNK = CIN / 16;
     constexpr int NT = COUT / 32;
@@ -519,7 +519,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     const int lane = tid & 63, wv = tid >> 6, kh = lane >> 5, li = lane & 31;
     const int prow = li >> 4, pcol = li & 15;
 
-    int bid = blockIdx.x;
+    int bid = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;    // zig-zag launch order, see conv_f16x3()
     const int tx = bid % tiles; bid /= tiles;
     const int ty = bid % tiles;
     const int n = bid / tiles;
@@ -557,10 +557,17 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         const int gy = ty * 16 - 1 + px / HALO, gx = tx * 16 - 1 + px % HALO;
         const bool ok = idx < NPX * 4 && gy >= 0 && gy < S && gx >= 0 && gx < S;
         goff[k] = ok ? (unsigned)(((gy * S + gx) * CIN + cq * 4) * 4) : 0x80000000u;
+#ifdef IODINE_ABL_NOINLOAD
+        goff[k] = 0x80000000u;
+#endif
     }
     unsigned woff[NW];
 #pragma unroll
     for (int k = 0; k < NW; ++k) woff[k] = tid + k * 256 < W_U4 ? (unsigned)((tid + k * 256) * 16) : 0x80000000u;
+#ifdef IODINE_ABL_NOWLOAD
+#pragma unroll
+    for (int k = 0; k < NW; ++k) woff[k] = 0x80000000u;
+#endif
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -674,6 +681,11 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         constexpr int tap = decltype(tapc)::value;
         constexpr int aoff = ((tap / 3) * HALO + (tap % 3)) * PXS;
         constexpr int boff = tap * 4 * COUT * 16;
+#ifdef IODINE_ABL_NOLDSREAD
+        asm volatile("" : "+v"(f.ah[0]), "+v"(f.al[0]), "+v"(f.ah[1]), "+v"(f.al[1]), "+v"(f.bh[0]), "+v"(f.bl[0]));
+        if constexpr (NT == 2) asm volatile("" : "+v"(f.bh[1]), "+v"(f.bl[1]));
+        return;
+#endif
         IOD_DSR128(f.ah[0], a_addr0, aoff);
         IOD_DSR128(f.al[0], a_addr0, aoff + 32);
         IOD_DSR128(f.ah[1], a_addr1, aoff);
@@ -687,6 +699,11 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     };
 #undef IOD_DSR128
     auto MMA = [&](const Frag& f) {
+#ifdef IODINE_ABL_NOMFMA
+        asm volatile("" :: "v"(f.ah[0]), "v"(f.al[0]), "v"(f.ah[1]), "v"(f.al[1]), "v"(f.bh[0]), "v"(f.bl[0]));
+        if constexpr (NT == 2) asm volatile("" :: "v"(f.bh[1]), "v"(f.bl[1]));
+        return;
+#endif
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -715,6 +732,9 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     auto compute = [&]() {
         TP_STAMP(5);                                         // [5] issue of the next prefetches (between commit and compute)
         Frag f0, f1;
+#ifdef IODINE_ABL_NOLDSREAD
+        f0 = Frag{}; f1 = Frag{};
+#endif
         LOADF(integral_constant<int, 0>{}, f0);
         IOD_STEP(0, f0, f1) IOD_STEP(1, f1, f0) IOD_STEP(2, f0, f1) IOD_STEP(3, f1, f0) IOD_STEP(4, f0, f1)
         IOD_STEP(5, f1, f0) IOD_STEP(6, f0, f1) IOD_STEP(7, f1, f0) IOD_STEP(8, f0, f1)
@@ -831,7 +851,11 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
                     const int soff = (nt * 32 + 8 * g4) * 4;
                     // (the s_nop covers the ">64-bit store data, then VALU write of those VGPRs" hazard that hipcc's
                     // hazard recognizer would handle for its own stores but cannot see inside inline asm)
+#ifdef IODINE_ABL_NOSTORE
+                    asm volatile("" :: "v"(v), "v"(voff[mt]), "s"(rsrc_out), "s"(soff) : "memory");
+#else
                     asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v), "v"(voff[mt]), "s"(rsrc_out), "s"(soff) : "memory");
+#endif
                 }
     }
     TP_STAMP(7);                                             // [7] epilogue (issue of the stores)
@@ -842,7 +866,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 
 template <int CIN, int COUT, int EPI>
 static hipError_t launch_tile_f16x3_inst(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
-                                         const float* bias, const float* aux, float* out, int N, int S)
+                                         const float* bias, const float* aux, float* out, int N, int S, int rev)
 {
     constexpr size_t lds = (size_t)(18 * 18 + 1) * 80 + (size_t)9 * 2 * 2 * COUT * 16 + 16;
     static bool attr_set = false;
@@ -854,7 +878,7 @@ static hipError_t launch_tile_f16x3_inst(hipStream_t st, const float* in, const 
     }
     const int tiles = S / 16;
     hipLaunchKernelGGL((conv3x3_tile_f16x3_kernel<CIN, COUT, EPI>), dim3(N * tiles * tiles), dim3(256), lds, st, in,
-                       reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, S, tiles);
+                       reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, S, tiles, rev);
 #ifdef IODINE_TILE_PROF
     {
         const int nb = std::min(N * tiles * tiles, TP_MAXBLK);
@@ -876,11 +900,11 @@ static hipError_t launch_tile_f16x3_inst(hipStream_t st, const float* in, const 
 
 hipError_t launch_conv3x3_tile_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                      const float* bias, const float* aux, float* out, int N, int S, int cin, int cout,
-                                     int epi)
+                                     int epi, int rev)
 {
     if (S % 16 != 0) return hipErrorInvalidValue;
 #define T16_CASE(CI, CO, EP) \
-    if (cin == CI && cout == CO && epi == EP) return launch_tile_f16x3_inst<CI, CO, EP>(st, in, wpk, wmeta, bias, aux, out, N, S);
+    if (cin == CI && cout == CO && epi == EP) return launch_tile_f16x3_inst<CI, CO, EP>(st, in, wpk, wmeta, bias, aux, out, N, S, rev);
     T16_CASE(64, 64, EPI_BIAS_ELU) T16_CASE(64, 64, EPI_MUL_ELUGRAD)
     T16_CASE(32, 32, EPI_BIAS_ELU) T16_CASE(32, 32, EPI_MUL_ELUGRAD)
 #undef T16_CASE
