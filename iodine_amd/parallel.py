@@ -24,9 +24,27 @@ def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
+def _shared_flat_view(grads):
+    """If the gradients are consecutive slices of ONE storage (the layout IODINE's backward hands to autograd: views of
+    the flat buffer iodine_train_backward fills), return that storage range as a 1-D tensor; else None."""
+    g0 = grads[0]
+    if not all(g.is_contiguous() and g.dtype == g0.dtype and g.device == g0.device for g in grads):
+        return None
+    base = g0.untyped_storage().data_ptr()
+    order = sorted(grads, key=lambda g: g.storage_offset())          # any parameter order, as long as the slices tile a range
+    start = off = order[0].storage_offset()
+    for g in order:
+        if g.untyped_storage().data_ptr() != base or g.storage_offset() != off:
+            return None
+        off += g.numel()
+    return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(g0.untyped_storage(), start, (off - start,))
+
+
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], world: int = None, group=None) -> None:
-    """Average .grad over ranks through one flat buffer (== ``loss.mean()`` over DataParallel replicas,
-    lib/engine/train.py:61).  Works with any backend (nccl = RCCL on ROCm, gloo on CPU)."""
+    """Average .grad over ranks with ONE all-reduce (== ``loss.mean()`` over DataParallel replicas,
+    lib/engine/train.py:61).  Works with any backend (nccl = RCCL on ROCm, gloo on CPU).  When the gradients already
+    live back to back in one buffer (they do after IODINE.backward) the collective runs on that buffer in place;
+    otherwise they are gathered into a flat buffer and scattered back."""
     if not dist.is_available() or not dist.is_initialized():
         return
     world = world or dist.get_world_size(group)
@@ -35,14 +53,20 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], world: int = None,
     ps = [p for p in params if p.grad is not None]
     if not ps:
         return
-    flat = torch.cat([p.grad.reshape(-1) for p in ps])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat.div_(world)
-    off = 0
-    for p in ps:
-        n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
-        off += n
+    with torch.no_grad():
+        flat = _shared_flat_view([p.grad for p in ps])
+        if flat is not None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            flat.div_(world)
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world)
+        off = 0
+        for p in ps:
+            n = p.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
 
 
 def allreduce_mean(t: torch.Tensor, world: int = None, group=None) -> torch.Tensor:

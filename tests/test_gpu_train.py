@@ -99,3 +99,20 @@ def test_sgd_step_changes_next_loss():
     l1 = _train_step(m, x, eps).item()
     assert l1 != l0 and np.isfinite(l1)
     assert l1 < l0                                                   # one Adam step on the same batch lowers the loss
+
+
+def test_gradients_form_one_flat_buffer():
+    """after zero_grad(set_to_none) + backward every .grad is a slice of the one buffer iodine_train_backward filled, so
+    the data-parallel all-reduce (iodine_amd.parallel.allreduce_gradients) runs on it in place, without gather/scatter"""
+    from iodine_amd import parallel
+    g = load_golden('tiny')
+    arch, params, x, eps, _ = golden_setup(g)
+    m = make_hip_model(arch, params)
+    m.zero_grad(set_to_none=True)
+    m(x.to(DEV), eps.to(DEV)).backward()
+    grads = [p.grad for p in m.parameters()]
+    flat = parallel._shared_flat_view(grads)
+    assert flat is not None and flat.numel() == sum(p.numel() for p in m.parameters())
+    before = [gr.clone() for gr in grads]
+    flat.mul_(2.0)                                                   # the view aliases the gradients
+    assert all(torch.equal(gr, 2.0 * b) for gr, b in zip(grads, before))

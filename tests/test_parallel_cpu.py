@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, flat_layout=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from oracle import iodine_oracle as O
@@ -32,8 +32,17 @@ def _worker(rank, world, port, ret):
     lo, hi = parallel.shard_range(x.shape[0], rank, world)
     out, grads = O.train_step_grads(x[lo:hi], eps[:, lo:hi].contiguous(), params, arch)
     ps = {k: torch.nn.Parameter(v.clone()) for k, v in params.items()}
-    for k, p in ps.items():
-        p.grad = grads[k].clone()
+    if flat_layout:                      # the layout IODINE.backward produces: consecutive views of one buffer
+        flat = torch.cat([grads[k].reshape(-1) for k in ps])
+        off = 0
+        for k, p in ps.items():
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        assert parallel._shared_flat_view([p.grad for p in ps.values()]) is not None
+    else:
+        for k, p in ps.items():
+            p.grad = grads[k].clone()
+        assert parallel._shared_flat_view([p.grad for p in ps.values()]) is None
     parallel.allreduce_gradients(ps.values(), world)
     loss = parallel.allreduce_mean(out['loss'].detach().reshape(1), world)
     if rank == 0:
@@ -42,11 +51,15 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_average_equals_full_batch():
+import pytest
+
+
+@pytest.mark.parametrize('flat_layout', [False, True])
+def test_two_rank_gradient_average_equals_full_batch(flat_layout):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, flat_layout), nprocs=world, join=True)
     g = load_golden('tiny')
     ref_loss = float(g['f32.train.loss'])
     assert abs(ret['loss'] - ref_loss) <= 1e-5 * abs(ref_loss)
