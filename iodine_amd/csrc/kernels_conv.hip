@@ -1132,6 +1132,11 @@ void conv3x3_tile_f16x3_v3_kernel(const float* __restrict__ in, const uint4* __r
     }
 
     // ---------------------------------------------------------------------- CONSUMER ----
+    // The step loop is software-pipelined ACROSS the barrier: once the fragments of a step's last tap are in registers the
+    // wave has no LDS reads of that step left, so it arrives at the barrier first, requests tap 0 of the NEXT step (and the
+    // next scale) behind it, and only then issues the last tap's 12 MFMAs - barrier skew, the scale read and the LDS
+    // latency of the first fragments hide under them instead of leaving the matrix pipe idle at every step boundary.
+    // Nine taps per step alternate the two fragment sets, so consecutive steps start on opposite sets (loop unrolled by 2).
     const int prow = li >> 4, pcol = li & 15;
     f32x16 acc[2][NT];
 #pragma unroll
@@ -1144,67 +1149,78 @@ void conv3x3_tile_f16x3_v3_kernel(const float* __restrict__ in, const uint4* __r
     block_barrier();                                        // P1
     float cur_scale = SCALE(0);
     block_barrier();                                        // P2
+    float sc_next = SCALE(1);                               // scale of chunk 1 (published before P2)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     struct Frag { f16x8 ah[2], al[2], bh[NT], bl[NT]; };
-    for (int q = 0; q < nq; ++q) {
-        const int sl = q % 3;
-        const float sc_next = SCALE((sl + 1) % 3);
-        // Fragment reads are issued as inline-asm ds_read_b128 (invisible to hipcc's wait-count pass, which otherwise
-        // drains lgkmcnt(0) - including the reads just issued for the NEXT tap - in front of every MFMA group).
-        // LDS returns in order, so "lgkmcnt(8)" after issuing the next tap's 4 + 2*NT reads retires exactly the
-        // current tap's fragments.
-        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_b;
-        const unsigned a_addr0 = lds_base + (q & 1) * IN_BYTES + ((4 * cwv + prow) * HALO + pcol) * PXS + kh * 16;
-        const unsigned a_addr1 = a_addr0 + 2 * HALO * PXS;
-        const unsigned b_addr = lds_base + 2 * IN_BYTES + sl * W_BYTES + (kh * COUT + li) * 16;
+    constexpr int NRD = 4 + 2 * NT;                         // ds_read_b128 per tap
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_b;
+    const unsigned a_lane = lds_base + ((4 * cwv + prow) * HALO + pcol) * PXS + kh * 16;
+    const unsigned b_lane = lds_base + 2 * IN_BYTES + (kh * COUT + li) * 16;
+    const unsigned m_addr = lds_base + 2 * IN_BYTES + 3 * W_BYTES;                       // s_max[3][4]
 #define IOD_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-        auto LOADF = [&](auto tapc, Frag& f) {
-            constexpr int tap = decltype(tapc)::value;
-            constexpr int aoff = ((tap / 3) * HALO + (tap % 3)) * PXS;
-            constexpr int boff = tap * 4 * COUT * 16;
-            IOD_DSR128(f.ah[0], a_addr0, aoff);
-            IOD_DSR128(f.al[0], a_addr0, aoff + 32);
-            IOD_DSR128(f.ah[1], a_addr1, aoff);
-            IOD_DSR128(f.al[1], a_addr1, aoff + 32);
-            IOD_DSR128(f.bh[0], b_addr, boff);
-            IOD_DSR128(f.bl[0], b_addr, boff + 2 * COUT * 16);
-            if constexpr (NT == 2) {
-                IOD_DSR128(f.bh[1], b_addr, boff + 512);
-                IOD_DSR128(f.bl[1], b_addr, boff + 2 * COUT * 16 + 512);
-            }
-        };
-#undef IOD_DSR128
-        auto MMA = [&](const Frag& f) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[nt], f.al[mt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[nt], f.ah[mt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[nt], f.ah[mt], acc[mt][nt], 0, 0, 0);
-        };
-        Frag f0, f1;
-        using std::integral_constant;
+    // one fragment read of tap `tapc` (i = 0 .. NRD-1) / one MFMA of a tap (i = 0 .. NMF-1, same order as the MMA of the
+    // one-tile-per-block kernel: results are bitwise identical)
+    constexpr int NMF = 6 * NT;
+    auto RD = [](auto ic, auto tapc, Frag& f, unsigned a_addr0, unsigned b_addr) {
+        constexpr int i = decltype(ic)::value, tap = decltype(tapc)::value;
+        constexpr int aoff = ((tap / 3) * HALO + (tap % 3)) * PXS;
+        constexpr int boff = tap * 4 * COUT * 16;
+        const unsigned a_addr1 = a_addr0 + 2 * HALO * PXS;
+        if constexpr (i == 0) IOD_DSR128(f.ah[0], a_addr0, aoff);
+        else if constexpr (i == 1) IOD_DSR128(f.al[0], a_addr0, aoff + 32);
+        else if constexpr (i == 2) IOD_DSR128(f.ah[1], a_addr1, aoff);
+        else if constexpr (i == 3) IOD_DSR128(f.al[1], a_addr1, aoff + 32);
+        else if constexpr (i == 4) IOD_DSR128(f.bh[0], b_addr, boff);
+        else if constexpr (i == 5) IOD_DSR128(f.bl[0], b_addr, boff + 2 * COUT * 16);
+        else if constexpr (i == 6 && NT == 2) IOD_DSR128(f.bh[NT - 1], b_addr, boff + 512);
+        else if constexpr (i == 7 && NT == 2) IOD_DSR128(f.bl[NT - 1], b_addr, boff + 2 * COUT * 16 + 512);
+    };
+    auto MF = [&](auto ic, const Frag& f) {
+        constexpr int i = decltype(ic)::value, term = i / (2 * NT), mt = (i % (2 * NT)) / NT, nt = i % NT;
+        if constexpr (term == 0) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[nt], f.al[mt], acc[mt][nt], 0, 0, 0);
+        else if constexpr (term == 1) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[nt], f.ah[mt], acc[mt][nt], 0, 0, 0);
+        else acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[nt], f.ah[mt], acc[mt][nt], 0, 0, 0);
+    };
+    using std::integral_constant;
+    // a tap: its MFMAs with the NEXT tap's fragment reads slotted in behind the first NRD of them (one LDS instruction per
+    // MFMA gap: the matrix pipe never waits for a block of eight reads to issue)
+    auto TAP = [&](const Frag& fc, Frag& fn, auto tapn, unsigned a_n, unsigned b_n) {
+#define IOD_MR(I)                                                                                              \
+        if constexpr (I < NMF) { MF(integral_constant<int, (I < NMF ? I : 0)>{}, fc); __builtin_amdgcn_sched_barrier(0); }       \
+        if constexpr (I < NRD) { RD(integral_constant<int, I>{}, tapn, fn, a_n, b_n); __builtin_amdgcn_sched_barrier(0); }
+        IOD_MR(0) IOD_MR(1) IOD_MR(2) IOD_MR(3) IOD_MR(4) IOD_MR(5) IOD_MR(6) IOD_MR(7) IOD_MR(8) IOD_MR(9) IOD_MR(10) IOD_MR(11)
+#undef IOD_MR
+    };
 #define IOD_STEP(T, FCUR, FNEXT)                                                                  \
-        if constexpr (T + 1 < 9) LOADF(integral_constant<int, (T + 1 < 9 ? T + 1 : 8)>{}, FNEXT);   \
-        if constexpr (T + 1 < 9) { if (NT == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  \
-                                   else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); }        \
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          \
         __builtin_amdgcn_sched_barrier(0);                                                          \
-        if (!(flags & 1)) MMA(FCUR);                                                                \
+        TAP(FCUR, FNEXT, integral_constant<int, T + 1>{}, a0, bb);
+    auto step_body = [&](int q, Frag& fa, Frag& fb) {
+        const int sl = q % 3;
+        const unsigned a0 = a_lane + (q & 1) * IN_BYTES, bb = b_lane + sl * W_BYTES;
+        IOD_STEP(0, fa, fb) IOD_STEP(1, fb, fa) IOD_STEP(2, fa, fb) IOD_STEP(3, fb, fa)
+        IOD_STEP(4, fa, fb) IOD_STEP(5, fb, fa) IOD_STEP(6, fa, fb) IOD_STEP(7, fb, fa)
+        // tap 8 (fragments in fa): every LDS read of this step has been issued; block_barrier() retires them and arrives
+        block_barrier();
+        f32x4 mraw;                                          // max |x| of chunk q + 2 (published during this step)
+        {
+            const unsigned ma = m_addr + ((sl + 2) % 3) * 16;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(mraw) : "v"(ma));
+        }
         __builtin_amdgcn_sched_barrier(0);
-        LOADF(integral_constant<int, 0>{}, f0);
-        IOD_STEP(0, f0, f1) IOD_STEP(1, f1, f0) IOD_STEP(2, f0, f1) IOD_STEP(3, f1, f0) IOD_STEP(4, f0, f1)
-        IOD_STEP(5, f1, f0) IOD_STEP(6, f0, f1) IOD_STEP(7, f1, f0) IOD_STEP(8, f0, f1)
-#undef IOD_STEP
+        TAP(fa, fb, integral_constant<int, 0>{}, a_lane + ((q + 1) & 1) * IN_BYTES, b_lane + ((q + 1) % 3) * W_BYTES);
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(NRD) : "memory");      // the scale read (older than the fragment reads)
+        asm volatile("" : "+v"(mraw));
+        __builtin_amdgcn_sched_barrier(0);
+        float sc_next2 = 1.f;
+        if (!(flags & 8)) {
+            const float mb = fmaxf(fmaxf(mraw.x, mraw.y), fmaxf(mraw.z, mraw.w));
+            const int e = (int)((__float_as_uint(mb) >> 23) & 0xffu) - 127;
+            int se = 12 - e;
+            se = se > 100 ? 100 : (se < -100 ? -100 : se);
+            sc_next2 = (mb > 0.f && mb < 3.0e38f) ? __uint_as_float((unsigned)(127 + se) << 23) : 1.f;
+        }
         if (q % NCHUNK == NCHUNK - 1) {
             int n, ty, tx;
             tile_coords(q, n, ty, tx);
@@ -1302,8 +1318,23 @@ void conv3x3_tile_f16x3_v3_kernel(const float* __restrict__ in, const uint4* __r
                     for (int e = 0; e < 16; ++e) acc[mt][nt][e] *= r;
             cur_scale = sc_next;
         }
-        block_barrier();
+        sc_next = sc_next2;
+    };
+#undef IOD_STEP
+    Frag f0, f1;
+    {
+        using Z = integral_constant<int, 0>;
+        RD(integral_constant<int, 0>{}, Z{}, f0, a_lane, b_lane); RD(integral_constant<int, 1>{}, Z{}, f0, a_lane, b_lane);
+        RD(integral_constant<int, 2>{}, Z{}, f0, a_lane, b_lane); RD(integral_constant<int, 3>{}, Z{}, f0, a_lane, b_lane);
+        RD(integral_constant<int, 4>{}, Z{}, f0, a_lane, b_lane); RD(integral_constant<int, 5>{}, Z{}, f0, a_lane, b_lane);
+        RD(integral_constant<int, 6>{}, Z{}, f0, a_lane, b_lane); RD(integral_constant<int, 7>{}, Z{}, f0, a_lane, b_lane);
     }
+    for (int q = 0; q < nq; q += 2) {                       // nq = tiles * NCHUNK is even
+        step_body(q, f0, f1);
+        step_body(q + 1, f1, f0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef IOD_DSR128
     prof_flush(0);
 }
 
