@@ -116,3 +116,34 @@ def test_gradients_form_one_flat_buffer():
     before = [gr.clone() for gr in grads]
     flat.mul_(2.0)                                                   # the view aliases the gradients
     assert all(torch.equal(gr, 2.0 * b) for gr, b in zip(grads, before))
+
+
+def test_rccl_allreduce_on_flat_gradient_buffer():
+    """RCCL (backend 'nccl') accepts the in-place flat view of the gradients: one-rank group on this GPU, SUM all-reduce
+    leaves the values unchanged.  The two-rank arithmetic is covered on CPU by tests/test_parallel_cpu.py (gloo)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from iodine_amd import parallel
+    g = load_golden('tiny')
+    arch, params, x, eps, _ = golden_setup(g)
+    m = make_hip_model(arch, params)
+    m.zero_grad(set_to_none=True)
+    m(x.to(DEV), eps.to(DEV)).backward()
+    grads = [p.grad for p in m.parameters()]
+    before = [gr.clone() for gr in grads]
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        flat = parallel._shared_flat_view(grads)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(1)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(grads, before))
+        parallel.allreduce_gradients(m.parameters())            # world 1: no-op path
+        assert all(torch.equal(a, b) for a, b in zip(grads, before))
+    finally:
+        dist.destroy_process_group()
