@@ -62,7 +62,7 @@ struct ProfCat { std::string name; std::vector<std::pair<hipEvent_t, hipEvent_t>
 struct iodine_handle {
     iodine_config cfg;
     std::string err;
-    bool profile = false;
+    int profile = 0;                            // 0 off, 1 the dominant conv kernels ("conv_tile_*") only, 2 every category
     std::vector<ProfCat> prof;
     ProfCat* prof_cat(const char* name) {
         for (auto& c : prof) if (c.name == name) return &c;
@@ -119,7 +119,7 @@ hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, c
 #define PROF(h, st, cat, expr)                                                       \
     do {                                                                             \
         hipEvent_t e0_ = nullptr, e1_ = nullptr;                                     \
-        if ((h)->profile) {                                                          \
+        if ((h)->profile > 1 || ((h)->profile == 1 && !strncmp(cat, "conv_tile_", 10))) {    \
             ProfCat* pc_ = (h)->prof_cat(cat);                                       \
             if (pc_->used == pc_->ev.size()) {                                       \
                 hipEvent_t a_, b_;                                                   \
@@ -683,7 +683,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
 {
     if (!h || !key) return IODINE_ERR_INVALID;
     if (!strcmp(key, "stop_after_iters")) { h->stop_after = (int)value; return IODINE_OK; }
-    if (!strcmp(key, "profile")) { h->profile = value != 0; return IODINE_OK; }
+    if (!strcmp(key, "profile")) { h->profile = (int)value; return IODINE_OK; }
     if (!strcmp(key, "wgrad_ws")) { h->wgrad_ws = (int)value; return IODINE_OK; }   // 0 one-role, 1 ws + alignbit, 2 ws + transposing LDS reads
     if (!strcmp(key, "zigzag")) { h->zigzag = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {

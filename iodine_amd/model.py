@@ -264,7 +264,8 @@ class IODINE(nn.Module):
             _lib.check(_lib.lib().iodine_set_option(self._handle, key.encode(), float(value)), self._handle)
 
     def profile_read(self, category: str, reset: bool = True):
-        """(total_ms, launches) of one kernel category measured with HIP events (set_option('profile', 1))."""
+        """(total_ms, launches) of one kernel category measured with HIP events (set_option('profile', 2); level 1 brackets the
+        dominant ``conv_tile_*`` launches only)."""
         tot, cnt = C.c_double(), C.c_longlong()
         _lib.check(_lib.lib().iodine_profile_read(self._handle, category.encode(), C.byref(tot), C.byref(cnt),
                                                   int(reset)), self._handle)
