@@ -115,3 +115,25 @@ def test_ari_known_answers():
         assert abs(A.compute_ari(g[f'rand{i}.table']) - float(g[f'rand{i}.ari'])) < 1e-12
         i += 1
     assert i >= 8
+
+
+@pytest.mark.parametrize('name,tag,dtype,tol', [('traj_tiny', 'f64', torch.float64, 1e-9), ('traj_tiny', 'f32', torch.float32, 2e-5),
+                                                ('traj_cfg1', 'f32', torch.float32, 5e-5)])
+def test_training_trajectory_matches_reference(name, tag, dtype, tol):
+    """four steps of lib/engine/train.py:58-65 with the reference's Adam (lib/solver/build.py:5-16): the oracle's
+    gradients driven through torch.optim.Adam reproduce the reference's losses and final parameters"""
+    from util import check_trajectory_params, trajectory_setup
+    tr, arch, params, x, eps = trajectory_setup(name, dtype)
+    ps = {k: torch.nn.Parameter(v.clone()) for k, v in params.items()}
+    opt = torch.optim.Adam(ps.values(), lr=float(tr['meta_lr']), weight_decay=0.0)
+    losses = []
+    for e in eps:
+        out, grads = O.train_step_grads(x, e, {k: p.detach() for k, p in ps.items()}, arch)
+        opt.zero_grad()
+        for k, p in ps.items():
+            p.grad = grads[k].to(dtype)
+        opt.step()
+        losses.append(float(out['loss']))
+    ref = tr[f'{tag}.losses']
+    assert np.abs(np.array(losses) - ref).max() <= tol * np.abs(ref).max(), (losses, ref)
+    check_trajectory_params(tr, tag, ps.items(), 1e-5 if dtype == torch.float64 else 0.05)
