@@ -10,6 +10,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define IOD_DEVINL __device__ __forceinline__
 
+// Timing-only ablation hook for tools/helper_cost.py: a library built with -DIODINE_XSKIP_HOOK lets
+// iodine_set_option("xskip", mask) turn the tagged launchers into no-ops (results are then WRONG; the product build has no
+// such option).  Bits: 1 partial-tile reductions, 2 head-backward GEMMs, 4 refine head, 8 pixel passes, 16 broadcast layer
+// forward, 32 broadcast layer backward, 64 pointwise/axpy, 128 output conv forward, 256 output conv data gradient,
+// 512 refinement convs forward, 1024 refinement conv gradients, 2048 output conv weight gradient.
+#ifdef IODINE_XSKIP_HOOK
+extern int g_iod_xskip;
+#define IOD_XSKIP(bit) do { if (g_iod_xskip & (bit)) return hipSuccess; } while (0)
+#else
+#define IOD_XSKIP(bit) do { } while (0)
+#endif
+
 // ELU with alpha = 1 (torch.nn.functional.elu): x > 0 ? x : expm1(x)
 IOD_DEVINL float elu1(float v) { return v > 0.f ? v : expm1f(v); }
 // derivative of ELU expressed through its OUTPUT a = ELU(x): a > 0 ? 1 : a + 1
@@ -206,6 +218,8 @@ hipError_t launch_adam_multi(hipStream_t st, const long long* ptrs, const long l
 hipError_t launch_ari_table(hipStream_t st, const float* mask, const unsigned char* gt, int B, int K, int G, int P,
                             int* table);
 hipError_t launch_pack_dec_out_gemm(hipStream_t st, const float* w, int C, float* meta, void* dst);
+hipError_t launch_dec_out_stream_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
+                                       const float* bias, float* out, int N, int S, int C);
 hipError_t launch_dec_out_gemm_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                      const float* bias, float* out, int N, int S, int C);
 

@@ -80,6 +80,7 @@ struct iodine_handle {
     std::vector<float*> dec_wf16, dec_wb16, dec_wmeta;   // split-fp16 packs (+ {scale, 1/scale, scale_b, 1/scale_b})
     int precision = 1;                          // 0: exact fp32 MFMA, 1: 3 x fp16 MFMA split (fp32-class accuracy)
     int wgrad_ws = 2;                           // decoder 64->64 weight gradient: 0 one-role kernel, 1 warp-specialised (transposing stagers + v_alignbit), 2 warp-specialised with ds_read_b64_tr_b16
+    int out_variant = 1;                        // output conv forward: 1 = streaming (fragments straight from global), 0 = LDS-staged
     int zigzag = 1;                             // odd decoder layers walk the tiles backwards (Infinity Cache reuse)
     int variant = 1;                            // split-fp16 tile conv: 1 = one tile per block (2 blocks/CU), 3 = warp-specialised persistent (experimental)
     float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr, *dec_out_w16 = nullptr, *dec_out_meta = nullptr;
@@ -102,6 +103,10 @@ struct iodine_handle {
 
     int fail(int code, const std::string& m) { err = m; return code; }
 };
+
+#ifdef IODINE_XSKIP_HOOK
+int g_iod_xskip = 0;
+#endif
 
 namespace {
 
@@ -343,7 +348,7 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N)
                                                              b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
     }
     if (h->precision == 1)
-        PROF(h, st, "dec_out", launch_dec_out_gemm_f16x3(st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b,
+        PROF(h, st, "dec_out", (h->out_variant ? launch_dec_out_stream_f16x3 : launch_dec_out_gemm_f16x3)(st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b,
                                                          b.dec_out, N, h->S, h->Cd));
     else
         PROF(h, st, "dec_out", launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, b.dec_out, N, h->S, h->Cd));
@@ -369,6 +374,9 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
     Buffers& b = h->buf;
     const int Cd = h->Cd, Dd = h->Dd;
     int cur = 0, nparts = 0, ncop = 0, nb = 0, rc;
+#ifdef IODINE_XSKIP_HOOK
+    if (!(g_iod_xskip & 256))
+#endif
     PROF(h, st, "dec_out_dgrad", launch_conv3x3_tile(st, b.g, h->dec_out_wb, nullptr, b.act[Dd - 1], b.dpre[cur], N,
                                                      h->S, 4, Cd, EPI_MUL_ELUGRAD));
     if (train_alpha != 0.f) {
@@ -685,6 +693,10 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "stop_after_iters")) { h->stop_after = (int)value; return IODINE_OK; }
     if (!strcmp(key, "profile")) { h->profile = (int)value; return IODINE_OK; }
     if (!strcmp(key, "wgrad_ws")) { h->wgrad_ws = (int)value; return IODINE_OK; }   // 0 one-role, 1 ws + alignbit, 2 ws + transposing LDS reads
+#ifdef IODINE_XSKIP_HOOK
+    if (!strcmp(key, "xskip")) { g_iod_xskip = (int)value; return IODINE_OK; }       // timing-only ablation builds (common.h)
+#endif
+    if (!strcmp(key, "out_variant")) { h->out_variant = value != 0; return IODINE_OK; }
     if (!strcmp(key, "zigzag")) { h->zigzag = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {
         if (value != 1 && value != 3 && value != 4) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1, 3 or 4");

@@ -1587,6 +1587,7 @@ void dec_out_gemm_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 hipError_t launch_dec_out_gemm_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                      const float* bias, float* out, int N, int S, int C)
 {
+    IOD_XSKIP(128);
     if (S % 16 != 0) return hipErrorInvalidValue;
     const int tiles = S / 16;
     if (C == 64) {

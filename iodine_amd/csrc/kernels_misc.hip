@@ -154,6 +154,7 @@ void dec_l0_kernel(const float4* __restrict__ V, const float4* __restrict__ cmap
 
 hipError_t launch_dec_l0(hipStream_t st, const float* V, const float* cmap, float* out, int N, int S, int C)
 {
+    IOD_XSKIP(16);
     const int pc4 = S * S * (C / 4);
     hipLaunchKernelGGL(dec_l0_kernel, dim3((pc4 + 1023) / 1024, N), dim3(256), 0, st, (const float4*)V,
                        (const float4*)cmap, (float4*)out, S, C / 4, pc4);
@@ -303,6 +304,7 @@ __global__ void sum_over_slots_kernel(const float4* __restrict__ dpre, float4* _
 hipError_t launch_l0_reduce(hipStream_t st, const float* dpre, float* rows, float* Rc, int N, int S, int C, float* Dpart,
                             float* Dacc, float alpha, int first)
 {
+    IOD_XSKIP(32);
     const int pc4 = S * S * (C / 4);
     const int per_group = (N + l0_dgroups(N) - 1) / l0_dgroups(N);   // <= 32
     const int Gr = (N + per_group - 1) / per_group;              // groups actually launched
@@ -400,6 +402,7 @@ __global__ void dz_latent_kernel(const float* __restrict__ Rc, const float* __re
 hipError_t launch_dz_latent(hipStream_t st, const float* Rc, const float* wclsT, const float* pm, const float* plv,
                             const float* eps, int N, int L, int C, int use_ln, float* g_pm, float* g_plv, float* latent)
 {
+    IOD_XSKIP(32);
     const int nth = ((L + 63) / 64) * 64;
     hipLaunchKernelGGL(dz_latent_kernel, dim3(N), dim3(nth), 9 * C * sizeof(float), st, Rc, wclsT, pm, plv, eps, L, C,
                        use_ln, g_pm, g_plv, latent);
@@ -579,6 +582,7 @@ hipError_t launch_refine_head(hipStream_t st, const float* feat, int N, int PL, 
                               float* pm, float* plv, float* sv_pooled, float* sv_s, float* sv_gates, float* sv_xin,
                               float* d_mean, float* d_logvar)
 {
+    IOD_XSKIP(4);
     if (256 % C != 0) return hipErrorInvalidValue;
     if ((H + 4 * L) % 4 != 0 || H % 4 != 0) return hipErrorInvalidValue;
     const size_t lds = (size_t)(C + (H + 4 * L) + H + H + 256 + 3 * 4 * H) * sizeof(float);
@@ -602,6 +606,7 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
 
 hipError_t launch_transpose(hipStream_t st, const float* src, float* dst, int R, int Cc)
 {
+    IOD_XSKIP(64);
     const int blocks = (int)std::min<size_t>(((size_t)R * Cc + 255) / 256, 2048);
     hipLaunchKernelGGL(transpose_kernel, dim3(blocks), dim3(256), 0, st, src, dst, R, Cc);
     return hipGetLastError();

@@ -257,6 +257,7 @@ int pixel_blocks_per_image(int P) { return (P + 2 * PIX_BLOCK - 1) / (2 * PIX_BL
 hipError_t launch_pixel_pass1(hipStream_t st, const float* x4, const float* dec, float* g, double* part, int B,
                               int K, int P, float sigma)
 {
+    IOD_XSKIP(8);
     const int nblk = pixel_blocks_per_image(P), ppb = (P + nblk - 1) / nblk;
     const float inv2s2 = 1.f / (2.f * sigma * sigma), invs2 = 1.f / (sigma * sigma);
     const float lconst = (float)(-log((double)sigma) - 0.5 * log(2.0 * M_PI));
@@ -273,6 +274,7 @@ hipError_t launch_pixel_pass1(hipStream_t st, const float* x4, const float* dec,
 hipError_t launch_pixel_finalize(hipStream_t st, const double* part, int B, int K, int P, int use_ln,
                                  float* lnstat, float* ll_img)
 {
+    IOD_XSKIP(8);
     hipLaunchKernelGGL(pixel_finalize_kernel, dim3(B), dim3(128), 0, st, part, pixel_blocks_per_image(P), K, P,
                        use_ln, lnstat, ll_img);
     return hipGetLastError();
@@ -281,6 +283,7 @@ hipError_t launch_pixel_finalize(hipStream_t st, const double* part, int B, int 
 hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec, const float* lnstat,
                               const float* lin, float* enc, int B, int K, int S, float sigma)
 {
+    IOD_XSKIP(8);
     const int P = S * S;
     const int nblk = pixel_blocks_per_image(P), ppb = (P + nblk - 1) / nblk;
     const float inv2s2 = 1.f / (2.f * sigma * sigma), invs2 = 1.f / (sigma * sigma);

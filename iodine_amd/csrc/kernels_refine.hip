@@ -302,6 +302,7 @@ hipError_t launch_s2_inst(hipStream_t st, const float* in, const void* wpk, cons
 hipError_t launch_conv3x3_s2_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
                                    float* out, int N, int S, int cin_real, int cout)
 {
+    IOD_XSKIP(512);
     if (S % 2 != 0 || S < 2) return hipErrorInvalidValue;
 #define S2F_CASE(CR, CP, CO) \
     if (cin_real == CR && cout == CO) return launch_s2_inst<CR, CP, CO, 0>(st, in, wpk, wmeta, bias, nullptr, out, N, S / 2);
@@ -315,6 +316,7 @@ hipError_t launch_conv3x3_s2_f16x3(hipStream_t st, const float* in, const void* 
 hipError_t launch_conv3x3_s2_dgrad_f16x3(hipStream_t st, const float* d, const void* wpk, const float* wmeta, const float* aux,
                                          float* out, int N, int S, int c)
 {
+    IOD_XSKIP(1024);
     if (S % 2 != 0 || S < 2) return hipErrorInvalidValue;
     if (c == 64) return launch_s2_inst<64, 64, 64, 1>(st, d, wpk, wmeta, nullptr, aux, out, N, S / 2);
     if (c == 32) return launch_s2_inst<32, 32, 32, 1>(st, d, wpk, wmeta, nullptr, aux, out, N, S / 2);
@@ -558,6 +560,7 @@ hipError_t launch_s2_wgrad_inst(hipStream_t st, const float* a, const float* d, 
 hipError_t launch_conv3x3_s2_wgrad_f16x3(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
                                          int S, int ci_real, int nco, int* nparts, int* cipad, int* nbias_parts)
 {
+    IOD_XSKIP(1024);
     if (S % 2 != 0 || S < 2) return hipErrorInvalidValue;
 #define S2W_CASE(CR, CP, CO, TH) \
     if (ci_real == CR && nco == CO) return launch_s2_wgrad_inst<CR, CP, CO, TH>(st, a, d, part, part_b, N, S / 2, nparts, cipad, nbias_parts);

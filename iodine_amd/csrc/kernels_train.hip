@@ -287,6 +287,7 @@ void wgrad_fold_kernel(const float4* __restrict__ part, int nparts, int per, int
 hipError_t launch_wgrad_reduce(hipStream_t st, const float* part, int nparts, int ci_pad, int co_pad, int O_real,
                                int I_real, int I_dst, float alpha, float* dst, float* fold)
 {
+    IOD_XSKIP(1);
     const int total = 9 * ci_pad * co_pad;
     if (fold && nparts >= 4 * WGRAD_FOLD && total % 4 == 0) {
         const int per = (nparts + WGRAD_FOLD - 1) / WGRAD_FOLD, nf = (nparts + per - 1) / per;
@@ -318,6 +319,7 @@ __global__ void colsum_kernel(const float* __restrict__ src, int rows, int cols,
 
 hipError_t launch_colsum(hipStream_t st, const float* src, int rows, int cols, int ld, float alpha, float* dst)
 {
+    IOD_XSKIP(1);
     hipLaunchKernelGGL(colsum_kernel, dim3(cols), dim3(256), 0, st, src, rows, cols, ld, alpha, dst);
     return hipGetLastError();
 }
@@ -391,6 +393,7 @@ void sgemm_kernel(int ta, int tb, int M, int N, int K, float alpha, const float*
 hipError_t launch_sgemm(hipStream_t st, int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
                         const float* B, int ldb, float beta, float* C, int ldc)
 {
+    IOD_XSKIP(2);
     hipLaunchKernelGGL(sgemm_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, st, ta, tb, M, N, K, alpha, A, lda,
                        B, ldb, beta, C, ldc);
     return hipGetLastError();
@@ -510,6 +513,7 @@ __global__ void scale_kernel(const float* __restrict__ a, float alpha, float* __
 
 hipError_t launch_scale(hipStream_t st, const float* a, float alpha, float* o, int n)
 {
+    IOD_XSKIP(64);
     hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, alpha, o, n);
     return hipGetLastError();
 }
@@ -522,6 +526,7 @@ __global__ void axpy_kernel(const float* __restrict__ x, float alpha, float* __r
 
 hipError_t launch_axpy(hipStream_t st, const float* x, float alpha, float* y, int n)
 {
+    IOD_XSKIP(64);
     hipLaunchKernelGGL(axpy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, alpha, y, n);
     return hipGetLastError();
 }
@@ -555,6 +560,7 @@ hipError_t launch_lstm_bwd_pointwise(hipStream_t st, const float* gates, const f
                                      const float* dc1_read, const float* dh1, const float* dc1_carry, float* dgates,
                                      float* dc0, int N, int H)
 {
+    IOD_XSKIP(64);
     hipLaunchKernelGGL(lstm_bwd_pointwise_kernel, dim3((N * H + 255) / 256), dim3(256), 0, st, gates, c0, c1, dc1_read,
                        dh1, dc1_carry, dgates, dc0, N, H);
     return hipGetLastError();
@@ -576,6 +582,7 @@ __global__ void mlp_bwd_pointwise_kernel(const float* __restrict__ du, int ldu, 
 
 hipError_t launch_mlp_bwd_pointwise(hipStream_t st, const float* du, int ldu, const float* s, float* ds, int N, int H)
 {
+    IOD_XSKIP(64);
     hipLaunchKernelGGL(mlp_bwd_pointwise_kernel, dim3((N * H + 255) / 256), dim3(256), 0, st, du, ldu, s, ds, N, H);
     return hipGetLastError();
 }
@@ -593,6 +600,7 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dpooled, const float* 
 
 hipError_t launch_pool_bwd(hipStream_t st, const float* dpooled, const float* act, float* dpre, int N, int PL, int C)
 {
+    IOD_XSKIP(64);
     const size_t total = (size_t)N * PL * C;
     hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dpooled, act, dpre, PL, C,
                        total);
@@ -1046,6 +1054,7 @@ void dec_out_wgrad_gemm_f16x3_kernel(const float* __restrict__ a, const float* _
 hipError_t launch_dec_out_wgrad_gemm_f16x3(hipStream_t st, const float* a, const float* g, float* part, float* part_b, int N,
                                            int S, int c, int* nparts, int* nbias_parts)
 {
+    IOD_XSKIP(2048);
     if (S % 16 != 0 || (c != 64 && c != 32)) return hipErrorInvalidValue;
     const int tiles_x = S / 16, tiles_y = S / 4, ntiles = N * tiles_x * tiles_y;
     const int blocks = ntiles < 1024 ? ntiles : 1024;
