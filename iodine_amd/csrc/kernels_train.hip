@@ -371,17 +371,26 @@ __global__ __launch_bounds__(256)
 void sgemm_kernel(int ta, int tb, int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
                   const float* __restrict__ B, int ldb, float beta, float* __restrict__ Cm, int ldc)
 {
-    __shared__ float sA[16][17], sB[16][17];
+    // These GEMMs are latency-bound (operands are L2-resident, a few hundred blocks): K advances 64 at a time so that every
+    // thread has 8 independent loads in flight per barrier pair instead of 2; the k order of the fma chain is unchanged.
+    constexpr int BK = 64;
+    __shared__ float sA[16][BK + 1], sB[BK][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
     float acc = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        const int ka = k0 + tx, kb = k0 + ty;
-        sA[ty][tx] = (row < M && ka < K) ? (ta ? A[(size_t)ka * lda + row] : A[(size_t)row * lda + ka]) : 0.f;
-        sB[ty][tx] = (kb < K && col < N) ? (tb ? B[(size_t)col * ldb + kb] : B[(size_t)kb * ldb + col]) : 0.f;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        float ra[BK / 16], rb[BK / 16];
+#pragma unroll
+        for (int q = 0; q < BK / 16; ++q) {
+            const int ka = k0 + q * 16 + tx, kb = k0 + q * 16 + ty;
+            ra[q] = (row < M && ka < K) ? (ta ? A[(size_t)ka * lda + row] : A[(size_t)row * lda + ka]) : 0.f;
+            rb[q] = (kb < K && col < N) ? (tb ? B[(size_t)col * ldb + kb] : B[(size_t)kb * ldb + col]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < BK / 16; ++q) { sA[ty][q * 16 + tx] = ra[q]; sB[q * 16 + ty][tx] = rb[q]; }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc = fmaf(sA[ty][k], sB[k][tx], acc);
+        for (int k = 0; k < BK; ++k) acc = fmaf(sA[ty][k], sB[k][tx], acc);
         __syncthreads();
     }
     if (row < M && col < N) {
