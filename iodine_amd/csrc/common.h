@@ -24,6 +24,8 @@ extern int g_iod_xskip;
 
 // ELU with alpha = 1 (torch.nn.functional.elu): x > 0 ? x : expm1(x)
 IOD_DEVINL float elu1(float v) { return v > 0.f ? v : expm1f(v); }
+// the same through v_exp_f32 (absolute error ~1e-7, as in the conv epilogues): the streaming kernels are otherwise VALU-bound on expm1f
+IOD_DEVINL float elu1_fast(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
 // derivative of ELU expressed through its OUTPUT a = ELU(x): a > 0 ? 1 : a + 1
 IOD_DEVINL float elu1_grad_from_out(float a) { return a > 0.f ? 1.f : a + 1.f; }
 IOD_DEVINL float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }

@@ -487,7 +487,6 @@ hipError_t launch_pack_conv_weights_f16(hipStream_t st, const float* src, int O,
     return hipGetLastError();
 }
 
-IOD_DEVINL float elu1_fast(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
 
 #ifdef IODINE_TILE_PROF
 __device__ unsigned g_tile_prof[TP_MAXBLK * 8];

@@ -22,7 +22,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4_ __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
 
-IOD_DEVINL float elu1_fast(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
 
 }  // namespace
 

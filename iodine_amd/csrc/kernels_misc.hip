@@ -147,7 +147,7 @@ void dec_l0_kernel(const float4* __restrict__ V, const float4* __restrict__ cmap
             const int cls = (y == 0 ? 0 : (y == S - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x == S - 1 ? 2 : 1));
             const float4 v = Vn[cls * C4 + c4];
             const float4 m = cmap[i];
-            on[i] = make_float4(elu1(v.x + m.x), elu1(v.y + m.y), elu1(v.z + m.z), elu1(v.w + m.w));
+            on[i] = make_float4(elu1_fast(v.x + m.x), elu1_fast(v.y + m.y), elu1_fast(v.z + m.z), elu1_fast(v.w + m.w));
         }
     }
 }
