@@ -378,16 +378,35 @@ __global__ void dz_latent_kernel(const float* __restrict__ Rc, const float* __re
                                  const float* __restrict__ eps, int L, int C, int use_ln,
                                  float* __restrict__ g_pm, float* __restrict__ g_plv, float* __restrict__ latent)
 {
-    extern __shared__ float s_rc[];                     // 9*C
+    // blockDim = 4 * Lp (Lp = L rounded up to 64): the 9C-long contraction is cut into four slices (one per group of Lp
+    // threads), four independent partial sums each, combined in fixed order; slice 0 finishes the row.  (One thread per
+    // latent walked all 9C terms as a single dependent load + fma chain: 64 us per launch at cfg3.)
+    extern __shared__ float s_rc[];                     // 9*C, then 4*Lp partial sums
     __shared__ float s_buf[8];
     const int n = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
-    for (int i = tid; i < 9 * C; i += nth) s_rc[i] = Rc[(size_t)n * 9 * C + i];
+    const int Lp = nth / 4, l = tid % Lp, slice = tid / Lp, J = 9 * C;
+    float* s_dz = s_rc + J;
+    for (int i = tid; i < J; i += nth) s_rc[i] = Rc[(size_t)n * J + i];
     __syncthreads();
-    const bool act = tid < L;
+    {
+        const int per = (J + 3) / 4, j0 = slice * per, j1 = min(J, j0 + per);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (l < L) {
+            const float* w = wclsT + l;
+            int j = j0;
+            for (; j + 3 < j1; j += 4) {
+                a0 = fmaf(s_rc[j], w[(size_t)j * L], a0); a1 = fmaf(s_rc[j + 1], w[(size_t)(j + 1) * L], a1);
+                a2 = fmaf(s_rc[j + 2], w[(size_t)(j + 2) * L], a2); a3 = fmaf(s_rc[j + 3], w[(size_t)(j + 3) * L], a3);
+            }
+            for (; j < j1; ++j) a0 = fmaf(s_rc[j], w[(size_t)j * L], a0);
+        }
+        s_dz[slice * Lp + l] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    const bool act = slice == 0 && l < L;
     float gm = 0.f, gl = 0.f, mu = 0.f, lv = 0.f;
     if (act) {
-        float dz = 0.f;
-        for (int j = 0; j < 9 * C; ++j) dz = fmaf(s_rc[j], wclsT[(size_t)j * L + tid], dz);
+        const float dz = (s_dz[l] + s_dz[Lp + l]) + (s_dz[2 * Lp + l] + s_dz[3 * Lp + l]);
         mu = pm[(size_t)n * L + tid]; lv = plv[(size_t)n * L + tid];
         const float e = eps[(size_t)n * L + tid];
         gm = dz - mu;
@@ -415,8 +434,9 @@ hipError_t launch_dz_latent(hipStream_t st, const float* Rc, const float* wclsT,
                             const float* eps, int N, int L, int C, int use_ln, float* g_pm, float* g_plv, float* latent)
 {
     IOD_XSKIP(32);
-    const int nth = ((L + 63) / 64) * 64;
-    hipLaunchKernelGGL(dz_latent_kernel, dim3(N), dim3(nth), 9 * C * sizeof(float), st, Rc, wclsT, pm, plv, eps, L, C,
+    const int nth = 4 * ((L + 63) / 64) * 64;
+    if (nth > 512) return hipErrorInvalidValue;                  // block_sum_f: at most 8 waves
+    hipLaunchKernelGGL(dz_latent_kernel, dim3(N), dim3(nth), (9 * C + nth) * sizeof(float), st, Rc, wclsT, pm, plv, eps, L, C,
                        use_ln, g_pm, g_plv, latent);
     return hipGetLastError();
 }
