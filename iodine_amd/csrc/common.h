@@ -192,7 +192,7 @@ hipError_t launch_sgemm(hipStream_t st, int ta, int tb, int M, int N, int K, flo
 hipError_t launch_l0_tap_sums(hipStream_t st, const float* Rc, float* RT, int N, int C);
 hipError_t launch_l0_scatter_z(hipStream_t st, const float* tmp, int L, int C, float alpha, float* gw);
 hipError_t launch_l0_coord_grads(hipStream_t st, const float* D, const float* lin, int S, int C, int L, float alpha,
-                                 float* gw, float* gb);
+                                 float* gw, float* gb, float* scratch);
 hipError_t launch_loss(hipStream_t st, const float* scal, int n, float* loss);
 hipError_t launch_scale(hipStream_t st, const float* a, float alpha, float* o, int n);
 hipError_t launch_axpy(hipStream_t st, const float* x, float alpha, float* y, int n);

@@ -431,19 +431,23 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // max |w| of a tensor -> meta[0] = scale (power of two with max*scale in [2^12, 2^13)), meta[1] = 1/scale
-__global__ void weight_scale_kernel(const float* __restrict__ w, int n, float* __restrict__ meta)
+__global__ __launch_bounds__(1024)
+void weight_scale_kernel(const float* __restrict__ w, int n, float* __restrict__ meta)
 {
-    __shared__ float s_red[256];
-    float m = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
-    s_red[threadIdx.x] = m;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + o]);
-        __syncthreads();
+    __shared__ float s_red[16];
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    int i = threadIdx.x;
+    for (; i + 3072 < n; i += 4096) {
+        m0 = fmaxf(m0, fabsf(w[i])); m1 = fmaxf(m1, fabsf(w[i + 1024]));
+        m2 = fmaxf(m2, fabsf(w[i + 2048])); m3 = fmaxf(m3, fabsf(w[i + 3072]));
     }
+    for (; i < n; i += 1024) m0 = fmaxf(m0, fabsf(w[i]));
+    const float m = wave_max_f32(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const float mx = s_red[0];
+        float mx = 0.f;
+        for (int k = 0; k < 16; ++k) mx = fmaxf(mx, s_red[k]);
         int e = 0;
         if (mx > 0.f && isfinite(mx)) { frexpf(mx, &e); }          // mx = f * 2^e, f in [0.5, 1)
         const float scale = ldexpf(1.f, 13 - e);                    // mx * scale in [2^12, 2^13)
@@ -480,7 +484,7 @@ __global__ void pack_conv_weights_f16_kernel(const float* __restrict__ src, int 
 hipError_t launch_pack_conv_weights_f16(hipStream_t st, const float* src, int O, int I, int cin, int cout, int tflip,
                                         float* meta, void* dst)
 {
-    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(256), 0, st, src, O * I * 9, meta);
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1024), 0, st, src, O * I * 9, meta);
     const size_t total = (size_t)(cin / 16) * 9 * 2 * 2 * cout * 8;
     hipLaunchKernelGGL(pack_conv_weights_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, O, I,
                        cin, cout, tflip, meta, (_Float16*)dst);
@@ -1417,7 +1421,7 @@ __global__ void pack_dec_out_gemm_kernel(const float* __restrict__ w /*[4][C][3]
 
 hipError_t launch_pack_dec_out_gemm(hipStream_t st, const float* w, int C, float* meta, void* dst)
 {
-    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(256), 0, st, w, 4 * C * 9, meta);
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1024), 0, st, w, 4 * C * 9, meta);
     hipLaunchKernelGGL(pack_dec_out_gemm_kernel, dim3(16), dim3(256), 0, st, w, C, meta, (_Float16*)dst);
     return hipGetLastError();
 }

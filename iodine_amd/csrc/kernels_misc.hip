@@ -115,9 +115,14 @@ void dec_v_kernel(const float* __restrict__ pm, const float* __restrict__ plv, c
     for (int o = tid; o < 9 * C; o += 256) {
         const int cls = o / C, co = o % C;
         const float* w = wcls + (size_t)cls * L * C + co;
-        float s = 0.f;
-        for (int ci = 0; ci < L; ++ci) s = fmaf(s_z[ci], w[(size_t)ci * C], s);
-        V[(size_t)n * 9 * C + o] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;              // four partial sums: the loads of a chain overlap
+        int ci = 0;
+        for (; ci + 3 < L; ci += 4) {
+            s0 = fmaf(s_z[ci], w[(size_t)ci * C], s0); s1 = fmaf(s_z[ci + 1], w[(size_t)(ci + 1) * C], s1);
+            s2 = fmaf(s_z[ci + 2], w[(size_t)(ci + 2) * C], s2); s3 = fmaf(s_z[ci + 3], w[(size_t)(ci + 3) * C], s3);
+        }
+        for (; ci < L; ++ci) s0 = fmaf(s_z[ci], w[(size_t)ci * C], s0);
+        V[(size_t)n * 9 * C + o] = (s0 + s1) + (s2 + s3);
     }
 }
 

@@ -450,18 +450,22 @@ hipError_t launch_l0_scatter_z(hipStream_t st, const float* tmp, int L, int C, f
     return hipGetLastError();
 }
 
-// coordinate-channel weights and the bias of layer 0 from D[p][c]; one block per output channel
+// coordinate-channel weights and the bias of layer 0 from D[p][c].  Stage 1: block b walks the pixels p = b, b + NB, ...
+// with thread = (channel, pixel lane) so that D is read in full rows (the one-block-per-channel form read one float per
+// 256-byte row: 151 us for a 4 MB map); 19 sums per channel (9 taps x {x, y} + bias) -> partial[b][19][C].
+// Stage 2: fixed-order sum over the NB partials into the gradient accumulators.
+constexpr int L0CG_BLOCKS = 128;
 __global__ __launch_bounds__(256)
-void l0_coord_grads_kernel(const float* __restrict__ D, const float* __restrict__ lin, int S, int C, int L, float alpha,
-                           float* __restrict__ gw, float* __restrict__ gb)
+void l0_coord_partial_kernel(const float* __restrict__ D, const float* __restrict__ lin, int S, int C,
+                             float* __restrict__ partial)
 {
-    __shared__ float s_red[256];
-    const int co = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ float s_cg[];                       // [pixel lanes][19][C]
+    const int tid = threadIdx.x, c = tid % C, pl = tid / C, PL = 256 / C;
     float acc[19];
 #pragma unroll
     for (int j = 0; j < 19; ++j) acc[j] = 0.f;
-    for (int p = tid; p < S * S; p += 256) {
-        const float v = D[(size_t)p * C + co];
+    for (int p = blockIdx.x * PL + pl; p < S * S; p += L0CG_BLOCKS * PL) {
+        const float v = D[(size_t)p * C + c];
         const int y = p / S, x = p % S;
         acc[18] += v;
 #pragma unroll
@@ -472,26 +476,41 @@ void l0_coord_grads_kernel(const float* __restrict__ D, const float* __restrict_
             acc[9 + tap] += lin[yy] * v;
         }
     }
-    for (int j = 0; j < 19; ++j) {
-        s_red[tid] = acc[j];
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) s_red[tid] += s_red[tid + o];
-            __syncthreads();
-        }
-        if (tid == 0) {
-            if (j < 9) gw[((size_t)co * (L + 2) + L) * 9 + j] += alpha * s_red[0];
-            else if (j < 18) gw[((size_t)co * (L + 2) + L + 1) * 9 + (j - 9)] += alpha * s_red[0];
-            else gb[co] += alpha * s_red[0];
-        }
-        __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 19; ++j) s_cg[(pl * 19 + j) * C + c] = acc[j];
+    __syncthreads();
+    for (int e = tid; e < 19 * C; e += 256) {
+        float t = 0.f;
+        for (int q = 0; q < PL; ++q) t += s_cg[q * 19 * C + e];
+        partial[(size_t)blockIdx.x * 19 * C + e] = t;
     }
 }
 
-hipError_t launch_l0_coord_grads(hipStream_t st, const float* D, const float* lin, int S, int C, int L, float alpha,
-                                 float* gw, float* gb)
+__global__ void l0_coord_final_kernel(const float* __restrict__ partial, int C, int L, float alpha, float* __restrict__ gw,
+                                      float* __restrict__ gb)
 {
-    hipLaunchKernelGGL(l0_coord_grads_kernel, dim3(C), dim3(256), 0, st, D, lin, S, C, L, alpha, gw, gb);
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 19 * C) return;
+    const int j = e / C, co = e % C;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int b = 0; b < L0CG_BLOCKS; b += 4) {
+        s0 += partial[(size_t)b * 19 * C + e]; s1 += partial[(size_t)(b + 1) * 19 * C + e];
+        s2 += partial[(size_t)(b + 2) * 19 * C + e]; s3 += partial[(size_t)(b + 3) * 19 * C + e];
+    }
+    const float t = alpha * ((s0 + s1) + (s2 + s3));
+    if (j < 9) gw[((size_t)co * (L + 2) + L) * 9 + j] += t;
+    else if (j < 18) gw[((size_t)co * (L + 2) + L + 1) * 9 + (j - 9)] += t;
+    else gb[co] += t;
+}
+
+// scratch: at least L0CG_BLOCKS * 19 * C floats
+hipError_t launch_l0_coord_grads(hipStream_t st, const float* D, const float* lin, int S, int C, int L, float alpha,
+                                 float* gw, float* gb, float* scratch)
+{
+    if (C > 256 || 256 % C != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(l0_coord_partial_kernel, dim3(L0CG_BLOCKS), dim3(256), (size_t)(256 / C) * 19 * C * sizeof(float), st, D,
+                       lin, S, C, scratch);
+    hipLaunchKernelGGL(l0_coord_final_kernel, dim3((19 * C + 255) / 256), dim3(256), 0, st, scratch, C, L, alpha, gw, gb);
     return hipGetLastError();
 }
 
