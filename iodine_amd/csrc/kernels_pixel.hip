@@ -189,8 +189,17 @@ void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict_
     __shared__ float s_ln[K * 8];
     for (int i = tid; i < K * 8; i += PIX_BLOCK) s_ln[i] = lnstat[(size_t)b * K * 8 + i];
     __syncthreads();
+    // The 20-channel rows are transposed through a wave-private LDS tile so that the wave writes its 64 pixels of a slot
+    // as 5 KB of CONTIGUOUS float4s (the direct form stored 16 bytes per lane at an 80-byte stride, five passes over the
+    // same 40 cache lines per slot).
+    __shared__ __attribute__((aligned(16))) float s_tr[PIX_BLOCK / 64][64 * 20];
+    const int lane = tid & 63, wv = tid >> 6;
+    float4* tw = reinterpret_cast<float4*>(s_tr[wv] + lane * 20);
+    const float4* trd = reinterpret_cast<const float4*>(s_tr[wv]);
     const int pend = min(P, (blk + 1) * ppb);
-    for (int p = blk * ppb + tid; p < pend; p += PIX_BLOCK) {
+    for (int p0 = blk * ppb + wv * 64; p0 < pend; p0 += PIX_BLOCK) {       // wave-uniform
+        const int nvalid = min(64, pend - p0);
+        const int p = p0 + min(lane, nvalid - 1);                          // idle lanes recompute the last pixel
         PixelTerms<K> t;
         const float4 xv = x4[(size_t)b * P + p];
         pixel_terms<K>(xv, dec_b, (size_t)P, (size_t)p, inv2s2, invs2, lconst, t);
@@ -202,13 +211,24 @@ void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict_
         for (int k = 0; k < K; ++k) {
             const float* ln = s_ln + k * 8;
             const float loo = (t.mix - t.m[k] * t.pk[k]) / (1.f - t.m[k] + 1e-5f);
-            float4* o = reinterpret_cast<float4*>(enc + (((size_t)b * K + k) * P + p) * 20);
-            o[0] = make_float4(xv.x, xv.y, xv.z, t.mu[k][0]);
-            o[1] = make_float4(t.mu[k][1], t.mu[k][2], t.m[k], t.logit[k]);
-            o[2] = make_float4(t.pk[k] / psum, (t.g1[k][0] - ln[0]) * ln[1], (t.g1[k][1] - ln[0]) * ln[1],
-                               (t.g1[k][2] - ln[0]) * ln[1]);
-            o[3] = make_float4((t.g2[k] - ln[2]) * ln[3], (t.like - ln[6]) * ln[7], (loo - ln[4]) * ln[5], cx);
-            o[4] = make_float4(cy, 0.f, 0.f, 0.f);
+            tw[0] = make_float4(xv.x, xv.y, xv.z, t.mu[k][0]);
+            tw[1] = make_float4(t.mu[k][1], t.mu[k][2], t.m[k], t.logit[k]);
+            tw[2] = make_float4(t.pk[k] / psum, (t.g1[k][0] - ln[0]) * ln[1], (t.g1[k][1] - ln[0]) * ln[1],
+                                (t.g1[k][2] - ln[0]) * ln[1]);
+            tw[3] = make_float4((t.g2[k] - ln[2]) * ln[3], (t.like - ln[6]) * ln[7], (loo - ln[4]) * ln[5], cx);
+            tw[4] = make_float4(cy, 0.f, 0.f, 0.f);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float4* o = reinterpret_cast<float4*>(enc + (((size_t)b * K + k) * P + p0) * 20);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int q = lane + 64 * j;
+                if (q < nvalid * 5) o[q] = trd[q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
