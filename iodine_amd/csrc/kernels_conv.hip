@@ -835,6 +835,48 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
                     for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(ax[mt][nt][g4]));
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifndef IODINE_TILE_EPI_DIRECT
+        // The finished tile goes through LDS once more so that the global stores are CONTIGUOUS: a lane's accumulator
+        // float4 is 16 bytes of one pixel (256-byte pixel stride: a direct store instruction touches 32 cache lines with
+        // 32 bytes each), whereas after the transposition every store instruction writes four whole pixels = 1 KB.
+        // Each wave owns a [64 pixels][COUT + 4 floats] region (the pad keeps the column-shaped writes off one bank).
+        constexpr int EPS = (COUT + 4) * 4;                      // bytes per staged pixel
+        __syncthreads();                                         // every wave is done with the staging buffers
+        unsigned char* s_ep = smem_b + wv * 64 * EPS;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 v = f32x4{acc[mt][nt][4 * g4] * inv_ws, acc[mt][nt][4 * g4 + 1] * inv_ws,
+                                    acc[mt][nt][4 * g4 + 2] * inv_ws, acc[mt][nt][4 * g4 + 3] * inv_ws};
+                    if constexpr (EPI == EPI_BIAS_ELU) {
+                        const f32x4 b4 = bv[nt][g4];
+                        v = f32x4{elu1_fast(v.x + b4.x), elu1_fast(v.y + b4.y), elu1_fast(v.z + b4.z), elu1_fast(v.w + b4.w)};
+                    } else if constexpr (EPI == EPI_MUL_ELUGRAD) {
+                        const f32x4 a4 = ax[mt][nt][g4];
+                        v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
+                        v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
+                    }
+                    *reinterpret_cast<f32x4*>(s_ep + (mt * 32 + li) * EPS + (nt * 32 + 8 * g4 + 4 * kh) * 4) = v;
+                }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // store j: pixels 4j .. 4j+3 of the wave's 64 (tile row j/4, columns 4(j%4) ..), lane = (pixel, 16-byte segment)
+        constexpr int SEGS = COUT / 4;                           // float4 segments per pixel (16 / 8)
+        constexpr int PPI = 64 / SEGS;                           // pixels per store instruction (4 / 8)
+        const int seg = lane % SEGS, pl = lane / SEGS;
+        const unsigned vbase = (unsigned)((((ty * 16 + 4 * wv) * S + tx * 16 + pl) * COUT + seg * 4) * 4);
+#pragma unroll
+        for (int j = 0; j < 64 / PPI; ++j) {
+            const int pq = j * PPI;                              // first pixel of this instruction (+ pl)
+            const f32x4 v = *reinterpret_cast<const f32x4*>(s_ep + (pq + pl) * EPS + seg * 16);
+            const int soff = ((pq / 16) * S + pq % 16) * COUT * 4;
+            asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v), "v"(vbase), "s"(rsrc_out), "s"(soff) : "memory");
+        }
+#else
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -860,6 +902,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
                     asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v), "v"(voff[mt]), "s"(rsrc_out), "s"(soff) : "memory");
 #endif
                 }
+#endif
     }
     TP_STAMP(7);                                             // [7] epilogue (issue of the stores)
     TP_FLUSH(g_tile_prof);
@@ -871,7 +914,9 @@ template <int CIN, int COUT, int EPI>
 static hipError_t launch_tile_f16x3_inst(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                          const float* bias, const float* aux, float* out, int N, int S, int rev)
 {
-    constexpr size_t lds = (size_t)(18 * 18 + 1) * 80 + (size_t)9 * 2 * 2 * COUT * 16 + 16;
+    constexpr size_t lds_stage = (size_t)(18 * 18 + 1) * 80 + (size_t)9 * 2 * 2 * COUT * 16 + 16;
+    constexpr size_t lds_epi = (size_t)4 * 64 * (COUT + 4) * 4;              // output tile, transposed for contiguous stores
+    constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_tile_f16x3_kernel<CIN, COUT, EPI>,
