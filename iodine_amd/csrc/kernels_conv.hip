@@ -746,6 +746,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     // data-gradient form: the ELU' operand (the saved activation of the layer below, one float4 per accumulator quad) is
     // requested right after the LAST chunk has been staged - its input / weight registers are free by then - and arrives
     // under the last 108 MFMAs instead of being waited for in the epilogue
+#ifdef IODINE_TILE_EPI_DIRECT
     f32x4 ax[2][NT][4];
     unsigned voff[2];
 #pragma unroll
@@ -768,6 +769,28 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
                     }
         }
     };
+#else
+    // Output-side lane mapping (see the epilogue): lane = (pixel pl of PPI, 16-byte channel segment seg); instruction j
+    // covers pixels j*PPI .. of the wave's 64.  The ELU' operand is fetched in exactly this shape - whole pixels, 1 KB
+    // per instruction - and applied AFTER the accumulators have been transposed through LDS.
+    constexpr int SEGS = COUT / 4;                           // float4 segments per pixel (16 / 8)
+    constexpr int PPI = 64 / SEGS;                           // pixels per load / store instruction (4 / 8)
+    constexpr int NEP = 64 / PPI;                            // instructions per wave tile (16 / 8)
+    const int seg = lane % SEGS, pl = lane / SEGS;
+    const unsigned vbase = (unsigned)((((ty * 16 + 4 * wv) * S + tx * 16 + pl) * COUT + seg * 4) * 4);
+    f32x4 ax[NEP];
+    auto prefetch_aux = [&]() {
+        if constexpr (EPI == EPI_MUL_ELUGRAD) {
+            const i32x4_ rsrc_aux = make_rsrc(aux + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
+#pragma unroll
+            for (int j = 0; j < NEP; ++j) {
+                const int soff = (((j * PPI) / 16) * S + (j * PPI) % 16) * COUT * 4;
+                IOD_SGPR_SETTLE(rsrc_aux, soff);
+                IOD_BLOAD4(ax[j], vbase, rsrc_aux, soff);
+            }
+        }
+    };
+#endif
     TP_STAMP(0);                                             // [0] block start: index arithmetic
     prefetch_in(0, rinA);
     prefetch_w(0);
@@ -809,6 +832,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     static_assert(EPI == EPI_BIAS_ELU || EPI == EPI_MUL_ELUGRAD, "the C -> 4 output conv has its own GEMM-form kernel");
     {
         const i32x4_ rsrc_out = make_rsrc(out + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
+#ifdef IODINE_TILE_EPI_DIRECT
         f32x4 bv[NT][4];
         if constexpr (EPI == EPI_BIAS_ELU) {
 #pragma unroll
@@ -835,6 +859,20 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
                     for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(ax[mt][nt][g4]));
             __builtin_amdgcn_sched_barrier(0);
         }
+#else
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EPI_BIAS_ELU) {
+            const float4 t = *reinterpret_cast<const float4*>(bias + seg * 4);
+            b4 = f32x4{t.x, t.y, t.z, t.w};
+            asm volatile("" : "+v"(b4));                     // (pinned before the asm stores, see the direct form)
+        }
+        if constexpr (EPI == EPI_MUL_ELUGRAD) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < NEP; ++j) asm volatile("" : "+v"(ax[j]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
 #ifndef IODINE_TILE_EPI_DIRECT
         // The finished tile goes through LDS once more so that the global stores are CONTIGUOUS: a lane's accumulator
         // float4 is 16 bytes of one pixel (256-byte pixel stride: a direct store instruction touches 32 cache lines with
@@ -848,31 +886,26 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    f32x4 v = f32x4{acc[mt][nt][4 * g4] * inv_ws, acc[mt][nt][4 * g4 + 1] * inv_ws,
-                                    acc[mt][nt][4 * g4 + 2] * inv_ws, acc[mt][nt][4 * g4 + 3] * inv_ws};
-                    if constexpr (EPI == EPI_BIAS_ELU) {
-                        const f32x4 b4 = bv[nt][g4];
-                        v = f32x4{elu1_fast(v.x + b4.x), elu1_fast(v.y + b4.y), elu1_fast(v.z + b4.z), elu1_fast(v.w + b4.w)};
-                    } else if constexpr (EPI == EPI_MUL_ELUGRAD) {
-                        const f32x4 a4 = ax[mt][nt][g4];
-                        v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
-                        v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
-                    }
-                    *reinterpret_cast<f32x4*>(s_ep + (mt * 32 + li) * EPS + (nt * 32 + 8 * g4 + 4 * kh) * 4) = v;
-                }
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *reinterpret_cast<f32x4*>(s_ep + (mt * 32 + li) * EPS + (nt * 32 + 8 * g4 + 4 * kh) * 4) =
+                        f32x4{acc[mt][nt][4 * g4] * inv_ws, acc[mt][nt][4 * g4 + 1] * inv_ws,
+                              acc[mt][nt][4 * g4 + 2] * inv_ws, acc[mt][nt][4 * g4 + 3] * inv_ws};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // store j: pixels 4j .. 4j+3 of the wave's 64 (tile row j/4, columns 4(j%4) ..), lane = (pixel, 16-byte segment)
-        constexpr int SEGS = COUT / 4;                           // float4 segments per pixel (16 / 8)
-        constexpr int PPI = 64 / SEGS;                           // pixels per store instruction (4 / 8)
-        const int seg = lane % SEGS, pl = lane / SEGS;
-        const unsigned vbase = (unsigned)((((ty * 16 + 4 * wv) * S + tx * 16 + pl) * COUT + seg * 4) * 4);
+        // instruction j: pixels j*PPI .. of the wave's 64 (tile row (j*PPI)/16, columns (j*PPI)%16 ..), bias + ELU or the
+        // ELU' factor applied in this layout (a lane keeps ONE float4 of bias: its channel segment never changes)
 #pragma unroll
-        for (int j = 0; j < 64 / PPI; ++j) {
-            const int pq = j * PPI;                              // first pixel of this instruction (+ pl)
-            const f32x4 v = *reinterpret_cast<const f32x4*>(s_ep + (pq + pl) * EPS + seg * 16);
+        for (int j = 0; j < NEP; ++j) {
+            const int pq = j * PPI;
+            f32x4 v = *reinterpret_cast<const f32x4*>(s_ep + (pq + pl) * EPS + seg * 16);
+            if constexpr (EPI == EPI_BIAS_ELU) {
+                v = f32x4{elu1_fast(v.x + b4.x), elu1_fast(v.y + b4.y), elu1_fast(v.z + b4.z), elu1_fast(v.w + b4.w)};
+            } else if constexpr (EPI == EPI_MUL_ELUGRAD) {
+                const f32x4 a4 = ax[j];
+                v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
+                v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
+            }
             const int soff = ((pq / 16) * S + pq % 16) * COUT * 4;
             asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v), "v"(vbase), "s"(rsrc_out), "s"(soff) : "memory");
         }
