@@ -131,7 +131,8 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * "profile" (bracket kernel launches with HIP events on the launch stream: 1 = the dominant "conv_tile_*" launches only --
  * 54 of ~330 per training step, what bench.py keeps on inside its timed region; 2 = every category; 0 = off),
  * "conv_precision" (3x3 convs of the decoder and refinement stacks: 0 = exact fp32 MFMA, 1 = fp32 operands split into
- * fp16 hi+lo, 3 fp16 MFMAs, fp32 accumulate -- default),
+ * fp16 hi+lo, 3 fp16 MFMAs, fp32 accumulate -- default; only the selected path's weight packs are maintained, so a change
+ * must be followed by iodine_set_params before the next compute call),
  * "conv_variant" (split-fp16 stride-1 conv: 1 = one tile per 4-wave block, two blocks per CU -- default; 3 = warp-specialised
  * persistent kernel, 4 = one tile per 8-wave block, four waves per SIMD; both experimental, same results bit for bit),
  * "zigzag" (1 -- default: odd decoder layers walk their tiles backwards so that a launch starts on what the previous one

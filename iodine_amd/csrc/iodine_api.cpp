@@ -615,8 +615,10 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
                                     h->S, h->wcls, h->wclsT, h->cmap));
     for (int l = 1; l < h->Dd; ++l) {
         const float* w = P("decoder.mlc.layers." + std::to_string(l) + ".weight");
-        HIPCHK(h, launch_pack_conv_weights(st, w, Cd, Cd, Cd, Cd, 0, h->dec_wf[l]));
-        HIPCHK(h, launch_pack_conv_weights(st, w, Cd, Cd, Cd, Cd, 1, h->dec_wb[l]));
+        if (h->precision == 0) {                               // exact-fp32 path only (conv_precision invalidates the params)
+            HIPCHK(h, launch_pack_conv_weights(st, w, Cd, Cd, Cd, Cd, 0, h->dec_wf[l]));
+            HIPCHK(h, launch_pack_conv_weights(st, w, Cd, Cd, Cd, Cd, 1, h->dec_wb[l]));
+        }
         HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cd, Cd, Cd, Cd, 0, h->dec_wmeta[l], h->dec_wf16[l]));
         HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cd, Cd, Cd, Cd, 1, h->dec_wmeta[l] + 2, h->dec_wb16[l]));
         HIPCHK(h, hipMemcpyAsync(h->dec_b[l], P("decoder.mlc.layers." + std::to_string(l) + ".bias"), sizeof(float) * Cd,
@@ -627,13 +629,14 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     HIPCHK(h, launch_pack_conv_weights(st, P("decoder.conv.weight"), 4, Cd, 4, Cd, 1, h->dec_out_wb));
     HIPCHK(h, launch_pack_dec_out_gemm(st, P("decoder.conv.weight"), Cd, h->dec_out_meta, h->dec_out_w16));
     // refinement conv stack
+    const bool ref_fp32 = h->precision == 0 || !refine_f16_ok(h);
     for (int l = 0; l < h->Dr; ++l) {
         const float* w = P("refine.mlc.layers." + std::to_string(l) + ".weight");
-        HIPCHK(h, launch_pack_conv_weights(st, w, Cr, l == 0 ? 17 : Cr, l == 0 ? 20 : Cr, Cr, 0, h->ref_w[l]));
+        if (ref_fp32) HIPCHK(h, launch_pack_conv_weights(st, w, Cr, l == 0 ? 17 : Cr, l == 0 ? 20 : Cr, Cr, 0, h->ref_w[l]));
         HIPCHK(h, hipMemcpyAsync(h->ref_b[l], P("refine.mlc.layers." + std::to_string(l) + ".bias"), sizeof(float) * Cr,
                                  hipMemcpyDeviceToDevice, st));
     }
-    for (int l = 1; l < h->Dr; ++l)
+    for (int l = 1; l < h->Dr && ref_fp32; ++l)
         HIPCHK(h, launch_pack_conv_weights(st, P("refine.mlc.layers." + std::to_string(l) + ".weight"), Cr, Cr, Cr, Cr, 2,
                                            h->ref_wb[l]));
     if (refine_f16_ok(h)) {
@@ -705,6 +708,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     }
     if (!strcmp(key, "conv_precision")) {
         if (value != 0 && value != 1) return h->fail(IODINE_ERR_INVALID, "conv_precision must be 0 (f32) or 1 (f16x3)");
+        if (h->precision != (int)value) h->params_set = false;    // the other path's weight packs are not kept up to date
         h->precision = (int)value;
         return IODINE_OK;
     }

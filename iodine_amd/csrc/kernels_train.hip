@@ -454,7 +454,7 @@ hipError_t launch_l0_scatter_z(hipStream_t st, const float* tmp, int L, int C, f
 // with thread = (channel, pixel lane) so that D is read in full rows (the one-block-per-channel form read one float per
 // 256-byte row: 151 us for a 4 MB map); 19 sums per channel (9 taps x {x, y} + bias) -> partial[b][19][C].
 // Stage 2: fixed-order sum over the NB partials into the gradient accumulators.
-constexpr int L0CG_BLOCKS = 128;
+constexpr int L0CG_BLOCKS = 512;
 __global__ __launch_bounds__(256)
 void l0_coord_partial_kernel(const float* __restrict__ D, const float* __restrict__ lin, int S, int C,
                              float* __restrict__ partial)
