@@ -183,7 +183,8 @@ hipError_t launch_conv3x3_wgrad_gather(hipStream_t st, const float* in, const fl
                                        int IW, int cip, int co, int stride, int* nparts, int* cipad);
 constexpr int WGRAD_FOLD = 32;    // tiles left after the first reduction stage; `fold` holds WGRAD_FOLD * 9 * ci_pad * co_pad floats
 hipError_t launch_wgrad_reduce(hipStream_t st, const float* part, int nparts, int ci_pad, int co_pad, int O_real,
-                               int I_real, int I_dst, float alpha, float* dst, float* fold);
+                               int I_real, int I_dst, float alpha, float* dst, float* fold = nullptr,
+                               const float* part_b = nullptr, int nb = 0, float* dst_b = nullptr);
 hipError_t launch_colsum(hipStream_t st, const float* src, int rows, int cols, int ld, float alpha, float* dst);
 hipError_t launch_colsum_tall(hipStream_t st, const float* src, int rows, int cols, float alpha, float* dst, float* tmp,
                               size_t tmp_elems);

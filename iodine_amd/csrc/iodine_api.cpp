@@ -360,8 +360,8 @@ int reduce_wgrad(iodine_handle* h, hipStream_t st, int nparts, int ci_pad, int c
                  int I_dst, float alpha, int wparam, int bparam, int nbias_parts)
 {
     Buffers& b = h->buf;
-    HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, ci_pad, co_pad, O_real, I_real, I_dst, alpha, h->gacc[wparam], b.wg_fold));
-    if (nbias_parts > 0) HIPCHK(h, launch_colsum(st, b.wg_part_b, nbias_parts, O_real, O_real, alpha, h->gacc[bparam]));
+    HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, ci_pad, co_pad, O_real, I_real, I_dst, alpha, h->gacc[wparam], b.wg_fold,
+                                  b.wg_part_b, nbias_parts, h->gacc[bparam]));
     return IODINE_OK;
 }
 
@@ -384,8 +384,8 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         if (h->precision == 1) {                           // GEMM form: rows (tap, co), no N = 4 -> 32 padding
             PROF(h, st, "dec_out_wgrad", launch_dec_out_wgrad_gemm_f16x3(st, b.act[Dd - 1], b.g, b.wg_part, b.wg_part_b, N, h->S,
                                                                           Cd, &nparts, &nb));
-            HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, Cd, 4, 4, Cd, Cd, train_alpha, h->gacc[wi], b.wg_fold));
-            HIPCHK(h, launch_colsum(st, b.wg_part_b, nb, 4, 4, train_alpha, h->gacc[bi]));
+            HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, Cd, 4, 4, Cd, Cd, train_alpha, h->gacc[wi], b.wg_fold,
+                                          b.wg_part_b, nb, h->gacc[bi]));
         } else {
             PROF(h, st, "dec_out_wgrad", launch_conv3x3_wgrad_tile(st, b.act[Dd - 1], b.g, b.wg_part, b.wg_part_b, N,
                                                                     h->S, Cd, 4, &nparts, &ncop, &nb));
@@ -860,8 +860,8 @@ int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, floa
                 int nb = 0;
                 PROF(h, st, "refine_wgrad", launch_conv3x3_s2_wgrad_f16x3(st, in, b.rdpre[l], b.wg_part, b.wg_part_b, N, sz[l],
                                                                           cip, Cr, &nparts, &cipad, &nb));
-                HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, G(base + ".weight"), b.wg_fold));
-                HIPCHK(h, launch_colsum(st, b.wg_part_b, nb, Cr, Cr, 1.f, G(base + ".bias")));
+                HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, G(base + ".weight"), b.wg_fold,
+                                              b.wg_part_b, nb, G(base + ".bias")));
             } else {
                 PROF(h, st, "refine_wgrad", launch_conv3x3_wgrad_gather(st, in, b.rdpre[l], b.wg_part, N, sz[l], sz[l], cip, Cr, 2,
                                                                         &nparts, &cipad));

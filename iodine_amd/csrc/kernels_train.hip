@@ -239,10 +239,28 @@ hipError_t launch_conv3x3_wgrad_gather(hipStream_t st, const float* in, const fl
 
 // fixed-order reduction of the partial tiles into an OIHW gradient:
 //   dst[co][ci_off + ci][tap] += alpha * sum_b part[b][tap][ci][co]      (ci < I_real, co < O_real)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int ci_pad, int co_pad, int O_real,
-                                    int I_real, int I_dst, float alpha, float* __restrict__ dst)
+__global__ __launch_bounds__(256)
+void wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int ci_pad, int co_pad, int O_real,
+                         int I_real, int I_dst, float alpha, float* __restrict__ dst,
+                         const float* __restrict__ part_b, int nb, float* __restrict__ dst_b)
 {
-    const int total = 9 * ci_pad * co_pad;
+    const int total = 9 * ci_pad * co_pad, nblk_w = (total + 255) / 256;
+    if ((int)blockIdx.x >= nblk_w) {
+        // the blocks behind the weight elements sum the bias partial rows of the same launch (one column each): saves the
+        // separate column-sum launch per weight-gradient launch
+        __shared__ float s_red[256];
+        const int c = blockIdx.x - nblk_w, tid = threadIdx.x;
+        float s = 0.f;
+        for (int r = tid; r < nb; r += 256) s += part_b[(size_t)r * O_real + c];
+        s_red[tid] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) s_red[tid] += s_red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) dst_b[c] += alpha * s_red[0];
+        return;
+    }
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     const int co = e % co_pad, ci = (e / co_pad) % ci_pad, tap = e / (co_pad * ci_pad);
@@ -284,8 +302,10 @@ void wgrad_fold_kernel(const float4* __restrict__ part, int nparts, int per, int
     fold[(size_t)f * total4 + e] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
 }
 
+// part_b / dst_b (optional): nb bias partial rows [nb][O_real] of the same launch, summed into dst_b with the same alpha
 hipError_t launch_wgrad_reduce(hipStream_t st, const float* part, int nparts, int ci_pad, int co_pad, int O_real,
-                               int I_real, int I_dst, float alpha, float* dst, float* fold)
+                               int I_real, int I_dst, float alpha, float* dst, float* fold, const float* part_b, int nb,
+                               float* dst_b)
 {
     IOD_XSKIP(1);
     const int total = 9 * ci_pad * co_pad;
@@ -296,8 +316,9 @@ hipError_t launch_wgrad_reduce(hipStream_t st, const float* part, int nparts, in
         part = fold;
         nparts = nf;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, nparts, ci_pad, co_pad,
-                       O_real, I_real, I_dst, alpha, dst);
+    const bool with_b = part_b && dst_b && nb > 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256 + (with_b ? O_real : 0)), dim3(256), 0, st, part, nparts,
+                       ci_pad, co_pad, O_real, I_real, I_dst, alpha, dst, part_b, nb, dst_b);
     return hipGetLastError();
 }
 
