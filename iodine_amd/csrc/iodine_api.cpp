@@ -91,7 +91,9 @@ struct iodine_handle {
     float *raw_mlp_w = nullptr, *raw_wih = nullptr, *raw_whh = nullptr, *raw_wm = nullptr, *raw_wv = nullptr;
     std::vector<float*> ref_wb;
     std::vector<float*> ref_wf16, ref_wb16, ref_wmeta;     // split-fp16 packs of the stride-2 convs (+ {scale, 1/scale} x {fwd, dgrad})
-    std::vector<float*> gacc;                   // one per parameter, reference shapes
+    std::vector<float*> gacc;                   // one per parameter, reference shapes (slices of gacc_arena)
+    float* gacc_arena = nullptr;
+    size_t gacc_total = 0;
     bool fwd_done = false;
     int fwd_batch = 0;
     std::vector<void*> owned;
@@ -569,8 +571,16 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
         ALLOC(h->ref_wmeta[l], (size_t)4);
         if (l > 0) ALLOC(h->ref_wb16[l], (size_t)(Cr / 16) * 9 * 2 * 2 * Cr * 4);
     }
+    // gradient accumulators: ONE buffer, parameters back to back in named_parameters() order (the layout the wrapper's
+    // flat gradient buffer has too), so that zeroing and the final scale-and-add are one launch each
     h->gacc.assign(h->params.size(), nullptr);
-    for (size_t i = 0; i < h->params.size(); ++i) ALLOC(h->gacc[i], h->params[i].numel());
+    h->gacc_total = 0;
+    for (size_t i = 0; i < h->params.size(); ++i) h->gacc_total += h->params[i].numel();
+    ALLOC(h->gacc_arena, h->gacc_total);
+    {
+        size_t off = 0;
+        for (size_t i = 0; i < h->params.size(); ++i) { h->gacc[i] = h->gacc_arena + off; off += h->params[i].numel(); }
+    }
 #undef ALLOC
     std::vector<float> lin(h->S);
     iodine_linspace_host(h->S, lin.data());
@@ -781,8 +791,7 @@ int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float*
     const int B = batch, N = B * h->K, T = h->T, L = h->L;
     const size_t eps_stride = (size_t)N * L;
     h->fwd_done = false;
-    for (size_t i = 0; i < h->params.size(); ++i)
-        HIPCHK(h, hipMemsetAsync(h->gacc[i], 0, sizeof(float) * h->params[i].numel(), st));
+    HIPCHK(h, hipMemsetAsync(h->gacc_arena, 0, sizeof(float) * h->gacc_total, st));
     HIPCHK(h, launch_x_to_nhwc4(st, x, b.x4, B, h->P));
     HIPCHK(h, launch_posterior_init(st, h->init_mean, h->init_logvar, b.pm, b.plv, b.h[0], b.c[0], N, L, h->H));
     for (int i = 0; i <= T; ++i) {
@@ -878,6 +887,13 @@ int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, floa
                                                                             b.rdpre[l - 1], N, sz[l], sz[l], Cr, 2));
             }
         }
+    }
+    bool flat = true;                                          // caller's gradients back to back in the same order?
+    for (size_t p = 0; p < h->params.size() && flat; ++p)
+        flat = param_grads[p] && param_grads[p] == param_grads[0] + (h->gacc[p] - h->gacc_arena);
+    if (flat) {
+        HIPCHK(h, launch_axpy(st, h->gacc_arena, grad_scale, param_grads[0], (int)h->gacc_total));
+        return IODINE_OK;
     }
     for (size_t p = 0; p < h->params.size(); ++p) {
         if (!param_grads[p]) continue;
