@@ -511,11 +511,27 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
     float* s_h = s_x + H + 4 * L;       // H   (h_prev)
     float* s_c = s_h + H;               // H   (c1)
     float* s_red = s_c + H;             // 256
-    float* s_part = s_red + 256;        // [3][4H]: LSTM partial gate sums of the K slices 1..3
+    float* s_part = s_red + 256;        // [16][4H]: LSTM partial gate sums of the K slices
     // 1024 threads: the LSTM reduction (H + 4L + H = 768 terms per gate) is split over 4 K slices (tid >> 8); everything
     // else runs on the first 256 threads.  One block per slot: the serial depth of the gate loop set this kernel's time.
     const int n = blockIdx.x, tid = threadIdx.x & 255, ksl = threadIdx.x >> 8;
     const bool lead = ksl == 0;
+    // The matrix-vector loops below are latency chains (one L2 round trip per term if the loads are issued one term at a
+    // time): every trip requests U terms' weights before the first fma, in the ORIGINAL term order, so the results are
+    // bit-identical and a chain of n terms costs n / U round trips.
+    constexpr int U = 8;
+    // s += v[c] * W[c][j] for c = 0 .. n-1 (stride ld)
+    auto dot_chain = [&](const float* __restrict__ vs, const float* __restrict__ wT, int n, int ld, float s) {
+        for (int c = 0; c < n; c += U) {
+            float w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[u] = wT[(size_t)(c + u < n ? c + u : 0) * ld];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (c + u < n) s = fmaf(vs[c + u], w[u], s);
+        }
+        return s;
+    };
 
     // global average pool over the PL pixels of the last conv layer (F.adaptive_avg_pool2d, iodine.py:481)
     {
@@ -537,8 +553,7 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
     }
     // MLP + double ELU
     for (int j = tid; lead && j < H; j += 256) {
-        float s = mlp_b[j];
-        for (int c = 0; c < C; ++c) s = fmaf(s_pool[c], mlp_wT[(size_t)c * H + j], s);
+        const float s = dot_chain(s_pool, mlp_wT + j, C, H, mlp_b[j]);
         const float u = elu1(elu1(s));
         s_x[j] = u;
         if (sv_s) sv_s[(size_t)n * H + j] = s;                   // pre-activation (training backward recomputes the ELUs)
@@ -550,39 +565,53 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
         for (int j = tid; j < H + 4 * L; j += 256) sv_xin[(size_t)n * (H + 4 * L) + j] = s_x[j];
     // LSTM cell, gate order i, f, g, o (torch.nn.LSTMCell)
     const int IN = H + 4 * L, H4 = 4 * H;
-    // partial sums of K slices 1..3 (fixed order: slice k takes terms i = k, k+4, ...; the lead slice adds them in order)
-    for (int j = tid; j < H; j += 256) {
-        if (!lead) {
-            float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
-            for (int i = ksl; i < IN; i += 4) {
-                const float xv = s_x[i];
-                const float* w = wihT + (size_t)i * H4 + j;
-                gi = fmaf(xv, w[0], gi); gf = fmaf(xv, w[H], gf); gg = fmaf(xv, w[2 * H], gg); go = fmaf(xv, w[3 * H], go);
+    // Gate pre-activations: the (H + 4L + H)-term contraction is cut into NS = 16 K slices (rows r = ks, ks + NS, ... of
+    // [W_ih^T ; W_hh^T]) and every thread owns FOUR adjacent gate columns, so a lane moves 16 bytes per load: with one
+    // column per thread the 3.2 MB of head weights went through the CU's texture path as dword loads (~0.1 ms per launch).
+    // Partial sums meet in LDS and are added in slice order (deterministic, independent of the slot's position).
+    {
+        const int HQ = H / 4;                                    // column groups
+        const int NS = min(16, 1024 / HQ);
+        const int t = threadIdx.x, jq = t % HQ, ks = t / HQ;
+        if (ks < NS) {
+            float4 gi = make_float4(0.f, 0.f, 0.f, 0.f), gf = gi, gg = gi, go = gi;
+            const int R = IN + H;
+            constexpr int UR = 4;
+            for (int r0 = ks; r0 < R; r0 += NS * UR) {
+                float4 w[UR][4];
+                float xv[UR];
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    const int r = r0 + u * NS;
+                    const int rr = r < R ? r : ks;
+                    const float* wrow = (rr < IN ? wihT + (size_t)rr * H4 : whhT + (size_t)(rr - IN) * H4) + 4 * jq;
+                    w[u][0] = *reinterpret_cast<const float4*>(wrow);
+                    w[u][1] = *reinterpret_cast<const float4*>(wrow + H);
+                    w[u][2] = *reinterpret_cast<const float4*>(wrow + 2 * H);
+                    w[u][3] = *reinterpret_cast<const float4*>(wrow + 3 * H);
+                    xv[u] = r < R ? (rr < IN ? s_x[rr] : s_h[rr - IN]) : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    const float x = xv[u];
+                    gi.x = fmaf(x, w[u][0].x, gi.x); gi.y = fmaf(x, w[u][0].y, gi.y); gi.z = fmaf(x, w[u][0].z, gi.z); gi.w = fmaf(x, w[u][0].w, gi.w);
+                    gf.x = fmaf(x, w[u][1].x, gf.x); gf.y = fmaf(x, w[u][1].y, gf.y); gf.z = fmaf(x, w[u][1].z, gf.z); gf.w = fmaf(x, w[u][1].w, gf.w);
+                    gg.x = fmaf(x, w[u][2].x, gg.x); gg.y = fmaf(x, w[u][2].y, gg.y); gg.z = fmaf(x, w[u][2].z, gg.z); gg.w = fmaf(x, w[u][2].w, gg.w);
+                    go.x = fmaf(x, w[u][3].x, go.x); go.y = fmaf(x, w[u][3].y, go.y); go.z = fmaf(x, w[u][3].z, go.z); go.w = fmaf(x, w[u][3].w, go.w);
+                }
             }
-            for (int i = ksl; i < H; i += 4) {
-                const float hv = s_h[i];
-                const float* w = whhT + (size_t)i * H4 + j;
-                gi = fmaf(hv, w[0], gi); gf = fmaf(hv, w[H], gf); gg = fmaf(hv, w[2 * H], gg); go = fmaf(hv, w[3 * H], go);
-            }
-            float* ps = s_part + (size_t)(ksl - 1) * H4;
-            ps[j] = gi; ps[H + j] = gf; ps[2 * H + j] = gg; ps[3 * H + j] = go;
+            float* ps = s_part + (size_t)ks * H4 + 4 * jq;
+            *reinterpret_cast<float4*>(ps) = gi;
+            *reinterpret_cast<float4*>(ps + H) = gf;
+            *reinterpret_cast<float4*>(ps + 2 * H) = gg;
+            *reinterpret_cast<float4*>(ps + 3 * H) = go;
         }
     }
     __syncthreads();
     for (int j = tid; lead && j < H; j += 256) {
         float gi = lstm_b[j], gf = lstm_b[H + j], gg = lstm_b[2 * H + j], go = lstm_b[3 * H + j];
-        for (int i = 0; i < IN; i += 4) {
-            const float xv = s_x[i];
-            const float* w = wihT + (size_t)i * H4 + j;
-            gi = fmaf(xv, w[0], gi); gf = fmaf(xv, w[H], gf); gg = fmaf(xv, w[2 * H], gg); go = fmaf(xv, w[3 * H], go);
-        }
-        for (int i = 0; i < H; i += 4) {
-            const float hv = s_h[i];
-            const float* w = whhT + (size_t)i * H4 + j;
-            gi = fmaf(hv, w[0], gi); gf = fmaf(hv, w[H], gf); gg = fmaf(hv, w[2 * H], gg); go = fmaf(hv, w[3 * H], go);
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        const int NS = min(16, 1024 / (H / 4));
+        for (int q = 0; q < NS; ++q) {
             const float* ps = s_part + (size_t)q * H4;
             gi += ps[j]; gf += ps[H + j]; gg += ps[2 * H + j]; go += ps[3 * H + j];
         }
@@ -603,8 +632,7 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
         const int l = t % L;
         const bool is_lv = t >= L;
         const float* w = (is_lv ? wvT : wmT) + l;
-        float s = is_lv ? bv[l] : bm[l];
-        for (int j = 0; j < H; ++j) s = fmaf(s_c[j], w[(size_t)j * L], s);
+        const float s = dot_chain(s_c, w, H, L, is_lv ? bv[l] : bm[l]);
         float* dst = (is_lv ? plv : pm) + (size_t)n * L + l;
         *dst = *dst + s;
         float* dd = is_lv ? d_logvar_out : d_mean_out;
@@ -622,7 +650,14 @@ hipError_t launch_refine_head(hipStream_t st, const float* feat, int N, int PL, 
     IOD_XSKIP(4);
     if (256 % C != 0) return hipErrorInvalidValue;
     if ((H + 4 * L) % 4 != 0 || H % 4 != 0) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(C + (H + 4 * L) + H + H + 256 + 3 * 4 * H) * sizeof(float);
+    const size_t lds = (size_t)(C + (H + 4 * L) + H + H + 256 + 16 * 4 * H) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)refine_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (lds > 96 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(refine_head_kernel, dim3(N), dim3(1024), lds, st, feat, PL, C, H, L, mlp_wT, mlp_b, wihT, whhT,
                        lstm_b, wmT, bm, wvT, bv, latent, h_prev, c_prev, h_out, c_out, pm, plv, sv_pooled, sv_s,
                        sv_gates, sv_xin, d_mean, d_logvar);
