@@ -516,21 +516,38 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
     // else runs on the first 256 threads.  One block per slot: the serial depth of the gate loop set this kernel's time.
     const int n = blockIdx.x, tid = threadIdx.x & 255, ksl = threadIdx.x >> 8;
     const bool lead = ksl == 0;
-    // The matrix-vector loops below are latency chains (one L2 round trip per term if the loads are issued one term at a
-    // time): every trip requests U terms' weights before the first fma, in the ORIGINAL term order, so the results are
-    // bit-identical and a chain of n terms costs n / U round trips.
-    constexpr int U = 8;
-    // s += v[c] * W[c][j] for c = 0 .. n-1 (stride ld)
-    auto dot_chain = [&](const float* __restrict__ vs, const float* __restrict__ wT, int n, int ld, float s) {
-        for (int c = 0; c < n; c += U) {
-            float w[U];
+    // The matrix-vector products below (MLP, LSTM gates, posterior update) stream 3.3 MB of weights through this CU.  With
+    // one output column per thread that is a dword load per term and one L2 round trip per fma; instead every thread owns
+    // four adjacent columns (16-byte loads at the full rate of the texture path), the rows are cut into up to 16 slices
+    // that run side by side, and a few rows' weights are requested before the first fma.
+    // part[ks][col] = sum over rows r = ks, ks + NS, ... of v[r] * W[r][col]: four adjacent columns per thread (16-byte
+    // loads), NS = min(16, 1024 / (ncols / 4)) row slices, UR rows' weights requested before the first fma.  The caller
+    // adds the NS partial rows in slice order after a barrier.  Returns NS.
+    auto matvec4 = [&](const float* __restrict__ v, int nrows, const float* __restrict__ W, int ld, int ncols,
+                       float* __restrict__ part) -> int {
+        const int CQ = ncols / 4, NS = min(16, 1024 / CQ);
+        const int t = threadIdx.x, cq = t % CQ, ks = t / CQ;
+        if (ks < NS) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            constexpr int UR = 4;
+            for (int r0 = ks; r0 < nrows; r0 += NS * UR) {
+                float4 w[UR];
+                float xv[UR];
 #pragma unroll
-            for (int u = 0; u < U; ++u) w[u] = wT[(size_t)(c + u < n ? c + u : 0) * ld];
+                for (int u = 0; u < UR; ++u) {
+                    const int r = r0 + u * NS, rr = r < nrows ? r : ks;
+                    w[u] = *reinterpret_cast<const float4*>(W + (size_t)rr * ld + 4 * cq);
+                    xv[u] = r < nrows ? v[rr] : 0.f;
+                }
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (c + u < n) s = fmaf(vs[c + u], w[u], s);
+                for (int u = 0; u < UR; ++u) {
+                    acc.x = fmaf(xv[u], w[u].x, acc.x); acc.y = fmaf(xv[u], w[u].y, acc.y);
+                    acc.z = fmaf(xv[u], w[u].z, acc.z); acc.w = fmaf(xv[u], w[u].w, acc.w);
+                }
+            }
+            *reinterpret_cast<float4*>(part + (size_t)ks * ncols + 4 * cq) = acc;
         }
-        return s;
+        return NS;
     };
 
     // global average pool over the PL pixels of the last conv layer (F.adaptive_avg_pool2d, iodine.py:481)
@@ -552,8 +569,11 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
         __syncthreads();
     }
     // MLP + double ELU
+    const int ns_mlp = matvec4(s_pool, C, mlp_wT, H, H, s_part);
+    __syncthreads();
     for (int j = tid; lead && j < H; j += 256) {
-        const float s = dot_chain(s_pool, mlp_wT + j, C, H, mlp_b[j]);
+        float s = mlp_b[j];
+        for (int q = 0; q < ns_mlp; ++q) s += s_part[(size_t)q * H + j];
         const float u = elu1(elu1(s));
         s_x[j] = u;
         if (sv_s) sv_s[(size_t)n * H + j] = s;                   // pre-activation (training backward recomputes the ELUs)
@@ -628,11 +648,15 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
     }
     __syncthreads();
     // posterior update from the cell state
+    const int ns_up = matvec4(s_c, H, wmT, L, L, s_part);
+    matvec4(s_c, H, wvT, L, L, s_part + 16 * L);
+    __syncthreads();
     for (int t = tid; lead && t < 2 * L; t += 256) {
         const int l = t % L;
         const bool is_lv = t >= L;
-        const float* w = (is_lv ? wvT : wmT) + l;
-        const float s = dot_chain(s_c, w, H, L, is_lv ? bv[l] : bm[l]);
+        const float* pp = s_part + (is_lv ? 16 * L : 0);
+        float s = is_lv ? bv[l] : bm[l];
+        for (int q = 0; q < ns_up; ++q) s += pp[(size_t)q * L + l];
         float* dst = (is_lv ? plv : pm) + (size_t)n * L + l;
         *dst = *dst + s;
         float* dd = is_lv ? d_logvar_out : d_mean_out;
@@ -649,7 +673,7 @@ hipError_t launch_refine_head(hipStream_t st, const float* feat, int N, int PL, 
 {
     IOD_XSKIP(4);
     if (256 % C != 0) return hipErrorInvalidValue;
-    if ((H + 4 * L) % 4 != 0 || H % 4 != 0) return hipErrorInvalidValue;
+    if ((H + 4 * L) % 4 != 0 || H % 4 != 0 || L % 4 != 0 || C % 4 != 0) return hipErrorInvalidValue;
     const size_t lds = (size_t)(C + (H + 4 * L) + H + H + 256 + 16 * 4 * H) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
