@@ -399,16 +399,39 @@ void sgemm_kernel(int ta, int tb, int M, int N, int K, float alpha, const float*
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
     float acc = 0.f;
+    // operand tiles are fetched as float4 along their contiguous dimension when the leading dimensions allow it (16-byte
+    // loads: a quarter of the instructions, full rate of the texture path); scalar loads otherwise / at the edges
+    const int t = threadIdx.x;
+    const bool vec_ok = !tb && (lda & 3) == 0 && (ldb & 3) == 0 && (K & 3) == 0 && (M & 3) == 0 && (N & 3) == 0 &&
+                        (((size_t)A | (size_t)B) & 15) == 0;
     for (int k0 = 0; k0 < K; k0 += BK) {
-        float ra[BK / 16], rb[BK / 16];
+        if (vec_ok) {
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb4 = va;
+            if (!ta) {                                       // A [M][K]: 16 rows x 64 k, float4 along k
+                const int r = t >> 4, kq = (t & 15) * 4, gr = blockIdx.y * 16 + r;
+                if (gr < M && k0 + kq < K) va = *reinterpret_cast<const float4*>(A + (size_t)gr * lda + k0 + kq);
+                sA[r][kq] = va.x; sA[r][kq + 1] = va.y; sA[r][kq + 2] = va.z; sA[r][kq + 3] = va.w;
+            } else {                                         // A [K][M]: 64 k x 16 rows, float4 along m
+                const int kk = t >> 2, mq = (t & 3) * 4, gm = blockIdx.y * 16 + mq;
+                if (k0 + kk < K && gm < M) va = *reinterpret_cast<const float4*>(A + (size_t)(k0 + kk) * lda + gm);
+                sA[mq][kk] = va.x; sA[mq + 1][kk] = va.y; sA[mq + 2][kk] = va.z; sA[mq + 3][kk] = va.w;
+            }
+            {                                                // B [K][N]: 64 k x 16 columns, float4 along n
+                const int kk = t >> 2, nq = (t & 3) * 4, gn = blockIdx.x * 16 + nq;
+                if (k0 + kk < K && gn < N) vb4 = *reinterpret_cast<const float4*>(B + (size_t)(k0 + kk) * ldb + gn);
+                sB[kk][nq] = vb4.x; sB[kk][nq + 1] = vb4.y; sB[kk][nq + 2] = vb4.z; sB[kk][nq + 3] = vb4.w;
+            }
+        } else {
+            float ra[BK / 16], rb[BK / 16];
 #pragma unroll
-        for (int q = 0; q < BK / 16; ++q) {
-            const int ka = k0 + q * 16 + tx, kb = k0 + q * 16 + ty;
-            ra[q] = (row < M && ka < K) ? (ta ? A[(size_t)ka * lda + row] : A[(size_t)row * lda + ka]) : 0.f;
-            rb[q] = (kb < K && col < N) ? (tb ? B[(size_t)col * ldb + kb] : B[(size_t)kb * ldb + col]) : 0.f;
+            for (int q = 0; q < BK / 16; ++q) {
+                const int ka = k0 + q * 16 + tx, kb = k0 + q * 16 + ty;
+                ra[q] = (row < M && ka < K) ? (ta ? A[(size_t)ka * lda + row] : A[(size_t)row * lda + ka]) : 0.f;
+                rb[q] = (kb < K && col < N) ? (tb ? B[(size_t)col * ldb + kb] : B[(size_t)kb * ldb + col]) : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < BK / 16; ++q) { sA[ty][q * 16 + tx] = ra[q]; sB[q * 16 + ty][tx] = rb[q]; }
         }
-#pragma unroll
-        for (int q = 0; q < BK / 16; ++q) { sA[ty][q * 16 + tx] = ra[q]; sB[q * 16 + ty][tx] = rb[q]; }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < BK; ++k) acc = fmaf(sA[ty][k], sB[k][tx], acc);
