@@ -308,6 +308,7 @@ hipError_t launch_wgrad_reduce(hipStream_t st, const float* part, int nparts, in
                                float* dst_b)
 {
     IOD_XSKIP(1);
+    if (nparts <= 0) return hipSuccess;
     const int total = 9 * ci_pad * co_pad;
     if (fold && nparts >= 4 * WGRAD_FOLD && total % 4 == 0) {
         const int per = (nparts + WGRAD_FOLD - 1) / WGRAD_FOLD, nf = (nparts + per - 1) / per;

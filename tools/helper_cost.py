@@ -13,7 +13,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else 'train'
 GROUPS = {1: 'partial-tile reductions (fold / reduce / colsum)', 2: 'head-backward GEMMs (sgemm)', 4: 'refine head',
           8: 'pixel passes', 16: 'broadcast layer forward', 32: 'broadcast layer backward', 64: 'pointwise / axpy / transpose',
           128: 'output conv forward', 256: 'output conv data gradient', 512: 'refinement convs forward',
-          1024: 'refinement conv gradients', 2048: 'output conv weight gradient'}
+          1024: "refinement conv gradients (dgrad only: wgrad needs its reduction)", 2048: 'output conv weight gradient'}
 B = 32
 arch = clevr6_arch()
 m = IODINE(arch).to('cuda:0')
