@@ -125,7 +125,9 @@ __host__ __device__ constexpr size_t conv_wpk_elems(int cin, int cout) {
     return (size_t)conv_nchunk(cin) * conv_nqp(cin) * cout;
 }
 
-enum ConvEpilogue { EPI_BIAS_ELU = 0, EPI_MUL_ELUGRAD = 1, EPI_NONE = 2, EPI_OUT4 = 3 };
+// EPI_L0ROWS: data-gradient form whose result is not stored but reduced to per-row left / interior / right sums
+// (rows_p[n][y][tile x][3][C]): the input of the broadcast layer's backward when nothing else needs d(pre-activation 0)
+enum ConvEpilogue { EPI_BIAS_ELU = 0, EPI_MUL_ELUGRAD = 1, EPI_NONE = 2, EPI_OUT4 = 3, EPI_L0ROWS = 4 };
 
 // ---- launchers (each returns hipError_t from the launch) -------------------------------
 hipError_t launch_pack_conv_weights(hipStream_t st, const float* src_oihw, int O, int I, int cin_pad,
@@ -158,6 +160,7 @@ hipError_t launch_dec_v(hipStream_t st, const float* pm, const float* plv, const
 hipError_t launch_dec_l0(hipStream_t st, const float* V, const float* cmap, float* out, int N, int S, int C);
 // slot groups of the fused layer-0 reduction (each at most 32 slots); Dpart holds l0_dgroups(N) * P * C floats
 inline int l0_dgroups(int N) { const int g = (N + 31) / 32; return g < 8 ? 8 : g; }
+hipError_t launch_l0_reduce_cls_tiles(hipStream_t st, const float* rows_p, float* Rc, int N, int S, int C);
 hipError_t launch_l0_reduce(hipStream_t st, const float* dpre, float* rows, float* Rc, int N, int S, int C, float* Dpart,
                             float* Dacc, float alpha, int first);
 hipError_t launch_dz_latent(hipStream_t st, const float* Rc, const float* wclsT, const float* pm, const float* plv,

@@ -37,7 +37,7 @@ struct Arena {
 struct Buffers {               // workspace carve-up for one batch size / mode
     int B = 0, mode = -1;
     size_t bytes = 0;
-    float *x4, *V, *dec_out, *g, *lnstat, *ll_img, *img_terms, *scal, *rows, *Rc, *pm, *plv;
+    float *x4, *V, *dec_out, *g, *lnstat, *ll_img, *img_terms, *scal, *rows, *rows_p, *Rc, *pm, *plv;
     double* part;
     std::vector<float*> act;                   // decoder activations a[0..Dd-1]   (N,P,Cd)
     float* dpre[2];                            // ping-pong gradient wrt pre-activations
@@ -80,6 +80,7 @@ struct iodine_handle {
     std::vector<float*> dec_wf16, dec_wb16, dec_wmeta;   // split-fp16 packs (+ {scale, 1/scale, scale_b, 1/scale_b})
     int precision = 1;                          // 0: exact fp32 MFMA, 1: 3 x fp16 MFMA split (fp32-class accuracy)
     int wgrad_ws = 2;                           // decoder 64->64 weight gradient: 0 one-role kernel, 1 warp-specialised (transposing stagers + v_alignbit), 2 warp-specialised with ds_read_b64_tr_b16
+    int fuse_l0 = 1;                            // inference: layer-1 data gradient reduces straight to the layer-0 row sums
     int out_variant = 1;                        // output conv forward: 1 = streaming (fragments straight from global), 0 = LDS-staged
     int zigzag = 1;                             // odd decoder layers walk the tiles backwards (Infinity Cache reuse)
     int variant = 1;                            // split-fp16 tile conv: 1 = one tile per block (2 blocks/CU), 3 = warp-specialised persistent (experimental)
@@ -249,6 +250,7 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
     b.img_terms = a.take<float>((size_t)(T + 1) * B * 2);
     b.scal = a.take<float>((size_t)(T + 1) * 3 + 4);
     b.rows = a.take<float>((size_t)N * h->S * 3 * Cd);
+    b.rows_p = a.take<float>((size_t)N * h->S * (h->S / 16 > 0 ? h->S / 16 : 1) * 3 * Cd);   // per-tile row sums (EPI_L0ROWS)
     b.Rc = a.take<float>((size_t)N * 9 * Cd);
     b.pm = a.take<float>((size_t)N * L);
     b.plv = a.take<float>((size_t)N * L);
@@ -376,6 +378,7 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
     Buffers& b = h->buf;
     const int Cd = h->Cd, Dd = h->Dd;
     int cur = 0, nparts = 0, ncop = 0, nb = 0, rc;
+    bool fused_l0 = false;
 #ifdef IODINE_XSKIP_HOOK
     if (!(g_iod_xskip & 256))
 #endif
@@ -411,15 +414,23 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
                               param_index(h, base + ".bias"), nb);
             if (rc) return rc;
         }
+        // Inference: nothing but the broadcast layer's row / class sums needs d(pre-activation 0), so the last data gradient
+        // reduces its tile to per-row sums in its epilogue (EPI_L0ROWS) and the 0.94 GB tensor is neither written nor re-read.
+        fused_l0 = l == 1 && train_alpha == 0.f && h->precision == 1 && h->variant == 1 && h->fuse_l0;
         if (h->precision == 1)
             PROF(h, st, "conv_tile_dgrad", conv_f16x3(h, st, b.dpre[cur], h->dec_wb16[l], h->dec_wmeta[l] + 2, nullptr,
-                                                      b.act[l - 1], b.dpre[cur ^ 1], N, h->S, Cd, Cd, EPI_MUL_ELUGRAD, l));
+                                                      b.act[l - 1], fused_l0 ? b.rows_p : b.dpre[cur ^ 1], N, h->S, Cd, Cd,
+                                                      fused_l0 ? EPI_L0ROWS : EPI_MUL_ELUGRAD, l));
         else
             PROF(h, st, "conv_tile_dgrad", launch_conv3x3_tile(st, b.dpre[cur], h->dec_wb[l], nullptr, b.act[l - 1],
                                                                b.dpre[cur ^ 1], N, h->S, Cd, Cd, EPI_MUL_ELUGRAD));
         cur ^= 1;
     }
     *dpre0 = b.dpre[cur];
+    if (fused_l0) {
+        PROF(h, st, "l0_reduce", launch_l0_reduce_cls_tiles(st, b.rows_p, b.Rc, N, h->S, Cd));
+        return IODINE_OK;
+    }
     // row / class sums of dpre0 for dz; in training the same read also feeds the slot-summed gradient map, which is
     // accumulated (with this pass's factor) over the T+1 passes and consumed once after the last one
     PROF(h, st, "l0_reduce", launch_l0_reduce(st, *dpre0, b.rows, b.Rc, N, h->S, Cd, train_alpha != 0.f ? b.Dpart : nullptr,
@@ -709,6 +720,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
 #ifdef IODINE_XSKIP_HOOK
     if (!strcmp(key, "xskip")) { g_iod_xskip = (int)value; return IODINE_OK; }       // timing-only ablation builds (common.h)
 #endif
+    if (!strcmp(key, "fuse_l0")) { h->fuse_l0 = value != 0; return IODINE_OK; }
     if (!strcmp(key, "out_variant")) { h->out_variant = value != 0; return IODINE_OK; }
     if (!strcmp(key, "zigzag")) { h->zigzag = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {

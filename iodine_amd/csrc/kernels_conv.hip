@@ -780,7 +780,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     const unsigned vbase = (unsigned)((((ty * 16 + 4 * wv) * S + tx * 16 + pl) * COUT + seg * 4) * 4);
     f32x4 ax[NEP];
     auto prefetch_aux = [&]() {
-        if constexpr (EPI == EPI_MUL_ELUGRAD) {
+        if constexpr (EPI == EPI_MUL_ELUGRAD || EPI == EPI_L0ROWS) {
             const i32x4_ rsrc_aux = make_rsrc(aux + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
 #pragma unroll
             for (int j = 0; j < NEP; ++j) {
@@ -829,7 +829,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     // (li, kh) holds pixel li of the 32-pixel tile and channels 8g + 4kh .. +3 in registers 4g .. 4g+3: the epilogue
     // moves float4s of 4 consecutive channels.  Stores (and the ELU' operand of the data-gradient form) are raw buffer
     // operations on the slot-image: one byte offset per 32-pixel tile and lane, channel group in the scalar offset.
-    static_assert(EPI == EPI_BIAS_ELU || EPI == EPI_MUL_ELUGRAD, "the C -> 4 output conv has its own GEMM-form kernel");
+    static_assert(EPI == EPI_BIAS_ELU || EPI == EPI_MUL_ELUGRAD || EPI == EPI_L0ROWS, "the C -> 4 output conv has its own GEMM-form kernel");
     {
         const i32x4_ rsrc_out = make_rsrc(out + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
 #ifdef IODINE_TILE_EPI_DIRECT
@@ -866,7 +866,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             b4 = f32x4{t.x, t.y, t.z, t.w};
             asm volatile("" : "+v"(b4));                     // (pinned before the asm stores, see the direct form)
         }
-        if constexpr (EPI == EPI_MUL_ELUGRAD) {
+        if constexpr (EPI == EPI_MUL_ELUGRAD || EPI == EPI_L0ROWS) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < NEP; ++j) asm volatile("" : "+v"(ax[j]));
@@ -895,19 +895,58 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // instruction j: pixels j*PPI .. of the wave's 64 (tile row (j*PPI)/16, columns (j*PPI)%16 ..), bias + ELU or the
         // ELU' factor applied in this layout (a lane keeps ONE float4 of bias: its channel segment never changes)
+        // EPI_L0ROWS: per tile row the left-border / interior / right-border column sums instead of the pixels
+        f32x4 rsum[EPI == EPI_L0ROWS ? 4 : 1][3];
+        if constexpr (EPI == EPI_L0ROWS) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rsum[rr][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int j = 0; j < NEP; ++j) {
             const int pq = j * PPI;
             f32x4 v = *reinterpret_cast<const f32x4*>(s_ep + (pq + pl) * EPS + seg * 16);
             if constexpr (EPI == EPI_BIAS_ELU) {
                 v = f32x4{elu1_fast(v.x + b4.x), elu1_fast(v.y + b4.y), elu1_fast(v.z + b4.z), elu1_fast(v.w + b4.w)};
-            } else if constexpr (EPI == EPI_MUL_ELUGRAD) {
+            } else {
                 const f32x4 a4 = ax[j];
                 v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
                 v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
             }
-            const int soff = ((pq / 16) * S + pq % 16) * COUT * 4;
-            asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v), "v"(vbase), "s"(rsrc_out), "s"(soff) : "memory");
+            if constexpr (EPI == EPI_L0ROWS) {
+                const int gx = tx * 16 + pq % 16 + pl;
+                const float wl = gx == 0 ? 1.f : 0.f, wr = gx == S - 1 ? 1.f : 0.f, wm = 1.f - wl - wr;
+                rsum[pq / 16][0] += v * wl; rsum[pq / 16][1] += v * wm; rsum[pq / 16][2] += v * wr;
+            } else {
+                const int soff = ((pq / 16) * S + pq % 16) * COUT * 4;
+                asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v), "v"(vbase), "s"(rsrc_out), "s"(soff) : "memory");
+            }
+        }
+        if constexpr (EPI == EPI_L0ROWS) {
+            // lanes (pl, seg) -> sum over the PPI pixel lanes through the (now free) tile region, one tile row at a time:
+            // out = rows_p[n][y][tx][3][COUT]
+            f32x4* s_rs = reinterpret_cast<f32x4*>(s_ep);
+            float* rows_p = out;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int c = 0; c < 3; ++c) s_rs[lane * 3 + c] = rsum[rr][c];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < 3 * SEGS) {
+                    const int c = lane / SEGS, sg = lane % SEGS;
+                    f32x4 t = s_rs[sg * 3 + c];
+#pragma unroll
+                    for (int q = 1; q < PPI; ++q) t += s_rs[(q * SEGS + sg) * 3 + c];
+                    const int gy = ty * 16 + 4 * wv + rr;
+                    *reinterpret_cast<f32x4*>(rows_p + ((((size_t)n * S + gy) * tiles + tx) * 3 + c) * COUT + sg * 4) = t;
+                }
+            }
         }
 #else
 #pragma unroll
@@ -986,8 +1025,8 @@ hipError_t launch_conv3x3_tile_f16x3(hipStream_t st, const float* in, const void
     if (S % 16 != 0) return hipErrorInvalidValue;
 #define T16_CASE(CI, CO, EP) \
     if (cin == CI && cout == CO && epi == EP) return launch_tile_f16x3_inst<CI, CO, EP>(st, in, wpk, wmeta, bias, aux, out, N, S, rev);
-    T16_CASE(64, 64, EPI_BIAS_ELU) T16_CASE(64, 64, EPI_MUL_ELUGRAD)
-    T16_CASE(32, 32, EPI_BIAS_ELU) T16_CASE(32, 32, EPI_MUL_ELUGRAD)
+    T16_CASE(64, 64, EPI_BIAS_ELU) T16_CASE(64, 64, EPI_MUL_ELUGRAD) T16_CASE(64, 64, EPI_L0ROWS)
+    T16_CASE(32, 32, EPI_BIAS_ELU) T16_CASE(32, 32, EPI_MUL_ELUGRAD) T16_CASE(32, 32, EPI_L0ROWS)
 #undef T16_CASE
     return hipErrorInvalidValue;
 }

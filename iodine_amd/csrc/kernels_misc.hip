@@ -228,6 +228,46 @@ __global__ void l0_reduce_cls_kernel(const float* __restrict__ rows, float* __re
     }
 }
 
+// The same from per-tile row sums rows_p[n][y][tile x][3][C] (written by the EPI_L0ROWS epilogue of the layer-1 data
+// gradient, which then never stores d(pre-activation 0)): sum over the tile columns first, then over the rows by class.
+__global__ void l0_reduce_cls_tiles_kernel(const float* __restrict__ rows_p, float* __restrict__ Rc, int S, int C, int tiles)
+{
+    __shared__ float s_mid[4][192];
+    const int n = blockIdx.x, W = 3 * C;
+    const int t = threadIdx.x % W, slice = threadIdx.x / W;
+    const float* src = rows_p + (size_t)n * S * tiles * W + t;
+    auto row_sum = [&](int y) {
+        const float* p = src + (size_t)y * tiles * W;
+        float a = 0.f, b = 0.f;
+        int tx = 0;
+        for (; tx + 1 < tiles; tx += 2) { a += p[(size_t)tx * W]; b += p[(size_t)(tx + 1) * W]; }
+        if (tx < tiles) a += p[(size_t)tx * W];
+        return a + b;
+    };
+    const int per = (S - 2 + 3) / 4, y0 = 1 + slice * per, y1 = min(S - 1, y0 + per);
+    float a0 = 0.f, a1 = 0.f;
+    int y = y0;
+    for (; y + 1 < y1; y += 2) { a0 += row_sum(y); a1 += row_sum(y + 1); }
+    if (y < y1) a0 += row_sum(y);
+    s_mid[slice][t] = a0 + a1;
+    __syncthreads();
+    if (slice == 0) {
+        float* o = Rc + (size_t)n * 9 * C;
+        const int cc = t / C, co = t % C;
+        o[(0 * 3 + cc) * C + co] = row_sum(0);
+        o[(1 * 3 + cc) * C + co] = (s_mid[0][t] + s_mid[1][t]) + (s_mid[2][t] + s_mid[3][t]);
+        o[(2 * 3 + cc) * C + co] = row_sum(S - 1);
+    }
+}
+
+hipError_t launch_l0_reduce_cls_tiles(hipStream_t st, const float* rows_p, float* Rc, int N, int S, int C)
+{
+    IOD_XSKIP(32);
+    if (C > 64 || S % 16 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(l0_reduce_cls_tiles_kernel, dim3(N), dim3(4 * 3 * C), 0, st, rows_p, Rc, S, C, S / 16);
+    return hipGetLastError();
+}
+
 // Fused variant for rows of exactly NIT*256 float4: one block per (image row y, slot group g) walks the slots of its
 // group, reading dpre0 ONCE for both consumers:
 //   rows[n][y][3][C]   left / interior / right sums of this row (as above)
