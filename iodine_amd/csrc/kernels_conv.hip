@@ -746,30 +746,6 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     // data-gradient form: the ELU' operand (the saved activation of the layer below, one float4 per accumulator quad) is
     // requested right after the LAST chunk has been staged - its input / weight registers are free by then - and arrives
     // under the last 108 MFMAs instead of being waited for in the epilogue
-#ifdef IODINE_TILE_EPI_DIRECT
-    f32x4 ax[2][NT][4];
-    unsigned voff[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int gy = ty * 16 + 4 * wv + 2 * mt + (li >> 4), gx = tx * 16 + (li & 15);
-        voff[mt] = (unsigned)(((gy * S + gx) * COUT + 4 * kh) * 4);
-    }
-    auto prefetch_aux = [&]() {
-        if constexpr (EPI == EPI_MUL_ELUGRAD) {
-            const i32x4_ rsrc_aux = make_rsrc(aux + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int soff = (nt * 32 + 8 * g4) * 4;
-                        IOD_SGPR_SETTLE(rsrc_aux, soff);
-                        IOD_BLOAD4(ax[mt][nt][g4], voff[mt], rsrc_aux, soff);
-                    }
-        }
-    };
-#else
     // Output-side lane mapping (see the epilogue): lane = (pixel pl of PPI, 16-byte channel segment seg); instruction j
     // covers pixels j*PPI .. of the wave's 64.  The ELU' operand is fetched in exactly this shape - whole pixels, 1 KB
     // per instruction - and applied AFTER the accumulators have been transposed through LDS.
@@ -790,7 +766,6 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             }
         }
     };
-#endif
     TP_STAMP(0);                                             // [0] block start: index arithmetic
     prefetch_in(0, rinA);
     prefetch_w(0);
@@ -832,34 +807,6 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     static_assert(EPI == EPI_BIAS_ELU || EPI == EPI_MUL_ELUGRAD || EPI == EPI_L0ROWS, "the C -> 4 output conv has its own GEMM-form kernel");
     {
         const i32x4_ rsrc_out = make_rsrc(out + (size_t)n * S * S * COUT, (unsigned)(S * S * COUT * 4));
-#ifdef IODINE_TILE_EPI_DIRECT
-        f32x4 bv[NT][4];
-        if constexpr (EPI == EPI_BIAS_ELU) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 t = *reinterpret_cast<const float4*>(bias + nt * 32 + 8 * g4 + 4 * kh);
-                    bv[nt][g4] = f32x4{t.x, t.y, t.z, t.w};
-                }
-            // pin the bias values in registers HERE: a compiler-generated vmcnt wait for one of these loads placed between
-            // the asm stores below would also wait for every store issued before it (stores count in vmcnt on gfx9)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(bv[nt][g4]));
-        }
-        if constexpr (EPI == EPI_MUL_ELUGRAD) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(ax[mt][nt][g4]));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#else
         f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (EPI == EPI_BIAS_ELU) {
             const float4 t = *reinterpret_cast<const float4*>(bias + seg * 4);
@@ -872,8 +819,6 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             for (int j = 0; j < NEP; ++j) asm volatile("" : "+v"(ax[j]));
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
-#ifndef IODINE_TILE_EPI_DIRECT
         // The finished tile goes through LDS once more so that the global stores are CONTIGUOUS: a lane's accumulator
         // float4 is 16 bytes of one pixel (256-byte pixel stride: a direct store instruction touches 32 cache lines with
         // 32 bytes each), whereas after the transposition every store instruction writes four whole pixels = 1 KB.
@@ -920,7 +865,14 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
                 rsum[pq / 16][0] += v * wl; rsum[pq / 16][1] += v * wm; rsum[pq / 16][2] += v * wr;
             } else {
                 const int soff = ((pq / 16) * S + pq % 16) * COUT * 4;
+                // (the s_nops cover two hazards hipcc's recognizer cannot see inside inline asm: an SGPR written by the
+                //  SALU needs 5 wait states before a VMEM instruction reads it, and a VALU write of the store's data VGPRs
+                //  has to wait for the store to have read them)
+#ifdef IODINE_ABL_NOSTORE
+                asm volatile("" :: "v"(v), "v"(vbase), "s"(rsrc_out), "s"(soff) : "memory");
+#else
                 asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v), "v"(vbase), "s"(rsrc_out), "s"(soff) : "memory");
+#endif
             }
         }
         if constexpr (EPI == EPI_L0ROWS) {
@@ -948,33 +900,6 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
                 }
             }
         }
-#else
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    f32x4 v = f32x4{acc[mt][nt][4 * g4] * inv_ws, acc[mt][nt][4 * g4 + 1] * inv_ws,
-                                    acc[mt][nt][4 * g4 + 2] * inv_ws, acc[mt][nt][4 * g4 + 3] * inv_ws};
-                    if constexpr (EPI == EPI_BIAS_ELU) {
-                        const f32x4 b4 = bv[nt][g4];
-                        v = f32x4{elu1_fast(v.x + b4.x), elu1_fast(v.y + b4.y), elu1_fast(v.z + b4.z), elu1_fast(v.w + b4.w)};
-                    } else if constexpr (EPI == EPI_MUL_ELUGRAD) {
-                        const f32x4 a4 = ax[mt][nt][g4];
-                        v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
-                        v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
-                    }
-                    const int soff = (nt * 32 + 8 * g4) * 4;
-                    // (the s_nop covers the ">64-bit store data, then VALU write of those VGPRs" hazard that hipcc's
-                    // hazard recognizer would handle for its own stores but cannot see inside inline asm)
-#ifdef IODINE_ABL_NOSTORE
-                    asm volatile("" :: "v"(v), "v"(voff[mt]), "s"(rsrc_out), "s"(soff) : "memory");
-#else
-                    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v), "v"(voff[mt]), "s"(rsrc_out), "s"(soff) : "memory");
-#endif
-                }
-#endif
     }
     TP_STAMP(7);                                             // [7] epilogue (issue of the stores)
     TP_FLUSH(g_tile_prof);
