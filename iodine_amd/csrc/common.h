@@ -160,6 +160,10 @@ hipError_t launch_dec_v(hipStream_t st, const float* pm, const float* plv, const
 hipError_t launch_dec_l0(hipStream_t st, const float* V, const float* cmap, float* out, int N, int S, int C);
 // slot groups of the fused layer-0 reduction (each at most 32 slots); Dpart holds l0_dgroups(N) * P * C floats
 inline int l0_dgroups(int N) { const int g = (N + 31) / 32; return g < 8 ? 8 : g; }
+// several small device-to-device copies in ONE launch (iodine_set_params: biases and raw weight copies)
+constexpr int MCOPY_MAX = 24;
+struct MultiCopy { const float* src[MCOPY_MAX]; float* dst[MCOPY_MAX]; int n[MCOPY_MAX]; int count; };
+hipError_t launch_multi_copy(hipStream_t st, const MultiCopy& mc);
 hipError_t launch_l0_reduce_cls_tiles(hipStream_t st, const float* rows_p, float* Rc, int N, int S, int C);
 hipError_t launch_l0_reduce(hipStream_t st, const float* dpre, float* rows, float* Rc, int N, int S, int C, float* Dpart,
                             float* Dacc, float alpha, int first);

@@ -630,6 +630,18 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         if (!dev[i]) return h->fail(IODINE_ERR_INVALID, "iodine_set_params: null pointer for " + h->params[i].name);
     hipStream_t st = (hipStream_t)stream;
     auto P = [&](const std::string& name) { return dev[param_index(h, name)]; };
+    // plain copies (biases, raw weights of the head backward) are collected and issued as one launch
+    MultiCopy mc;
+    mc.count = 0;
+    auto queue_copy = [&](float* dst, const float* src, size_t count) -> hipError_t {
+        if (mc.count == MCOPY_MAX) {
+            const hipError_t e = launch_multi_copy(st, mc);
+            if (e != hipSuccess) return e;
+            mc.count = 0;
+        }
+        mc.src[mc.count] = src; mc.dst[mc.count] = dst; mc.n[mc.count] = (int)count; ++mc.count;
+        return hipSuccess;
+    };
     const int L = h->L, Cd = h->Cd, Cr = h->Cr, H = h->H;
     // decoder
     HIPCHK(h, launch_dec_l0_prepare(st, P("decoder.mlc.layers.0.weight"), P("decoder.mlc.layers.0.bias"), h->lin, Cd, L,
@@ -642,11 +654,10 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         }
         HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cd, Cd, Cd, Cd, 0, h->dec_wmeta[l], h->dec_wf16[l]));
         HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cd, Cd, Cd, Cd, 1, h->dec_wmeta[l] + 2, h->dec_wb16[l]));
-        HIPCHK(h, hipMemcpyAsync(h->dec_b[l], P("decoder.mlc.layers." + std::to_string(l) + ".bias"), sizeof(float) * Cd,
-                                 hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, queue_copy(h->dec_b[l], P("decoder.mlc.layers." + std::to_string(l) + ".bias"), Cd));
     }
     HIPCHK(h, launch_pack_dec_out(st, P("decoder.conv.weight"), h->dec_out_w, Cd));
-    HIPCHK(h, hipMemcpyAsync(h->dec_out_b, P("decoder.conv.bias"), sizeof(float) * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, queue_copy(h->dec_out_b, P("decoder.conv.bias"), 4));
     HIPCHK(h, launch_pack_conv_weights(st, P("decoder.conv.weight"), 4, Cd, 4, Cd, 1, h->dec_out_wb));
     HIPCHK(h, launch_pack_dec_out_gemm(st, P("decoder.conv.weight"), Cd, h->dec_out_meta, h->dec_out_w16));
     // refinement conv stack
@@ -654,8 +665,7 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     for (int l = 0; l < h->Dr; ++l) {
         const float* w = P("refine.mlc.layers." + std::to_string(l) + ".weight");
         if (ref_fp32) HIPCHK(h, launch_pack_conv_weights(st, w, Cr, l == 0 ? 17 : Cr, l == 0 ? 20 : Cr, Cr, 0, h->ref_w[l]));
-        HIPCHK(h, hipMemcpyAsync(h->ref_b[l], P("refine.mlc.layers." + std::to_string(l) + ".bias"), sizeof(float) * Cr,
-                                 hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, queue_copy(h->ref_b[l], P("refine.mlc.layers." + std::to_string(l) + ".bias"), Cr));
     }
     for (int l = 1; l < h->Dr && ref_fp32; ++l)
         HIPCHK(h, launch_pack_conv_weights(st, P("refine.mlc.layers." + std::to_string(l) + ".weight"), Cr, Cr, Cr, Cr, 2,
@@ -670,8 +680,7 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         }
     }
     auto copy_raw = [&](float* dst, const std::string& name) {
-        return hipMemcpyAsync(dst, P(name), sizeof(float) * h->params[param_index(h, name)].numel(),
-                              hipMemcpyDeviceToDevice, st);
+        return queue_copy(dst, P(name), h->params[param_index(h, name)].numel());
     };
     HIPCHK(h, copy_raw(h->raw_mlp_w, "refine.mlp.layers.0.weight"));
     HIPCHK(h, copy_raw(h->raw_wih, "refine.lstm.weight_ih"));
@@ -680,16 +689,17 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     HIPCHK(h, copy_raw(h->raw_wv, "refine.logvar_update.weight"));
     // head
     HIPCHK(h, launch_transpose(st, P("refine.mlp.layers.0.weight"), h->mlp_wT, H, Cr));
-    HIPCHK(h, hipMemcpyAsync(h->mlp_b, P("refine.mlp.layers.0.bias"), sizeof(float) * H, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, queue_copy(h->mlp_b, P("refine.mlp.layers.0.bias"), H));
     HIPCHK(h, launch_transpose(st, P("refine.lstm.weight_ih"), h->wihT, 4 * H, H + 4 * L));
     HIPCHK(h, launch_transpose(st, P("refine.lstm.weight_hh"), h->whhT, 4 * H, H));
     HIPCHK(h, launch_add2(st, P("refine.lstm.bias_ih"), P("refine.lstm.bias_hh"), h->lstm_b, 4 * H));
     HIPCHK(h, launch_transpose(st, P("refine.mean_update.weight"), h->wmT, L, H));
     HIPCHK(h, launch_transpose(st, P("refine.logvar_update.weight"), h->wvT, L, H));
-    HIPCHK(h, hipMemcpyAsync(h->bm, P("refine.mean_update.bias"), sizeof(float) * L, hipMemcpyDeviceToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(h->bv, P("refine.logvar_update.bias"), sizeof(float) * L, hipMemcpyDeviceToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(h->init_mean, P("posterior.init_mean"), sizeof(float) * L, hipMemcpyDeviceToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(h->init_logvar, P("posterior.init_logvar"), sizeof(float) * L, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, queue_copy(h->bm, P("refine.mean_update.bias"), L));
+    HIPCHK(h, queue_copy(h->bv, P("refine.logvar_update.bias"), L));
+    HIPCHK(h, queue_copy(h->init_mean, P("posterior.init_mean"), L));
+    HIPCHK(h, queue_copy(h->init_logvar, P("posterior.init_logvar"), L));
+    HIPCHK(h, launch_multi_copy(st, mc));
     h->params_set = true;
     h->fwd_done = false;
     return IODINE_OK;

@@ -740,6 +740,24 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
     }
 }
 
+__global__ void multi_copy_kernel(const MultiCopy mc)
+{
+    const int j = blockIdx.y;
+    const float* __restrict__ src = mc.src[j];
+    float* __restrict__ dst = mc.dst[j];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < mc.n[j]; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+hipError_t launch_multi_copy(hipStream_t st, const MultiCopy& mc)
+{
+    if (mc.count <= 0) return hipSuccess;
+    int nmax = 1;
+    for (int j = 0; j < mc.count; ++j) nmax = mc.n[j] > nmax ? mc.n[j] : nmax;
+    const int bx = (nmax + 255) / 256 < 256 ? (nmax + 255) / 256 : 256;
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(bx, mc.count), dim3(256), 0, st, mc);
+    return hipGetLastError();
+}
+
 hipError_t launch_transpose(hipStream_t st, const float* src, float* dst, int R, int Cc)
 {
     IOD_XSKIP(64);
