@@ -138,6 +138,7 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * "fuse_l0" (1 -- default: in iodine_reconstruct the last decoder data gradient reduces its result to the broadcast layer's
  * row sums in its epilogue instead of storing it; 0 = store and reduce in a second kernel, as the training path does),
  * "out_variant" (output conv forward: 1 = streaming kernel -- default, 0 = LDS-staged),
+ * "out_dgrad_variant" (output conv data gradient: 1 = split-fp16 streaming kernel -- default, 0 = generic fp32 tile kernel),
  * "zigzag" (1 -- default: odd decoder layers walk their tiles backwards so that a launch starts on what the previous one
  * wrote last; 0 = every launch in ascending order; results identical),
  * "wgrad_ws" (split-fp16 64->64 / 32->32 weight gradient: 2 = warp-specialised, natural-order staging + transposing LDS

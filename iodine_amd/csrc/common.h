@@ -228,6 +228,9 @@ hipError_t launch_adam_multi(hipStream_t st, const long long* ptrs, const long l
 hipError_t launch_ari_table(hipStream_t st, const float* mask, const unsigned char* gt, int B, int K, int G, int P,
                             int* table);
 hipError_t launch_pack_dec_out_gemm(hipStream_t st, const float* w, int C, float* meta, void* dst);
+hipError_t launch_pack_dec_out_dgrad(hipStream_t st, const float* w, int C, const float* meta, void* dst);
+hipError_t launch_dec_out_dgrad_f16x3(hipStream_t st, const float* g, const void* wpk, const float* wmeta, const float* aux,
+                                      float* out, int N, int S, int C);
 hipError_t launch_dec_out_stream_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                        const float* bias, float* out, int N, int S, int C);
 hipError_t launch_dec_out_gemm_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,

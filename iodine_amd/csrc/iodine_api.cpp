@@ -80,11 +80,13 @@ struct iodine_handle {
     std::vector<float*> dec_wf16, dec_wb16, dec_wmeta;   // split-fp16 packs (+ {scale, 1/scale, scale_b, 1/scale_b})
     int precision = 1;                          // 0: exact fp32 MFMA, 1: 3 x fp16 MFMA split (fp32-class accuracy)
     int wgrad_ws = 2;                           // decoder 64->64 weight gradient: 0 one-role kernel, 1 warp-specialised (transposing stagers + v_alignbit), 2 warp-specialised with ds_read_b64_tr_b16
+    int out_dgrad_variant = 1;                  // output conv data gradient: 1 = split-fp16 streaming kernel, 0 = generic fp32 tile kernel
     int fuse_l0 = 1;                            // inference: layer-1 data gradient reduces straight to the layer-0 row sums
     int out_variant = 1;                        // output conv forward: 1 = streaming (fragments straight from global), 0 = LDS-staged
     int zigzag = 1;                             // odd decoder layers walk the tiles backwards (Infinity Cache reuse)
     int variant = 1;                            // split-fp16 tile conv: 1 = one tile per block (2 blocks/CU), 3 = warp-specialised persistent (experimental)
-    float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr, *dec_out_w16 = nullptr, *dec_out_meta = nullptr;
+    float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr, *dec_out_w16 = nullptr, *dec_out_meta = nullptr,
+          *dec_out_wb16 = nullptr;               // split-fp16 pack of the output conv for its data gradient
     std::vector<float*> ref_w, ref_b;
     float *mlp_wT = nullptr, *mlp_b = nullptr, *wihT = nullptr, *whhT = nullptr, *lstm_b = nullptr;
     float *wmT = nullptr, *bm = nullptr, *wvT = nullptr, *bv = nullptr, *init_mean = nullptr, *init_logvar = nullptr;
@@ -382,8 +384,14 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
 #ifdef IODINE_XSKIP_HOOK
     if (!(g_iod_xskip & 256))
 #endif
-    PROF(h, st, "dec_out_dgrad", launch_conv3x3_tile(st, b.g, h->dec_out_wb, nullptr, b.act[Dd - 1], b.dpre[cur], N,
-                                                     h->S, 4, Cd, EPI_MUL_ELUGRAD));
+    {
+        if (h->precision == 1 && h->out_dgrad_variant)
+            PROF(h, st, "dec_out_dgrad", launch_dec_out_dgrad_f16x3(st, b.g, h->dec_out_wb16, h->dec_out_meta, b.act[Dd - 1],
+                                                                     b.dpre[cur], N, h->S, Cd));
+        else
+            PROF(h, st, "dec_out_dgrad", launch_conv3x3_tile(st, b.g, h->dec_out_wb, nullptr, b.act[Dd - 1], b.dpre[cur], N,
+                                                             h->S, 4, Cd, EPI_MUL_ELUGRAD));
+    }
     if (train_alpha != 0.f) {
         const int wi = param_index(h, "decoder.conv.weight"), bi = param_index(h, "decoder.conv.bias");
         if (h->precision == 1) {                           // GEMM form: rows (tap, co), no N = 4 -> 32 padding
@@ -563,6 +571,7 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     ALLOC(h->dec_out_wb, conv_wpk_elems(4, Cd) * 4);
     ALLOC(h->dec_out_w16, (size_t)(Cd / 16) * 2 * 2 * 64 * 4);            // GEMM-form pack: [chunk][hi/lo][kh][64][8 fp16]
     ALLOC(h->dec_out_meta, (size_t)4);
+    ALLOC(h->dec_out_wb16, (size_t)3 * 2 * 2 * Cd * 4);
     h->ref_w.assign(h->Dr, nullptr); h->ref_b.assign(h->Dr, nullptr);
     for (int l = 0; l < h->Dr; ++l) {
         ALLOC(h->ref_w[l], conv_wpk_elems(l == 0 ? 20 : Cr, Cr) * 4);
@@ -660,6 +669,7 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     HIPCHK(h, queue_copy(h->dec_out_b, P("decoder.conv.bias"), 4));
     HIPCHK(h, launch_pack_conv_weights(st, P("decoder.conv.weight"), 4, Cd, 4, Cd, 1, h->dec_out_wb));
     HIPCHK(h, launch_pack_dec_out_gemm(st, P("decoder.conv.weight"), Cd, h->dec_out_meta, h->dec_out_w16));
+    HIPCHK(h, launch_pack_dec_out_dgrad(st, P("decoder.conv.weight"), Cd, h->dec_out_meta, h->dec_out_wb16));   // same scale
     // refinement conv stack
     const bool ref_fp32 = h->precision == 0 || !refine_f16_ok(h);
     for (int l = 0; l < h->Dr; ++l) {
@@ -730,6 +740,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
 #ifdef IODINE_XSKIP_HOOK
     if (!strcmp(key, "xskip")) { g_iod_xskip = (int)value; return IODINE_OK; }       // timing-only ablation builds (common.h)
 #endif
+    if (!strcmp(key, "out_dgrad_variant")) { h->out_dgrad_variant = value != 0; return IODINE_OK; }
     if (!strcmp(key, "fuse_l0")) { h->fuse_l0 = value != 0; return IODINE_OK; }
     if (!strcmp(key, "out_variant")) { h->out_variant = value != 0; return IODINE_OK; }
     if (!strcmp(key, "zigzag")) { h->zigzag = value != 0; return IODINE_OK; }

@@ -181,3 +181,169 @@ hipError_t launch_dec_out_stream_f16x3(hipStream_t st, const float* in, const vo
     }
     return hipGetLastError();
 }
+
+// =========================================================================================
+// Data gradient of the output conv (4 -> C channels, times ELU' of the saved activation): the first kernel of every
+// decoder backward pass.  out[p][c] = ELU'(aux[p][c]) * sum_{tap, o} g[p + tap - 1][o] * W[o][c][8 - tap]: a
+// [pixels x 36] . [36 x C] GEMM (K = tap*4 + o, padded to 48) whose A operand comes from the 4-channel gradient of the
+// decoder output (5 KB halo tile per block) - the launch is a stream of aux in and out out (1.9 GB at cfg3).  The generic
+// exact-fp32 tile kernel it replaces spent 72 fp32 MFMAs (4.6 k matrix-pipe cycles) per wave and tile and moved the big
+// tensors with dword loads / stores; this one issues 36 split-fp16 MFMAs, fetches the ELU' operand as whole pixels at
+// block start (it lands under the staging and the MFMAs) and writes whole pixels after a transposition through LDS.
+//   wpk: [chunk 3][term hi/lo][kh 2][C] uint4 = 8 fp16 (k = chunk*16 + kh*8 + e; k = tap*4 + o, zero for k >= 36) * wscale
+// =========================================================================================
+__global__ void pack_dec_out_dgrad_kernel(const float* __restrict__ w /*[4][C][3][3]*/, int C, const float* __restrict__ meta,
+                                          _Float16* __restrict__ dst)
+{
+    const float scale = meta[0];
+    const int total = 3 * 2 * 2 * C * 8;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 7;
+        int r = idx >> 3;
+        const int c = r % C; r /= C;
+        const int kh = r & 1; r >>= 1;
+        const int term = r & 1; r >>= 1;
+        const int chunk = r;
+        const int k = chunk * 16 + kh * 8 + e, tap = k >> 2, o = k & 3;
+        float v = 0.f;
+        if (tap < 9) v = w[((size_t)o * C + c) * 9 + (8 - tap)] * scale;
+        const _Float16 hi = (_Float16)v;
+        dst[idx] = term == 0 ? hi : (_Float16)(v - (float)hi);
+    }
+}
+
+hipError_t launch_pack_dec_out_dgrad(hipStream_t st, const float* w, int C, const float* meta, void* dst)
+{
+    hipLaunchKernelGGL(pack_dec_out_dgrad_kernel, dim3(12), dim3(256), 0, st, w, C, meta, (_Float16*)dst);
+    return hipGetLastError();
+}
+
+template <int C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void dec_out_dgrad_f16x3_kernel(const float4* __restrict__ g, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
+                                const float* __restrict__ aux, float* __restrict__ out, int S, int tiles)
+{
+    constexpr int NT = C / 32;
+    constexpr int HALO = 18, NPX = HALO * HALO;
+    constexpr int W_U4 = 3 * 2 * 2 * C;
+    constexpr int EPS = (C + 4) * 4;                                // bytes per transposed pixel
+    constexpr int SEGS = C / 4, PPI = 64 / SEGS, NEP = 32 / PPI;    // per 32-pixel half tile of a wave
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    float4* s_g = reinterpret_cast<float4*>(smem_b);                // [324] gradient halo tile, fp32
+    uint4* s_w = reinterpret_cast<uint4*>(smem_b + NPX * 16);       // packed weights
+    float* s_max = reinterpret_cast<float*>(smem_b + NPX * 16 + W_U4 * 16);
+    unsigned char* s_ep = smem_b + NPX * 16 + W_U4 * 16 + 16;       // [4 waves][32 px][EPS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kh = lane >> 5, li = lane & 31;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles; bid /= tiles;
+    const int ty = bid % tiles;
+    const int n = bid / tiles;
+
+    // ELU' operand: whole pixels (lane = pixel pl of PPI, 16-byte segment seg), requested first
+    const int seg = lane % SEGS, pl = lane / SEGS;
+    const float* aux_n = aux + (size_t)n * S * S * C;
+    float* out_n = out + (size_t)n * S * S * C;
+    f32x4 ax[2][NEP];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < NEP; ++j) {
+            const int pq = j * PPI + pl;                            // pixel of the half tile: row pq / 16, column pq % 16
+            const int gy = ty * 16 + 4 * wv + 2 * mt + pq / 16, gx = tx * 16 + pq % 16;
+            const float4 t = *reinterpret_cast<const float4*>(aux_n + ((size_t)gy * S + gx) * C + seg * 4);
+            ax[mt][j] = f32x4{t.x, t.y, t.z, t.w};
+        }
+    // gradient halo tile + weights -> LDS, block max of |g|
+    float m = 0.f;
+    for (int idx = tid; idx < NPX; idx += 256) {
+        const int gy = ty * 16 - 1 + idx / HALO, gx = tx * 16 - 1 + idx % HALO;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < S && gx >= 0 && gx < S) v = g[((size_t)n * S + gy) * S + gx];
+        s_g[idx] = v;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (int idx = tid; idx < W_U4; idx += 256) s_w[idx] = wpk[idx];
+    m = wave_max_f32(m);
+    if (lane == 0) s_max[wv] = m;
+    __syncthreads();
+    const float scale = tile_scale(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])), 1.f);
+    const float inv = wmeta[1] / scale;
+
+    unsigned char* ep = s_ep + wv * 32 * EPS;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        // accumulators of this half tile: rows = channels (weights are the first MFMA operand), columns = 32 pixels
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        const int py = 4 * wv + 2 * mt + (li >> 4), px = li & 15;  // tile pixel of this lane's fragment column
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int t0 = 4 * c + 2 * kh;                          // this lane's two taps of the chunk
+            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+            if (t0 < 9) q0 = s_g[(py + t0 / 3) * HALO + px + t0 % 3];
+            if (t0 + 1 < 9) q1 = s_g[(py + (t0 + 1) / 3) * HALO + px + (t0 + 1) % 3];
+            unsigned l0, l1, l2, l3;
+            const unsigned h0 = pack_hi_lo(q0.x * scale, q0.y * scale, l0), h1 = pack_hi_lo(q0.z * scale, q0.w * scale, l1);
+            const unsigned h2 = pack_hi_lo(q1.x * scale, q1.y * scale, l2), h3 = pack_hi_lo(q1.z * scale, q1.w * scale, l3);
+            const u32x4_ uh = {h0, h1, h2, h3}, ul = {l0, l1, l2, l3};
+            f16x8 ah, al;
+            __builtin_memcpy(&ah, &uh, 16); __builtin_memcpy(&al, &ul, 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const uint4* q = s_w + ((c * 2 + 0) * 2 + kh) * C + nt * 32 + li;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(q);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(q + 2 * C);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[nt], 0, 0, 0);
+            }
+        }
+        // transposition through the wave's LDS region: lane (li, kh) holds channels nt*32 + 8*g4 + 4*kh .. +3 of pixel li
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<f32x4*>(ep + li * EPS + (nt * 32 + 8 * g4 + 4 * kh) * 4) =
+                    f32x4{acc[nt][4 * g4] * inv, acc[nt][4 * g4 + 1] * inv, acc[nt][4 * g4 + 2] * inv, acc[nt][4 * g4 + 3] * inv};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < NEP; ++j) {
+            const int pq = j * PPI + pl;
+            const int gy = ty * 16 + 4 * wv + 2 * mt + pq / 16, gx = tx * 16 + pq % 16;
+            f32x4 v = *reinterpret_cast<const f32x4*>(ep + pq * EPS + seg * 16);
+            const f32x4 a4 = ax[mt][j];
+            v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
+            v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
+            *reinterpret_cast<f32x4*>(out_n + ((size_t)gy * S + gx) * C + seg * 4) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+hipError_t launch_dec_out_dgrad_f16x3(hipStream_t st, const float* g, const void* wpk, const float* wmeta, const float* aux,
+                                      float* out, int N, int S, int C)
+{
+    if (S % 16 != 0) return hipErrorInvalidValue;
+    const int tiles = S / 16;
+    if (C == 64) {
+        constexpr size_t lds = (size_t)324 * 16 + 3 * 2 * 2 * 64 * 16 + 16 + 4 * 32 * (64 + 4) * 4;
+        hipLaunchKernelGGL((dec_out_dgrad_f16x3_kernel<64>), dim3(N * tiles * tiles), dim3(256), lds, st, (const float4*)g,
+                           (const uint4*)wpk, wmeta, aux, out, S, tiles);
+    } else if (C == 32) {
+        constexpr size_t lds = (size_t)324 * 16 + 3 * 2 * 2 * 32 * 16 + 16 + 4 * 32 * (32 + 4) * 4;
+        hipLaunchKernelGGL((dec_out_dgrad_f16x3_kernel<32>), dim3(N * tiles * tiles), dim3(256), lds, st, (const float4*)g,
+                           (const uint4*)wpk, wmeta, aux, out, S, tiles);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
