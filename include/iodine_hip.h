@@ -134,7 +134,8 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * fp16 hi+lo, 3 fp16 MFMAs, fp32 accumulate -- default; only the selected path's weight packs are maintained, so a change
  * must be followed by iodine_set_params before the next compute call),
  * "conv_variant" (split-fp16 stride-1 conv: 1 = one tile per 4-wave block, two blocks per CU -- default; 3 = warp-specialised
- * persistent kernel, 4 = one tile per 8-wave block, four waves per SIMD; both experimental, same results bit for bit),
+ * persistent kernel, 4 = one tile per 8-wave block, four waves per SIMD; 5 = 8x16 tiles, three 4-wave blocks per CU; all experimental, same
+ * results bit for bit),
  * "fuse_l0" (1 -- default: in iodine_reconstruct the last decoder data gradient reduces its result to the broadcast layer's
  * row sums in its epilogue instead of storing it; 0 = store and reduce in a second kernel, as the training path does),
  * "out_variant" (output conv forward: 1 = streaming kernel -- default, 0 = LDS-staged),

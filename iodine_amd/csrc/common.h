@@ -214,7 +214,7 @@ hipError_t launch_pack_conv_weights_f16(hipStream_t st, const float* src, int O,
                                         float* meta, void* dst);
 hipError_t launch_conv3x3_tile_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                      const float* bias, const float* aux, float* out, int N, int S, int cin, int cout,
-                                     int epi, int rev = 0);
+                                     int epi, int rev = 0, int th = 16);
 hipError_t launch_conv3x3_wgrad_f16x3(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
                                       int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts);
 hipError_t launch_conv3x3_tile8_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,

@@ -154,7 +154,7 @@ hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, c
     // Tiles are independent: results do not depend on the order.  Measured -0.3 % on the cfg3 step (same-box A/B).
     const int rev = h->zigzag ? (layer & 1) : 0;
     if (h->variant == 4) return launch_conv3x3_tile8_f16x3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi, rev);
-    return launch_conv3x3_tile_f16x3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi, rev);
+    return launch_conv3x3_tile_f16x3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi, rev, h->variant == 5 ? 8 : 16);
 }
 
 template <typename T>
@@ -424,7 +424,7 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         }
         // Inference: nothing but the broadcast layer's row / class sums needs d(pre-activation 0), so the last data gradient
         // reduces its tile to per-row sums in its epilogue (EPI_L0ROWS) and the 0.94 GB tensor is neither written nor re-read.
-        fused_l0 = l == 1 && train_alpha == 0.f && h->precision == 1 && h->variant == 1 && h->fuse_l0;
+        fused_l0 = l == 1 && train_alpha == 0.f && h->precision == 1 && (h->variant == 1 || h->variant == 5) && h->fuse_l0;
         if (h->precision == 1)
             PROF(h, st, "conv_tile_dgrad", conv_f16x3(h, st, b.dpre[cur], h->dec_wb16[l], h->dec_wmeta[l] + 2, nullptr,
                                                       b.act[l - 1], fused_l0 ? b.rows_p : b.dpre[cur ^ 1], N, h->S, Cd, Cd,
@@ -745,7 +745,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "out_variant")) { h->out_variant = value != 0; return IODINE_OK; }
     if (!strcmp(key, "zigzag")) { h->zigzag = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {
-        if (value != 1 && value != 3 && value != 4) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1, 3 or 4");
+        if (value != 1 && value != 3 && value != 4 && value != 5) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1, 3, 4 or 5");
         h->variant = (int)value;
         return IODINE_OK;
     }
@@ -1056,14 +1056,14 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, c
         if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(s2 f16x3): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
         return IODINE_OK;
     }
-    if (mode == 2 || mode == 4 || mode == 7) {   // split-fp16 tile kernels (4 = warp-specialised persistent, 7 = eight-wave form)
+    if (mode == 2 || mode == 4 || mode == 7 || mode == 8) {   // split-fp16 tile kernels (4 = warp-specialised persistent, 7 = eight-wave form, 8 = 8x16 tiles)
         float* meta = nullptr;
         const size_t bytes = (size_t)(cin_pad / 16) * 9 * 2 * 2 * cout * 16;
         if (hipMalloc((void**)&wpk, bytes + 64) != hipSuccess) return IODINE_ERR_HIP;
         meta = (float*)((char*)wpk + bytes);
         hipError_t e2 = launch_pack_conv_weights_f16(st, w, w_o, w_i, cin_pad, cout, tflip, meta, wpk);
         if (e2 == hipSuccess)
-            e2 = mode == 2 ? launch_conv3x3_tile_f16x3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi)
+            e2 = (mode == 2 || mode == 8) ? launch_conv3x3_tile_f16x3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi, 0, mode == 8 ? 8 : 16)
                  : mode == 4 ? launch_conv3x3_tile_f16x3_v3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi)
                              : launch_conv3x3_tile8_f16x3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);

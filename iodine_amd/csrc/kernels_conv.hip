@@ -496,15 +496,19 @@ hipError_t launch_pack_conv_weights_f16(hipStream_t st, const float* src, int O,
 __device__ unsigned g_tile_prof[TP_MAXBLK * 8];
 #endif
 
-template <int CIN, int COUT, int EPI>
-__global__ __launch_bounds__(256, 2)
+// TH = tile height: 16 (default: 16x16 tile, 64 px per wave, two blocks per CU) or 8 (conv_variant = 5: 8x16 tile, 32 px per
+// wave, <= 168 VGPR and 51 KB LDS -> THREE blocks per CU at twice the weight staging per pixel)
+template <int CIN, int COUT, int EPI, int TH = 16>
+__global__ __launch_bounds__(256, TH == 16 ? 2 : 3)
 void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
                                const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
                                int S, int tiles, int rev)
 {
     constexpr int NCHUNK = CIN / 16;
     constexpr int NT = COUT / 32;
-    constexpr int HALO = 18, NPX = HALO * HALO;
+    static_assert(TH == 16 || TH == 8, "tile height");
+    constexpr int MT = TH / 8;                           // 32-pixel row-blocks per wave (a wave owns TH / 4 tile rows)
+    constexpr int HALO = 18, NPX = HALO * (TH + 2);
     constexpr int PXS = 80;                              // bytes per staged pixel: 32 hi + 32 lo + 16 pad
     constexpr int IN_BYTES = (NPX + 1) * PXS;            // +1 pixel: dump slot for idle lanes
     constexpr int W_U4 = 9 * 2 * 2 * COUT;               // uint4 (8 x fp16) per chunk
@@ -524,8 +528,9 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 
     int bid = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;    // zig-zag launch order, see conv_f16x3()
     const int tx = bid % tiles; bid /= tiles;
-    const int ty = bid % tiles;
-    const int n = bid / tiles;
+    const int tiles_y = tiles * (16 / TH);
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
 
     // Global traffic goes through RAW BUFFER loads issued as inline asm:
     //   * one descriptor per tensor (input: this block's slot-image, num_records = one image; packed weights), byte
@@ -557,7 +562,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     for (int k = 0; k < NIN; ++k) {
         const int idx = tid + k * 256;
         const int px = idx >> 2, cq = idx & 3;
-        const int gy = ty * 16 - 1 + px / HALO, gx = tx * 16 - 1 + px % HALO;
+        const int gy = ty * TH - 1 + px / HALO, gx = tx * 16 - 1 + px % HALO;
         const bool ok = idx < NPX * 4 && gy >= 0 && gy < S && gx >= 0 && gx < S;
         goff[k] = ok ? (unsigned)(((gy * S + gx) * CIN + cq * 4) * 4) : 0x80000000u;
 #ifdef IODINE_ABL_NOINLOAD
@@ -572,9 +577,9 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     for (int k = 0; k < NW; ++k) woff[k] = 0x80000000u;
 #endif
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -662,7 +667,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         if (new_scale != cur_scale) {                        // block-uniform
             const float r = new_scale / cur_scale;           // exact: both are powers of two
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -674,9 +679,9 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     // Fragment reads are inline-asm ds_read_b128 (invisible to hipcc's wait-count pass, which otherwise drains
     // lgkmcnt(0) - including the reads just issued for the NEXT tap - in front of every MFMA group).  LDS returns in
     // order, so a counted wait after issuing the next tap's 4 + 2*NT reads retires exactly the current tap's fragments.
-    struct Frag { f16x8 ah[2], al[2], bh[NT], bl[NT]; };
+    struct Frag { f16x8 ah[MT], al[MT], bh[NT], bl[NT]; };
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_b;
-    const unsigned a_addr0 = lds_base + ((4 * wv + prow) * HALO + pcol) * PXS + kh * 16;
+    const unsigned a_addr0 = lds_base + (((TH / 4) * wv + prow) * HALO + pcol) * PXS + kh * 16;
     const unsigned a_addr1 = a_addr0 + 2 * HALO * PXS;
     const unsigned b_addr = lds_base + IN_BYTES + (kh * COUT + li) * 16;
 #define IOD_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
@@ -685,14 +690,16 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         constexpr int aoff = ((tap / 3) * HALO + (tap % 3)) * PXS;
         constexpr int boff = tap * 4 * COUT * 16;
 #ifdef IODINE_ABL_NOLDSREAD
-        asm volatile("" : "+v"(f.ah[0]), "+v"(f.al[0]), "+v"(f.ah[1]), "+v"(f.al[1]), "+v"(f.bh[0]), "+v"(f.bl[0]));
+        asm volatile("" : "+v"(f.ah[0]), "+v"(f.al[0]), "+v"(f.ah[MT - 1]), "+v"(f.al[MT - 1]), "+v"(f.bh[0]), "+v"(f.bl[0]));
         if constexpr (NT == 2) asm volatile("" : "+v"(f.bh[1]), "+v"(f.bl[1]));
         return;
 #endif
         IOD_DSR128(f.ah[0], a_addr0, aoff);
         IOD_DSR128(f.al[0], a_addr0, aoff + 32);
-        IOD_DSR128(f.ah[1], a_addr1, aoff);
-        IOD_DSR128(f.al[1], a_addr1, aoff + 32);
+        if constexpr (MT == 2) {
+            IOD_DSR128(f.ah[MT - 1], a_addr1, aoff);
+            IOD_DSR128(f.al[MT - 1], a_addr1, aoff + 32);
+        }
         IOD_DSR128(f.bh[0], b_addr, boff);
         IOD_DSR128(f.bl[0], b_addr, boff + 2 * COUT * 16);
         if constexpr (NT == 2) {
@@ -703,30 +710,29 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 #undef IOD_DSR128
     auto MMA = [&](const Frag& f) {
 #ifdef IODINE_ABL_NOMFMA
-        asm volatile("" :: "v"(f.ah[0]), "v"(f.al[0]), "v"(f.ah[1]), "v"(f.al[1]), "v"(f.bh[0]), "v"(f.bl[0]));
+        asm volatile("" :: "v"(f.ah[0]), "v"(f.al[0]), "v"(f.ah[MT - 1]), "v"(f.al[MT - 1]), "v"(f.bh[0]), "v"(f.bl[0]));
         if constexpr (NT == 2) asm volatile("" :: "v"(f.bh[1]), "v"(f.bl[1]));
         return;
 #endif
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[nt], f.al[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[nt], f.ah[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[nt], f.ah[mt], acc[mt][nt], 0, 0, 0);
     };
 #define IOD_STEP(T, FCUR, FNEXT)                                                                  \
     if constexpr (T + 1 < 9) LOADF(integral_constant<int, (T + 1 < 9 ? T + 1 : 8)>{}, FNEXT);       \
-    if constexpr (T + 1 < 9) { if (NT == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      \
-                               else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); }            \
+    if constexpr (T + 1 < 9) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(2 * MT + 2 * NT) : "memory");   \
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
     __builtin_amdgcn_sched_barrier(0);                                                              \
     MMA(FCUR);                                                                                      \
@@ -751,9 +757,9 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     // per instruction - and applied AFTER the accumulators have been transposed through LDS.
     constexpr int SEGS = COUT / 4;                           // float4 segments per pixel (16 / 8)
     constexpr int PPI = 64 / SEGS;                           // pixels per load / store instruction (4 / 8)
-    constexpr int NEP = 64 / PPI;                            // instructions per wave tile (16 / 8)
+    constexpr int NEP = 32 * MT / PPI;                       // instructions per wave tile (16 / 8; half of it at TH = 8)
     const int seg = lane % SEGS, pl = lane / SEGS;
-    const unsigned vbase = (unsigned)((((ty * 16 + 4 * wv) * S + tx * 16 + pl) * COUT + seg * 4) * 4);
+    const unsigned vbase = (unsigned)((((ty * TH + (TH / 4) * wv) * S + tx * 16 + pl) * COUT + seg * 4) * 4);
     f32x4 ax[NEP];
     auto prefetch_aux = [&]() {
         if constexpr (EPI == EPI_MUL_ELUGRAD || EPI == EPI_L0ROWS) {
@@ -825,9 +831,9 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         // Each wave owns a [64 pixels][COUT + 4 floats] region (the pad keeps the column-shaped writes off one bank).
         constexpr int EPS = (COUT + 4) * 4;                      // bytes per staged pixel
         __syncthreads();                                         // every wave is done with the staging buffers
-        unsigned char* s_ep = smem_b + wv * 64 * EPS;
+        unsigned char* s_ep = smem_b + wv * (32 * MT) * EPS;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -841,10 +847,10 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         // instruction j: pixels j*PPI .. of the wave's 64 (tile row (j*PPI)/16, columns (j*PPI)%16 ..), bias + ELU or the
         // ELU' factor applied in this layout (a lane keeps ONE float4 of bias: its channel segment never changes)
         // EPI_L0ROWS: per tile row the left-border / interior / right-border column sums instead of the pixels
-        f32x4 rsum[EPI == EPI_L0ROWS ? 4 : 1][3];
+        f32x4 rsum[EPI == EPI_L0ROWS ? TH / 4 : 1][3];
         if constexpr (EPI == EPI_L0ROWS) {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
+            for (int rr = 0; rr < TH / 4; ++rr)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) rsum[rr][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -881,7 +887,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             f32x4* s_rs = reinterpret_cast<f32x4*>(s_ep);
             float* rows_p = out;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
+            for (int rr = 0; rr < TH / 4; ++rr) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -895,7 +901,7 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
                     f32x4 t = s_rs[sg * 3 + c];
 #pragma unroll
                     for (int q = 1; q < PPI; ++q) t += s_rs[(q * SEGS + sg) * 3 + c];
-                    const int gy = ty * 16 + 4 * wv + rr;
+                    const int gy = ty * TH + (TH / 4) * wv + rr;
                     *reinterpret_cast<f32x4*>(rows_p + ((((size_t)n * S + gy) * tiles + tx) * 3 + c) * COUT + sg * 4) = t;
                 }
             }
@@ -907,26 +913,26 @@ void conv3x3_tile_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 #undef IOD_SGPR_SETTLE
 }
 
-template <int CIN, int COUT, int EPI>
+template <int CIN, int COUT, int EPI, int TH>
 static hipError_t launch_tile_f16x3_inst(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                          const float* bias, const float* aux, float* out, int N, int S, int rev)
 {
-    constexpr size_t lds_stage = (size_t)(18 * 18 + 1) * 80 + (size_t)9 * 2 * 2 * COUT * 16 + 16;
-    constexpr size_t lds_epi = (size_t)4 * 64 * (COUT + 4) * 4;              // output tile, transposed for contiguous stores
+    constexpr size_t lds_stage = (size_t)(18 * (TH + 2) + 1) * 80 + (size_t)9 * 2 * 2 * COUT * 16 + 16;
+    constexpr size_t lds_epi = (size_t)4 * (TH * 4) * (COUT + 4) * 4;              // output tile, transposed for contiguous stores
     constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_tile_f16x3_kernel<CIN, COUT, EPI>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_tile_f16x3_kernel<CIN, COUT, EPI, TH>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int tiles = S / 16;
-    hipLaunchKernelGGL((conv3x3_tile_f16x3_kernel<CIN, COUT, EPI>), dim3(N * tiles * tiles), dim3(256), lds, st, in,
+    hipLaunchKernelGGL((conv3x3_tile_f16x3_kernel<CIN, COUT, EPI, TH>), dim3(N * tiles * tiles * (16 / TH)), dim3(256), lds, st, in,
                        reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, S, tiles, rev);
 #ifdef IODINE_TILE_PROF
     {
-        const int nb = std::min(N * tiles * tiles, TP_MAXBLK);
+        const int nb = std::min(N * tiles * tiles * (16 / TH), TP_MAXBLK);
         std::vector<unsigned> hp((size_t)nb * 8);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(g_tile_prof), hp.size() * sizeof(unsigned));
@@ -945,11 +951,12 @@ static hipError_t launch_tile_f16x3_inst(hipStream_t st, const float* in, const 
 
 hipError_t launch_conv3x3_tile_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                      const float* bias, const float* aux, float* out, int N, int S, int cin, int cout,
-                                     int epi, int rev)
+                                     int epi, int rev, int th)
 {
     if (S % 16 != 0) return hipErrorInvalidValue;
 #define T16_CASE(CI, CO, EP) \
-    if (cin == CI && cout == CO && epi == EP) return launch_tile_f16x3_inst<CI, CO, EP>(st, in, wpk, wmeta, bias, aux, out, N, S, rev);
+    if (cin == CI && cout == CO && epi == EP) return th == 8 ? launch_tile_f16x3_inst<CI, CO, EP, 8>(st, in, wpk, wmeta, bias, aux, out, N, S, rev) \
+                                                            : launch_tile_f16x3_inst<CI, CO, EP, 16>(st, in, wpk, wmeta, bias, aux, out, N, S, rev);
     T16_CASE(64, 64, EPI_BIAS_ELU) T16_CASE(64, 64, EPI_MUL_ELUGRAD) T16_CASE(64, 64, EPI_L0ROWS)
     T16_CASE(32, 32, EPI_BIAS_ELU) T16_CASE(32, 32, EPI_MUL_ELUGRAD) T16_CASE(32, 32, EPI_L0ROWS)
 #undef T16_CASE
