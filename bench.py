@@ -214,7 +214,7 @@ def main():
                  f'fwd, dgrad, wgrad launches; exact fp32 MFMA)')
     # HBM traffic per launch from the rocprofv3 PMC pass recorded in profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
     # measured on the forward launch of this shape; null for other shapes
-    traffic = 1.08e9 + 0.94e9 if (args.config == 'clevr6' and B == 32 and K == 7 and args.conv_precision == 1) else None
+    traffic = 1.06e9 + 0.94e9 if (args.config == 'clevr6' and B == 32 and K == 7 and args.conv_precision == 1) else None
     roofline = dict(bound='mfma', kernel=kname, achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
                     frac=round(achieved / peak, 4), traffic=traffic,
                     flops_per_launch=flops_per_launch, avg_launch_ms=round(dom_ms / max(dom_n, 1), 4),
