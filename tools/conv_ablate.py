@@ -2,7 +2,7 @@
 """Time the split-fp16 tile conv kernels (op-level) at the cfg3 shape, interleaving ablation variants.
 usage: conv_ablate.py <mode> <flags,flags,...>   (IODINE_CONV_ABLATE is read once per process, so each variant
 runs in a child process; rounds are interleaved to average out clock drift).
-Flags understood by conv_variant=3 (mode 4): 1 skip the MFMAs, 4 skip the weight LDS-DMA, 8 fixed scale (no max), 16 skip the consumers'
+Flags understood by conv_variant=3 (mode 4): (1 = skip the MFMAs: gone since the fragment reads are interleaved with them), 4 skip the weight LDS-DMA, 8 fixed scale (no max), 16 skip the consumers'
 epilogue, 32 skip the input staging writes.  Results are WRONG with any flag set: timing only."""
 import os, subprocess, sys, time
 if len(sys.argv) > 2 and sys.argv[2] != 'child':
