@@ -29,7 +29,7 @@ extern "C" {
 #define IODINE_ERR_STATE 3         /* call order violated (params not set, no forward before backward ...) */
 #define IODINE_ERR_WORKSPACE 4     /* caller-provided workspace too small */
 
-#define IODINE_ABI_VERSION 1
+#define IODINE_ABI_VERSION 2
 
 /* bit i set <=> the i-th entry of ARCH.ENCODING is enabled; order = code order of
  * IODINE.get_input_encoding (iodine.py:253-340).  Only IODINE_ENC_FULL (every shipped
@@ -104,14 +104,46 @@ int iodine_reconstruct(iodine_handle* h, void* stream, int batch, const float* x
 /* pred, mask, mean = model.decode(z) -- iodine.py:59-71. */
 int iodine_decode(iodine_handle* h, void* stream, int batch, const float* z, float* pred, float* mask, float* mean);
 
+/* elbo = model.elbo(x) -- IODINE.elbo, iodine.py:161-241: ONE sample z = mu + exp(logvar/2) * eps from the given posterior
+ * (post_mean / post_logvar (B,K,L); both NULL = the initial posterior of Gaussian.init_unit, iodine.py:607-618), decode,
+ * mixture log-likelihood and KL.  eps (B,K,L); terms (3) = {ELBO, KL, LL} (device, may be NULL).  The tensors the reference
+ * leaves on `self` (z, mean, mask, mask_logits) and the `pred` it hands to the logger are read with
+ * iodine_last_elbo_outputs. */
+int iodine_elbo(iodine_handle* h, void* stream, int batch, const float* x, const float* post_mean, const float* post_logvar,
+                const float* eps, float* terms);
+
+/* self.z / self.mean / self.mask / self.mask_logits and pred of the LAST elbo() call (iodine.py:171-187,225) -- the one made by
+ * iodine_elbo, the last refinement iteration of iodine_reconstruct (NOT its final decode: the reference's logger shows the
+ * last elbo() call, iodine.py:226-239) or the final elbo of iodine_train_forward -- for the first `count` images of that
+ * call's batch: z (count,K,L), mean (count,K,3,S,S), mask and mask_logits (count,K,1,S,S), pred (count,3,S,S); any may be
+ * NULL.  count = 1 is what the logger side channel needs. */
+int iodine_last_elbo_outputs(iodine_handle* h, void* stream, int count, float* z, float* mean, float* mask,
+                             float* mask_logits, float* pred);
+
 /* loss = model(x) -- IODINE.forward, iodine.py:115-158.  loss (1) and elbo_iter (T+1,3) are device outputs.
  * Keeps what iodine_train_backward needs in the workspace (the autograd graph of the reference). */
 int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float* x, const float* eps,
                          float* loss, float* elbo_iter);
 
 /* loss.backward() -- lib/engine/train.py:63.  Accumulates grad_scale * d loss / d param INTO param_grads[i]
- * (+=, like autograd's .grad accumulation; zero_grad is the caller's job, train.py:62). */
+ * (+=, like autograd's .grad accumulation; zero_grad is the caller's job, train.py:62).  Consumes the saved forward (autograd
+ * without retain_graph): a second call, or a call after any other compute entry point re-used the workspace, returns
+ * IODINE_ERR_STATE. */
 int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, float* const* param_grads, int n);
+
+/* The same with the caller's gradients as ONE buffer (parameters back to back in iodine_param_info order -- the layout
+ * iodine_amd.IODINE hands to autograd and all-reduces in place) and autograd's incoming d(out)/d(loss) read from DEVICE memory
+ * (grad_loss_dev, one float; NULL = 1): flat = (accumulate ? flat : 0) + *grad_loss_dev * d loss / d params.  One launch at the
+ * end; no host round trip, no separate zero-fill. */
+int iodine_train_backward_flat(iodine_handle* h, void* stream, const float* grad_loss_dev, float* flat_grads, int accumulate);
+
+/* logger.update(init_mean=posterior.init_mean.mean(), init_logvar=posterior.init_logvar.mean()) -- iodine.py:156-157:
+ * out2 (2, device) = the two means of the parameters last handed to iodine_set_params. */
+int iodine_logger_scalars(iodine_handle* h, void* stream, float* out2);
+
+/* torch.randn_like of Gaussian.sample (iodine.py:632) without ATen: n standard normals from Philox4x32-10 + Box-Muller,
+ * counter-based (element e depends only on (seed, stream_id, e)); the wrapper passes one stream_id per call. */
+int iodine_randn(void* stream, float* out, long long n, unsigned long long seed, unsigned long long stream_id);
 
 /* optimizer.step() -- lib/engine/train.py:65 with the Adam built by lib/solver/build.py:5-16.  One fused launch over all
  * tensors.  ptrs_dev[4*t + {0,1,2,3}] = device addresses of {param, grad, exp_avg, exp_avg_sq} of tensor t (as int64),
@@ -128,14 +160,16 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
                      int* table);
 
 /* Options: "stop_after_iters" (debug: run only the first v refinement iterations of reconstruct, no final decode),
+ * "graph" (1: replay the fixed-shape launch sequence of reconstruct / decode / elbo / train_forward / train_backward through a
+ * hipGraph per distinct argument tuple -- first call eager, second captured, later ones one hipGraphLaunch; needs a non-default
+ * stream; ignored while "profile" is on; 0 -- default),
  * "profile" (bracket kernel launches with HIP events on the launch stream: 1 = the dominant "conv_tile_*" launches only --
  * 54 of ~330 per training step, what bench.py keeps on inside its timed region; 2 = every category; 0 = off),
  * "conv_precision" (3x3 convs of the decoder and refinement stacks: 0 = exact fp32 MFMA, 1 = fp32 operands split into
  * fp16 hi+lo, 3 fp16 MFMAs, fp32 accumulate -- default; only the selected path's weight packs are maintained, so a change
  * must be followed by iodine_set_params before the next compute call),
- * "conv_variant" (split-fp16 stride-1 conv: 1 = one tile per 4-wave block, two blocks per CU -- default; 3 = warp-specialised
- * persistent kernel, 4 = one tile per 8-wave block, four waves per SIMD; 5 = 8x16 tiles, three 4-wave blocks per CU; all experimental, same
- * results bit for bit),
+ * "conv_variant" (split-fp16 stride-1 conv: 1 = 16x16 tiles, one per 4-wave block, two blocks per CU -- default; 5 = 8x16
+ * tiles, three blocks per CU; same results bit for bit),
  * "fuse_l0" (1 -- default: in iodine_reconstruct the last decoder data gradient reduces its result to the broadcast layer's
  * row sums in its epilogue instead of storing it; 0 = store and reduce in a second kernel, as the training path does),
  * "out_variant" (output conv forward: 1 = streaming kernel -- default, 0 = LDS-staged),
@@ -159,7 +193,8 @@ int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter
 void iodine_linspace_host(int n, float* out);
 /* 3x3 conv, NHWC activations, OIHW weights; mode 0: stride-1 LDS-tiled fp32 MFMA (epi 0 bias+ELU, 1 multiply by
  * ELU'(aux), 2 none; transpose_flip=1 computes the data-gradient conv), mode 1: strided gather kernel (bias+ELU),
- * mode 2: stride-1 LDS-tiled split-fp16 (3 MFMA) variant of mode 0, mode 4: its warp-specialised persistent form. */
+ * mode 2: stride-1 LDS-tiled split-fp16 (3 MFMA) variant of mode 0, mode 8: the same on 8x16 tiles, modes 5 / 6: split-fp16
+ * stride-2 forward / data gradient of the refinement stack. */
 int iodine_op_conv3x3(void* stream, int mode, const float* in_nhwc, const float* w_oihw, const float* bias,
                       const float* aux, float* out_nhwc, int n, int ih, int iw, int w_o, int w_i, int cin_pad,
                       int cout, int stride, int epi, int transpose_flip);

@@ -20,7 +20,8 @@ ENC_FULL = 0xFFF
 EXPORTS = (
     'iodine_abi_version', 'iodine_create', 'iodine_destroy', 'iodine_last_error', 'iodine_num_params',
     'iodine_param_info', 'iodine_set_params', 'iodine_workspace_bytes', 'iodine_set_workspace',
-    'iodine_reconstruct', 'iodine_decode', 'iodine_train_forward', 'iodine_train_backward',
+    'iodine_reconstruct', 'iodine_decode', 'iodine_elbo', 'iodine_last_elbo_outputs', 'iodine_randn',
+    'iodine_train_forward', 'iodine_train_backward', 'iodine_train_backward_flat', 'iodine_logger_scalars',
     'iodine_adam_step', 'iodine_ari_table', 'iodine_set_option', 'iodine_profile_read', 'iodine_debug_copy', 'iodine_linspace_host', 'iodine_op_conv3x3', 'iodine_op_dec_out',
     'iodine_op_conv3x3_wgrad',
 )
@@ -76,8 +77,13 @@ def lib() -> C.CDLL:
     L.iodine_set_workspace.argtypes = [vp, vp, C.c_size_t]
     L.iodine_reconstruct.argtypes = [vp, vp, ci] + [vp] * 9
     L.iodine_decode.argtypes = [vp, vp, ci] + [vp] * 4
+    L.iodine_elbo.argtypes = [vp, vp, ci] + [vp] * 5
+    L.iodine_last_elbo_outputs.argtypes = [vp, vp, ci] + [vp] * 5
+    L.iodine_randn.argtypes = [vp, vp, C.c_longlong, C.c_ulonglong, C.c_ulonglong]
     L.iodine_train_forward.argtypes = [vp, vp, ci] + [vp] * 4
     L.iodine_train_backward.argtypes = [vp, vp, cf, C.POINTER(vp), ci]
+    L.iodine_train_backward_flat.argtypes = [vp, vp, vp, vp, ci]
+    L.iodine_logger_scalars.argtypes = [vp, vp, vp]
     L.iodine_adam_step.argtypes = [vp, vp, vp, ci, C.c_longlong] + [C.c_double] * 5 + [ci]
     L.iodine_ari_table.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     L.iodine_set_option.argtypes = [vp, C.c_char_p, C.c_double]
@@ -88,7 +94,7 @@ def lib() -> C.CDLL:
     L.iodine_op_conv3x3.argtypes = [vp, ci] + [vp] * 5 + [ci] * 10
     L.iodine_op_dec_out.argtypes = [vp] + [vp] * 4 + [ci] * 3
     L.iodine_op_conv3x3_wgrad.argtypes = [vp] + [vp] * 4 + [ci] * 6
-    if L.iodine_abi_version() != 1:
+    if L.iodine_abi_version() != 2:
         raise RuntimeError('libiodine_hip.so ABI version mismatch')
     _lib = L
     return L

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, 'libiodine_hip.so')
-SOURCES = ['kernels_conv.hip', 'kernels_conv8.hip', 'kernels_out.hip', 'kernels_pixel.hip', 'kernels_misc.hip', 'kernels_train.hip', 'kernels_refine.hip', 'iodine_api.cpp']
+SOURCES = ['kernels_conv.hip', 'kernels_out.hip', 'kernels_pixel.hip', 'kernels_misc.hip', 'kernels_train.hip', 'kernels_refine.hip', 'iodine_api.cpp']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(ROOT, 'include', 'iodine_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
          '-Wno-unused-result'] + os.environ.get('IODINE_EXTRA_HIPCC_FLAGS', '').split()   # e.g. -DIODINE_TILE_PROF (tools only)
@@ -68,6 +68,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
     return LIB
+
+
+def source_digest() -> str:
+    """sha256 over the kernel / host sources the library is built from (csrc/* and the ABI header).  Measurements kept
+    under profiles/ (PMC traffic per launch) carry this digest; bench.py quotes them only while it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in sorted(SOURCES) + ['common.h']:
+        p = os.path.join(CSRC, s)
+        if os.path.exists(p):
+            h.update(s.encode())
+            h.update(open(p, 'rb').read())
+    h.update(open(os.path.join(ROOT, 'include', 'iodine_hip.h'), 'rb').read())
+    return h.hexdigest()
 
 
 if __name__ == '__main__':

@@ -15,12 +15,27 @@ def strip_module_prefix(state_dict):
     return {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state_dict.items()}
 
 
+def last_checkpoint(save_dir):
+    """Path of the newest checkpoint listed in ``save_dir/checkpoint.pkl`` (the index ``Checkpointer.update_checkpoint``
+    maintains, lib/utils/checkpoint.py:82-116), or None."""
+    import os
+    import pickle
+    index = os.path.join(save_dir, 'checkpoint.pkl')
+    if not os.path.exists(index):
+        return None
+    with open(index, 'rb') as f:
+        names = pickle.load(f)
+    return os.path.join(save_dir, names[-1]) if names else None
+
+
 def load_checkpoint(path, model, optimizer=None, strict=True):
     """Load a reference-format checkpoint into ``model`` (and ``optimizer``).  Returns the extra entries (epoch, iter...)."""
     ckpt = torch.load(path, map_location=torch.device('cpu'))
     if 'model' not in ckpt:
         raise KeyError("not a reference checkpoint: no 'model' entry")
     model.load_state_dict(strip_module_prefix(ckpt.pop('model')), strict=strict)
+    if hasattr(model, 'mark_params_dirty'):
+        model.mark_params_dirty()                  # re-pack the library's weight copies on the next call
     opt_state = ckpt.pop('optimizer', None)
     if optimizer is not None and opt_state is not None:
         optimizer.load_state_dict(opt_state)

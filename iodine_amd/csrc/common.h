@@ -147,8 +147,8 @@ hipError_t launch_pixel_finalize(hipStream_t st, const double* part, int B, int 
                                  float* lnstat, float* ll_img);
 hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec, const float* lnstat,
                               const float* lin, float* enc, int B, int K, int S, float sigma);
-hipError_t launch_final_out(hipStream_t st, const float* dec, float* pred, float* mask, float* mean, int B, int K,
-                            int P);
+hipError_t launch_final_out(hipStream_t st, const float* dec, float* pred, float* mask, float* mean, float* logits,
+                            int B, int K, int P);
 // kernels_misc.hip
 hipError_t launch_x_to_nhwc4(hipStream_t st, const float* x, float* x4, int B, int P);
 hipError_t launch_posterior_init(hipStream_t st, const float* im, const float* ilv, float* pm, float* plv, float* h,
@@ -204,6 +204,8 @@ hipError_t launch_l0_coord_grads(hipStream_t st, const float* D, const float* li
 hipError_t launch_loss(hipStream_t st, const float* scal, int n, float* loss);
 hipError_t launch_scale(hipStream_t st, const float* a, float alpha, float* o, int n);
 hipError_t launch_axpy(hipStream_t st, const float* x, float alpha, float* y, int n);
+hipError_t launch_axpy_dev(hipStream_t st, const float* x, float alpha, const float* alpha_dev, float* y, int n, int accumulate);
+hipError_t launch_mean2(hipStream_t st, const float* a, const float* b, int n, float* out);
 hipError_t launch_lstm_bwd_pointwise(hipStream_t st, const float* gates, const float* c0, const float* c1,
                                      const float* dc1_read, const float* dh1, const float* dc1_carry, float* dgates,
                                      float* dc0, int N, int H);
@@ -217,14 +219,9 @@ hipError_t launch_conv3x3_tile_f16x3(hipStream_t st, const float* in, const void
                                      int epi, int rev = 0, int th = 16);
 hipError_t launch_conv3x3_wgrad_f16x3(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
                                       int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts);
-hipError_t launch_conv3x3_tile8_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
-                                      const float* bias, const float* aux, float* out, int N, int S, int cin, int cout,
-                                      int epi, int rev = 0);
-hipError_t launch_conv3x3_tile_f16x3_v3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
-                                        const float* bias, const float* aux, float* out, int N, int S, int cin, int cout,
-                                        int epi);
 hipError_t launch_adam_multi(hipStream_t st, const long long* ptrs, const long long* offs, int n_tensors, long long total,
                              double lr, double beta1, double beta2, double eps, double wd, int step);
+hipError_t launch_randn_philox(hipStream_t st, float* out, long long n, unsigned long long seed, unsigned long long stream_id);
 hipError_t launch_ari_table(hipStream_t st, const float* mask, const unsigned char* gt, int B, int K, int G, int P,
                             int* table);
 hipError_t launch_pack_dec_out_gemm(hipStream_t st, const float* w, int C, float* meta, void* dst);

@@ -59,6 +59,8 @@ struct Buffers {               // workspace carve-up for one batch size / mode
 // launch stream; totals are read back (after a sync) with iodine_profile_read.
 struct ProfCat { std::string name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; };
 
+struct GraphEntry { std::vector<uintptr_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long long used = 0; };
+
 struct iodine_handle {
     iodine_config cfg;
     std::string err;
@@ -84,7 +86,7 @@ struct iodine_handle {
     int fuse_l0 = 1;                            // inference: layer-1 data gradient reduces straight to the layer-0 row sums
     int out_variant = 1;                        // output conv forward: 1 = streaming (fragments straight from global), 0 = LDS-staged
     int zigzag = 1;                             // odd decoder layers walk the tiles backwards (Infinity Cache reuse)
-    int variant = 1;                            // split-fp16 tile conv: 1 = one tile per block (2 blocks/CU), 3 = warp-specialised persistent (experimental)
+    int variant = 1;                            // split-fp16 tile conv: 1 = 16x16 tiles (2 blocks/CU), 5 = 8x16 tiles (3 blocks/CU)
     float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr, *dec_out_w16 = nullptr, *dec_out_meta = nullptr,
           *dec_out_wb16 = nullptr;               // split-fp16 pack of the output conv for its data gradient
     std::vector<float*> ref_w, ref_b;
@@ -99,6 +101,14 @@ struct iodine_handle {
     size_t gacc_total = 0;
     bool fwd_done = false;
     int fwd_batch = 0;
+    // last elbo() call (iodine.py:161-241): which z buffer / batch the decoder output in buf.dec_out belongs to
+    int last_elbo_iter = -1, last_elbo_batch = 0;
+    // hipGraph replay of the fixed-shape launch sequences (option "graph"): one instantiated graph per distinct argument tuple
+    int graph = 0;
+    std::vector<GraphEntry> graphs;
+    std::vector<std::vector<uintptr_t>> seen_keys;       // argument tuples that ran eagerly once (the next call captures)
+    unsigned long long graph_clock = 0;
+    long long graph_replays = 0, graph_captures = 0;
     std::vector<void*> owned;
 
     // workspace
@@ -147,13 +157,11 @@ hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, c
 hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                       const float* bias, const float* aux, float* out, int N, int S, int cin, int cout, int epi, int layer)
 {
-    if (h->variant == 3) return launch_conv3x3_tile_f16x3_v3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi);
     // zig-zag: odd decoder layers walk the slot-images backwards (forward pass: l0 writes forwards, layer 1 reads
     // backwards, layer 2 forwards, ...; backward pass the same by layer), so a launch starts on the part of its input
     // that the previous launch wrote last - still in the 256 MiB Infinity Cache - instead of the part written first.
     // Tiles are independent: results do not depend on the order.  Measured -0.3 % on the cfg3 step (same-box A/B).
     const int rev = h->zigzag ? (layer & 1) : 0;
-    if (h->variant == 4) return launch_conv3x3_tile8_f16x3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi, rev);
     return launch_conv3x3_tile_f16x3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi, rev, h->variant == 5 ? 8 : 16);
 }
 
@@ -266,6 +274,7 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
         for (int i = 0; i <= T; ++i) v[i] = (i < copies) ? a.take<float>(n) : v[0];
     };
     per_iter(b.z, (size_t)N * L, ncopy);
+    if (mode != 1) b.z[T] = a.take<float>((size_t)N * L);   // the final sample must not overwrite the last elbo()'s z (self.z)
     per_iter(b.g_pm, (size_t)N * L, ncopy);
     per_iter(b.g_plv, (size_t)N * L, ncopy);
     per_iter(b.latent, (size_t)N * 4 * L, ncopy);
@@ -314,6 +323,16 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
     b.bytes = (a.off + 255) & ~(size_t)255;
 }
 
+void drop_graphs(iodine_handle* h)
+{
+    for (auto& g : h->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    h->graphs.clear();
+    h->seen_keys.clear();
+}
+
 int ensure_workspace(iodine_handle* h, int B, int mode)
 {
     if (h->buf.B == B && h->buf.mode == mode && h->buf.bytes > 0) return IODINE_OK;
@@ -337,13 +356,17 @@ int ensure_workspace(iodine_handle* h, int B, int mode)
     }
     Arena a(base);
     plan(h, B, mode, a, h->buf);
+    h->fwd_done = false;                 // a re-planned arena no longer holds the saved forward / the last elbo() outputs
+    h->last_elbo_iter = -1;
+    drop_graphs(h);
     return IODINE_OK;
 }
 
 // one decoder forward pass from z (already in buf.V via dec_v) -> dec_out
-int decoder_forward(iodine_handle* h, hipStream_t st, int N)
+int decoder_forward(iodine_handle* h, hipStream_t st, int N, float* out = nullptr)
 {
     Buffers& b = h->buf;
+    if (!out) out = b.dec_out;
     PROF(h, st, "dec_l0", launch_dec_l0(st, b.V, h->cmap, b.act[0], N, h->S, h->Cd));
     for (int l = 1; l < h->Dd; ++l) {
         if (h->precision == 1)
@@ -355,9 +378,9 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N)
     }
     if (h->precision == 1)
         PROF(h, st, "dec_out", (h->out_variant ? launch_dec_out_stream_f16x3 : launch_dec_out_gemm_f16x3)(st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b,
-                                                         b.dec_out, N, h->S, h->Cd));
+                                                         out, N, h->S, h->Cd));
     else
-        PROF(h, st, "dec_out", launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, b.dec_out, N, h->S, h->Cd));
+        PROF(h, st, "dec_out", launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, out, N, h->S, h->Cd));
     return IODINE_OK;
 }
 
@@ -468,6 +491,7 @@ int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps
     PROF(h, st, "pixel_pass1", launch_pixel_pass1(st, b.x4, b.dec_out, b.g, b.part, B, h->K, h->P, (float)h->cfg.sigma));
     HIPCHK(h, launch_pixel_finalize(st, b.part, B, h->K, h->P, h->cfg.layernorm, b.lnstat, b.ll_img));
     HIPCHK(h, launch_elbo(st, b.pm, b.plv, b.ll_img, B, h->K, h->L, b.img_terms + (size_t)i * B * 2, b.scal + 3 * i));
+    h->last_elbo_iter = i; h->last_elbo_batch = B;
     if (!need_grads) return IODINE_OK;
     float* dpre0 = nullptr;
     rc = decoder_backward_data(h, st, N, &dpre0, train_alpha, i);
@@ -522,6 +546,61 @@ int check_ready(iodine_handle* h, int batch)
         return h->fail(IODINE_ERR_INVALID, "batch too large for one device: batch * slots * pixels * channels must stay below 2^31 "
                                            "(shard the images over ranks, iodine_amd.parallel)");
     return IODINE_OK;
+}
+
+// Run `body` (a fixed-shape sequence of launches on `st`) eagerly, or - with option "graph" - through a hipGraph keyed by
+// the full argument tuple: the first call with a tuple runs eagerly (it also performs the one-time hipFuncSetAttribute
+// calls of the launchers), the second is captured + instantiated, later ones are a single hipGraphLaunch.  Host-side state
+// changes must NOT live in `body` (a replay does not execute it).
+template <typename F>
+int run_graphed(iodine_handle* h, hipStream_t st, const std::vector<uintptr_t>& key, F&& body)
+{
+    if (!h->graph || h->profile) return body();
+    if (!st) return h->fail(IODINE_ERR_INVALID, "option graph=1 needs a non-default stream (the legacy null stream cannot be captured)");
+    for (auto& g : h->graphs)
+        if (g.key == key) {
+            g.used = ++h->graph_clock;
+            HIPCHK(h, hipGraphLaunch(g.exec, st));
+            ++h->graph_replays;
+            return IODINE_OK;
+        }
+    bool seen = false;
+    for (auto& k : h->seen_keys) if (k == key) { seen = true; break; }
+    if (!seen) {
+        if (h->seen_keys.size() >= 64) h->seen_keys.clear();
+        h->seen_keys.push_back(key);
+        return body();
+    }
+    HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = body();
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return h->fail(IODINE_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    GraphEntry ge;
+    ge.key = key; ge.graph = graph;
+    const hipError_t e2 = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+    if (e2 != hipSuccess) { (void)hipGraphDestroy(graph); return h->fail(IODINE_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2)); }
+    if (h->graphs.size() >= 8) {                           // least recently used out
+        size_t lru = 0;
+        for (size_t i = 1; i < h->graphs.size(); ++i) if (h->graphs[i].used < h->graphs[lru].used) lru = i;
+        (void)hipGraphExecDestroy(h->graphs[lru].exec); (void)hipGraphDestroy(h->graphs[lru].graph);
+        h->graphs.erase(h->graphs.begin() + lru);
+    }
+    ge.used = ++h->graph_clock;
+    h->graphs.push_back(ge);
+    ++h->graph_captures;
+    HIPCHK(h, hipGraphLaunch(ge.exec, st));
+    return IODINE_OK;
+}
+
+std::vector<uintptr_t> graph_key(const iodine_handle* h, int entry, int batch, std::initializer_list<const void*> ptrs)
+{
+    std::vector<uintptr_t> k = {(uintptr_t)entry, (uintptr_t)batch, (uintptr_t)h->stop_after, (uintptr_t)h->precision,
+                                (uintptr_t)h->variant, (uintptr_t)h->wgrad_ws, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_variant,
+                                (uintptr_t)h->out_dgrad_variant, (uintptr_t)h->zigzag, (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
+    for (const void* p : ptrs) k.push_back((uintptr_t)p);
+    return k;
 }
 
 }  // namespace
@@ -616,6 +695,7 @@ void iodine_destroy(iodine_handle* h)
     for (void* p : h->owned) (void)hipFree(p);
     for (auto& c : h->prof) for (auto& e : c.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->ws_own) (void)hipFree(h->ws_own);
+    drop_graphs(h);
     delete h;
 }
 
@@ -728,6 +808,9 @@ int iodine_set_workspace(iodine_handle* h, void* dev_ptr, size_t bytes)
     if (((uintptr_t)dev_ptr & 255) != 0) return h->fail(IODINE_ERR_INVALID, "workspace must be 256-byte aligned");
     h->ws_user = dev_ptr; h->ws_user_bytes = dev_ptr ? bytes : 0;
     h->buf = Buffers();
+    h->fwd_done = false;
+    h->last_elbo_iter = -1;
+    drop_graphs(h);
     return IODINE_OK;
 }
 
@@ -736,6 +819,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!h || !key) return IODINE_ERR_INVALID;
     if (!strcmp(key, "stop_after_iters")) { h->stop_after = (int)value; return IODINE_OK; }
     if (!strcmp(key, "profile")) { h->profile = (int)value; return IODINE_OK; }
+    if (!strcmp(key, "graph")) { h->graph = value != 0; if (!h->graph) drop_graphs(h); return IODINE_OK; }
     if (!strcmp(key, "wgrad_ws")) { h->wgrad_ws = (int)value; return IODINE_OK; }   // 0 one-role, 1 ws + alignbit, 2 ws + transposing LDS reads
 #ifdef IODINE_XSKIP_HOOK
     if (!strcmp(key, "xskip")) { g_iod_xskip = (int)value; return IODINE_OK; }       // timing-only ablation builds (common.h)
@@ -745,7 +829,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "out_variant")) { h->out_variant = value != 0; return IODINE_OK; }
     if (!strcmp(key, "zigzag")) { h->zigzag = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {
-        if (value != 1 && value != 3 && value != 4 && value != 5) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1, 3, 4 or 5");
+        if (value != 1 && value != 5) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1 or 5");
         h->variant = (int)value;
         return IODINE_OK;
     }
@@ -766,31 +850,41 @@ int iodine_reconstruct(iodine_handle* h, void* stream, int batch, const float* x
     if (!x || !eps) return h->fail(IODINE_ERR_INVALID, "iodine_reconstruct: x and eps are required");
     rc = ensure_workspace(h, batch, 0);
     if (rc) return rc;
+    h->fwd_done = false;                                   // the arena is re-used: a saved training forward is gone
     hipStream_t st = (hipStream_t)stream;
-    Buffers& b = h->buf;
     const int B = batch, N = B * h->K, T = h->T;
-    const size_t eps_stride = (size_t)N * h->L;
-    HIPCHK(h, launch_x_to_nhwc4(st, x, b.x4, B, h->P));
-    HIPCHK(h, launch_posterior_init(st, h->init_mean, h->init_logvar, b.pm, b.plv, b.h[0], b.c[0], N, h->L, h->H));
     const bool partial = h->stop_after >= 0 && h->stop_after <= T;     // debug: stop before the final sample/decode
     const int n_it = partial ? h->stop_after : T;
-    for (int i = 0; i < n_it; ++i) {
-        rc = elbo_and_gradients(h, st, B, eps + (size_t)i * eps_stride, i, true);
-        if (rc) return rc;
-        rc = refine_step(h, st, B, i, false);
-        if (rc) return rc;
-    }
-    if (!partial) {
-        // z = posterior.sample(); decode(z)   (iodine.py:103,110)
-        HIPCHK(h, launch_dec_v(st, b.pm, b.plv, eps + (size_t)T * eps_stride, nullptr, h->wcls, b.z[T], b.V, N, h->L, h->Cd));
-        rc = decoder_forward(h, st, N);
-        if (rc) return rc;
-        HIPCHK(h, launch_final_out(st, b.dec_out, pred, mask, mean, B, h->K, h->P));
-        if (z) HIPCHK(h, hipMemcpyAsync(z, b.z[T], sizeof(float) * eps_stride, hipMemcpyDeviceToDevice, st));
-    }
-    if (post_mean) HIPCHK(h, hipMemcpyAsync(post_mean, b.pm, sizeof(float) * eps_stride, hipMemcpyDeviceToDevice, st));
-    if (post_logvar) HIPCHK(h, hipMemcpyAsync(post_logvar, b.plv, sizeof(float) * eps_stride, hipMemcpyDeviceToDevice, st));
-    if (elbo_iter) HIPCHK(h, hipMemcpyAsync(elbo_iter, b.scal, sizeof(float) * 3 * n_it, hipMemcpyDeviceToDevice, st));
+    auto body = [&]() -> int {
+        Buffers& b = h->buf;
+        const size_t eps_stride = (size_t)N * h->L;
+        HIPCHK(h, launch_x_to_nhwc4(st, x, b.x4, B, h->P));
+        HIPCHK(h, launch_posterior_init(st, h->init_mean, h->init_logvar, b.pm, b.plv, b.h[0], b.c[0], N, h->L, h->H));
+        for (int i = 0; i < n_it; ++i) {
+            int r = elbo_and_gradients(h, st, B, eps + (size_t)i * eps_stride, i, true);
+            if (r) return r;
+            r = refine_step(h, st, B, i, false);
+            if (r) return r;
+        }
+        if (!partial) {
+            // z = posterior.sample(); decode(z)   (iodine.py:103,110).  The decoder writes into the (now free) gradient
+            // buffer so that buf.dec_out keeps the outputs of the LAST elbo() call: the reference's self.mean / self.mask
+            // and its logger entries are those (iodine.py:226-239), not the final decode.
+            HIPCHK(h, launch_dec_v(st, b.pm, b.plv, eps + (size_t)T * eps_stride, nullptr, h->wcls, b.z[T], b.V, N, h->L, h->Cd));
+            const int r = decoder_forward(h, st, N, b.g);
+            if (r) return r;
+            HIPCHK(h, launch_final_out(st, b.g, pred, mask, mean, nullptr, B, h->K, h->P));
+            if (z) HIPCHK(h, hipMemcpyAsync(z, b.z[T], sizeof(float) * eps_stride, hipMemcpyDeviceToDevice, st));
+        }
+        if (post_mean) HIPCHK(h, hipMemcpyAsync(post_mean, b.pm, sizeof(float) * eps_stride, hipMemcpyDeviceToDevice, st));
+        if (post_logvar) HIPCHK(h, hipMemcpyAsync(post_logvar, b.plv, sizeof(float) * eps_stride, hipMemcpyDeviceToDevice, st));
+        if (elbo_iter && n_it > 0) HIPCHK(h, hipMemcpyAsync(elbo_iter, b.scal, sizeof(float) * 3 * n_it, hipMemcpyDeviceToDevice, st));
+        return IODINE_OK;
+    };
+    rc = run_graphed(h, st, graph_key(h, 1, B, {x, eps, pred, mask, mean, z, post_mean, post_logvar, elbo_iter}), body);
+    if (rc) return rc;
+    h->last_elbo_iter = n_it > 0 ? n_it - 1 : -1;
+    h->last_elbo_batch = B;
     return IODINE_OK;
 }
 
@@ -801,13 +895,69 @@ int iodine_decode(iodine_handle* h, void* stream, int batch, const float* z, flo
     if (!z) return h->fail(IODINE_ERR_INVALID, "iodine_decode: z is required");
     rc = ensure_workspace(h, batch, 0);
     if (rc) return rc;
+    h->fwd_done = false;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = batch * h->K;
+    auto body = [&]() -> int {
+        Buffers& b = h->buf;
+        HIPCHK(h, launch_dec_v(st, nullptr, nullptr, nullptr, z, h->wcls, nullptr, b.V, N, h->L, h->Cd));
+        const int r = decoder_forward(h, st, N, b.g);         // not buf.dec_out: that belongs to the last elbo() call
+        if (r) return r;
+        HIPCHK(h, launch_final_out(st, b.g, pred, mask, mean, nullptr, batch, h->K, h->P));
+        return IODINE_OK;
+    };
+    return run_graphed(h, st, graph_key(h, 2, batch, {z, pred, mask, mean}), body);
+}
+
+int iodine_elbo(iodine_handle* h, void* stream, int batch, const float* x, const float* post_mean, const float* post_logvar,
+                const float* eps, float* terms)
+{
+    int rc = check_ready(h, batch);
+    if (rc) return rc;
+    if (!x || !eps) return h->fail(IODINE_ERR_INVALID, "iodine_elbo: x and eps are required");
+    if ((post_mean == nullptr) != (post_logvar == nullptr))
+        return h->fail(IODINE_ERR_INVALID, "iodine_elbo: pass both post_mean and post_logvar, or neither");
+    rc = ensure_workspace(h, batch, 0);
+    if (rc) return rc;
+    h->fwd_done = false;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = batch, N = B * h->K;
+    auto body = [&]() -> int {
+        Buffers& b = h->buf;
+        HIPCHK(h, launch_x_to_nhwc4(st, x, b.x4, B, h->P));
+        if (post_mean) {
+            HIPCHK(h, hipMemcpyAsync(b.pm, post_mean, sizeof(float) * (size_t)N * h->L, hipMemcpyDeviceToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(b.plv, post_logvar, sizeof(float) * (size_t)N * h->L, hipMemcpyDeviceToDevice, st));
+        } else {
+            HIPCHK(h, launch_posterior_init(st, h->init_mean, h->init_logvar, b.pm, b.plv, b.h[0], b.c[0], N, h->L, h->H));
+        }
+        const int r = elbo_and_gradients(h, st, B, eps, 0, false);
+        if (r) return r;
+        if (terms) HIPCHK(h, hipMemcpyAsync(terms, b.scal, sizeof(float) * 3, hipMemcpyDeviceToDevice, st));
+        return IODINE_OK;
+    };
+    rc = run_graphed(h, st, graph_key(h, 3, B, {x, post_mean, post_logvar, eps, terms}), body);
+    if (rc) return rc;
+    h->last_elbo_iter = 0;
+    h->last_elbo_batch = B;
+    return IODINE_OK;
+}
+
+int iodine_last_elbo_outputs(iodine_handle* h, void* stream, int count, float* z, float* mean, float* mask,
+                             float* mask_logits, float* pred)
+{
+    if (!h) return IODINE_ERR_INVALID;
+    if (h->last_elbo_iter < 0 || h->buf.bytes == 0)
+        return h->fail(IODINE_ERR_STATE, "iodine_last_elbo_outputs: no elbo() has run on the current workspace");
+    if (count < 1 || count > h->last_elbo_batch)
+        return h->fail(IODINE_ERR_INVALID, "iodine_last_elbo_outputs: count must be in 1..batch of the last call");
     hipStream_t st = (hipStream_t)stream;
     Buffers& b = h->buf;
-    const int N = batch * h->K;
-    HIPCHK(h, launch_dec_v(st, nullptr, nullptr, nullptr, z, h->wcls, nullptr, b.V, N, h->L, h->Cd));
-    rc = decoder_forward(h, st, N);
-    if (rc) return rc;
-    HIPCHK(h, launch_final_out(st, b.dec_out, pred, mask, mean, batch, h->K, h->P));
+    if (mean || mask || mask_logits || pred)
+        HIPCHK(h, launch_final_out(st, b.dec_out, pred, mask, mean, mask_logits, count, h->K, h->P));
+    if (z)
+        HIPCHK(h, hipMemcpyAsync(z, b.z[h->last_elbo_iter], sizeof(float) * (size_t)count * h->K * h->L,
+                                 hipMemcpyDeviceToDevice, st));
     return IODINE_OK;
 }
 
@@ -820,41 +970,60 @@ int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float*
     rc = ensure_workspace(h, batch, 1);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    Buffers& b = h->buf;
     const int B = batch, N = B * h->K, T = h->T, L = h->L;
-    const size_t eps_stride = (size_t)N * L;
     h->fwd_done = false;
-    HIPCHK(h, hipMemsetAsync(h->gacc_arena, 0, sizeof(float) * h->gacc_total, st));
-    HIPCHK(h, launch_x_to_nhwc4(st, x, b.x4, B, h->P));
-    HIPCHK(h, launch_posterior_init(st, h->init_mean, h->init_logvar, b.pm, b.plv, b.h[0], b.c[0], N, L, h->H));
-    for (int i = 0; i <= T; ++i) {
-        const float alpha = -((float)(i + 1) / (float)(T + 1)) / (float)B;      // d loss / d (B * ELBO_i)
-        rc = elbo_and_gradients(h, st, B, eps + (size_t)i * eps_stride, i, true, alpha);
-        if (rc) return rc;
-        if (i == 0) {
-            // lambda_0 = init_mean / init_logvar repeated over (B, K) (iodine.py:615-616): their gradient is the
-            // column sum of d loss / d lambda_0; later lambdas are detached from it (iodine.py:642-643)
-            HIPCHK(h, launch_colsum(st, b.g_pm[0], N, L, L, alpha, h->gacc[param_index(h, "posterior.init_mean")]));
-            HIPCHK(h, launch_colsum(st, b.g_plv[0], N, L, L, alpha, h->gacc[param_index(h, "posterior.init_logvar")]));
+    auto body = [&]() -> int {
+        Buffers& b = h->buf;
+        const size_t eps_stride = (size_t)N * L;
+        HIPCHK(h, hipMemsetAsync(h->gacc_arena, 0, sizeof(float) * h->gacc_total, st));
+        HIPCHK(h, launch_x_to_nhwc4(st, x, b.x4, B, h->P));
+        HIPCHK(h, launch_posterior_init(st, h->init_mean, h->init_logvar, b.pm, b.plv, b.h[0], b.c[0], N, L, h->H));
+        for (int i = 0; i <= T; ++i) {
+            const float alpha = -((float)(i + 1) / (float)(T + 1)) / (float)B;      // d loss / d (B * ELBO_i)
+            int r = elbo_and_gradients(h, st, B, eps + (size_t)i * eps_stride, i, true, alpha);
+            if (r) return r;
+            if (i == 0) {
+                // lambda_0 = init_mean / init_logvar repeated over (B, K) (iodine.py:615-616): their gradient is the
+                // column sum of d loss / d lambda_0; later lambdas are detached from it (iodine.py:642-643)
+                HIPCHK(h, launch_colsum(st, b.g_pm[0], N, L, L, alpha, h->gacc[param_index(h, "posterior.init_mean")]));
+                HIPCHK(h, launch_colsum(st, b.g_plv[0], N, L, L, alpha, h->gacc[param_index(h, "posterior.init_logvar")]));
+            }
+            if (i < T) {
+                r = refine_step(h, st, B, i, true);
+                if (r) return r;
+            }
         }
-        if (i < T) {
-            rc = refine_step(h, st, B, i, true);
-            if (rc) return rc;
-        }
-    }
-    HIPCHK(h, launch_loss(st, b.scal, T + 1, loss));
-    if (elbo_iter) HIPCHK(h, hipMemcpyAsync(elbo_iter, b.scal, sizeof(float) * 3 * (T + 1), hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, launch_loss(st, b.scal, T + 1, loss));
+        if (elbo_iter) HIPCHK(h, hipMemcpyAsync(elbo_iter, b.scal, sizeof(float) * 3 * (T + 1), hipMemcpyDeviceToDevice, st));
+        return IODINE_OK;
+    };
+    rc = run_graphed(h, st, graph_key(h, 4, B, {x, eps, loss, elbo_iter}), body);
+    if (rc) return rc;
     h->fwd_done = true;
     h->fwd_batch = B;
+    h->last_elbo_iter = T;
+    h->last_elbo_batch = B;
     return IODINE_OK;
 }
 
-int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, float* const* param_grads, int n)
+static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale, const float* grad_scale_dev,
+                               float* const* param_grads, int n, int accumulate)
 {
     if (!h) return IODINE_ERR_INVALID;
     if (!h->fwd_done) return h->fail(IODINE_ERR_STATE, "iodine_train_backward: no iodine_train_forward to differentiate");
     if (n != (int)h->params.size() || !param_grads) return h->fail(IODINE_ERR_INVALID, "iodine_train_backward: wrong parameter count");
+    if (h->buf.mode != 1 || h->buf.B != h->fwd_batch)
+        return h->fail(IODINE_ERR_STATE, "iodine_train_backward: the training workspace of the forward pass was re-planned");
     hipStream_t st = (hipStream_t)stream;
+    std::vector<const void*> kp;
+    for (int i = 0; i < n; ++i) kp.push_back(param_grads[i]);
+    std::vector<uintptr_t> key = graph_key(h, 5, h->fwd_batch, {});
+    for (const void* q : kp) key.push_back((uintptr_t)q);
+    uint32_t gs_bits; memcpy(&gs_bits, &grad_scale, 4);
+    key.push_back(gs_bits);
+    key.push_back((uintptr_t)grad_scale_dev);
+    key.push_back((uintptr_t)accumulate);
+    auto body = [&]() -> int {
     Buffers& b = h->buf;
     const int B = h->fwd_batch, N = B * h->K, T = h->T, L = h->L, H = h->H, Cr = h->Cr, IN = H + 4 * L;
     auto G = [&](const std::string& name) { return h->gacc[param_index(h, name)]; };
@@ -925,13 +1094,41 @@ int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, floa
     for (size_t p = 0; p < h->params.size() && flat; ++p)
         flat = param_grads[p] && param_grads[p] == param_grads[0] + (h->gacc[p] - h->gacc_arena);
     if (flat) {
-        HIPCHK(h, launch_axpy(st, h->gacc_arena, grad_scale, param_grads[0], (int)h->gacc_total));
+        HIPCHK(h, launch_axpy_dev(st, h->gacc_arena, grad_scale, grad_scale_dev, param_grads[0], (int)h->gacc_total, accumulate));
         return IODINE_OK;
     }
     for (size_t p = 0; p < h->params.size(); ++p) {
         if (!param_grads[p]) continue;
-        HIPCHK(h, launch_axpy(st, h->gacc[p], grad_scale, param_grads[p], (int)h->params[p].numel()));
+        HIPCHK(h, launch_axpy_dev(st, h->gacc[p], grad_scale, grad_scale_dev, param_grads[p], (int)h->params[p].numel(), accumulate));
     }
+    return IODINE_OK;
+    };
+    const int rc = run_graphed(h, st, key, body);
+    // like autograd without retain_graph: the saved forward is consumed (a second backward would add the BPTT terms to the
+    // accumulators twice); iodine_train_forward must run again first
+    h->fwd_done = false;
+    return rc;
+}
+
+int iodine_train_backward(iodine_handle* h, void* stream, float grad_scale, float* const* param_grads, int n)
+{
+    return train_backward_impl(h, stream, grad_scale, nullptr, param_grads, n, 1);
+}
+
+int iodine_train_backward_flat(iodine_handle* h, void* stream, const float* grad_loss_dev, float* flat_grads, int accumulate)
+{
+    if (!h) return IODINE_ERR_INVALID;
+    if (!flat_grads) return h->fail(IODINE_ERR_INVALID, "iodine_train_backward_flat: flat_grads is required");
+    std::vector<float*> ptrs(h->params.size());
+    for (size_t p = 0; p < h->params.size(); ++p) ptrs[p] = flat_grads + (h->gacc[p] - h->gacc_arena);
+    return train_backward_impl(h, stream, 1.f, grad_loss_dev, ptrs.data(), (int)ptrs.size(), accumulate ? 1 : 0);
+}
+
+int iodine_logger_scalars(iodine_handle* h, void* stream, float* out2)
+{
+    if (!h || !out2) return IODINE_ERR_INVALID;
+    if (!h->params_set) return h->fail(IODINE_ERR_STATE, "iodine_set_params has not been called");
+    HIPCHK(h, launch_mean2((hipStream_t)stream, h->init_mean, h->init_logvar, h->L, out2));
     return IODINE_OK;
 }
 
@@ -1020,6 +1217,14 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
     return IODINE_OK;
 }
 
+int iodine_randn(void* stream, float* out, long long n, unsigned long long seed, unsigned long long stream_id)
+{
+    if (!out || n < 1) { g_create_error = "iodine_randn: bad argument"; return IODINE_ERR_INVALID; }
+    const hipError_t e = launch_randn_philox((hipStream_t)stream, out, n, seed, stream_id);
+    if (e != hipSuccess) { g_create_error = std::string("iodine_randn: ") + hipGetErrorString(e); return IODINE_ERR_HIP; }
+    return IODINE_OK;
+}
+
 void iodine_linspace_host(int n, float* out)
 {
     // ATen's CPU linspace for float: step = (end - start) / (n - 1); first half counts up from start,
@@ -1056,16 +1261,14 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, c
         if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(s2 f16x3): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
         return IODINE_OK;
     }
-    if (mode == 2 || mode == 4 || mode == 7 || mode == 8) {   // split-fp16 tile kernels (4 = warp-specialised persistent, 7 = eight-wave form, 8 = 8x16 tiles)
+    if (mode == 2 || mode == 8) {   // split-fp16 tile kernel (8 = 8x16 tiles)
         float* meta = nullptr;
         const size_t bytes = (size_t)(cin_pad / 16) * 9 * 2 * 2 * cout * 16;
         if (hipMalloc((void**)&wpk, bytes + 64) != hipSuccess) return IODINE_ERR_HIP;
         meta = (float*)((char*)wpk + bytes);
         hipError_t e2 = launch_pack_conv_weights_f16(st, w, w_o, w_i, cin_pad, cout, tflip, meta, wpk);
         if (e2 == hipSuccess)
-            e2 = (mode == 2 || mode == 8) ? launch_conv3x3_tile_f16x3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi, 0, mode == 8 ? 8 : 16)
-                 : mode == 4 ? launch_conv3x3_tile_f16x3_v3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi)
-                             : launch_conv3x3_tile8_f16x3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi);
+            e2 = launch_conv3x3_tile_f16x3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi, 0, mode == 8 ? 8 : 16);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
         (void)hipFree(wpk);
         if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(f16x3): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }

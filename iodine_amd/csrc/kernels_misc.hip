@@ -879,3 +879,52 @@ hipError_t launch_ari_table(hipStream_t st, const float* mask, const unsigned ch
     hipLaunchKernelGGL(ari_table_kernel, dim3(bx, B), dim3(256), (size_t)G * K * sizeof(int), st, mask, gt, K, G, P, table);
     return hipGetLastError();
 }
+
+// -----------------------------------------------------------------------------------------------
+// Counter-based standard normals for Gaussian.sample (iodine.py:620-634 calls torch.randn_like; the values of a torch
+// generator are not part of the reference's contract, only their distribution).  Philox4x32-10 (Salmon et al., SC'11):
+// counter = {quad index lo, hi, stream lo, hi}, key = {seed lo, hi}; the four 32-bit outputs of one call give two
+// Box-Muller pairs.  Element e of the output is normal #(e & 3) of quad e >> 2, so any sub-range / any launch shape
+// produces the same numbers (oracle/philox_oracle.py restates this in numpy; tests/test_gpu_extras.py compares).
+// -----------------------------------------------------------------------------------------------
+IOD_DEVINL void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256)
+void randn_philox_kernel(float* __restrict__ out, long long n, unsigned k0, unsigned k1, unsigned s0, unsigned s1)
+{
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q * 4 >= n) return;
+    unsigned r[4];
+    philox4x32_10((unsigned)q, (unsigned)((unsigned long long)q >> 32), s0, s1, k0, k1, r);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float u1 = ((float)(r[2 * j] >> 9) + 0.5f) * 1.1920928955078125e-07f;        // (0, 1), exact in fp32
+        const float u2 = ((float)(r[2 * j + 1] >> 9) + 0.5f) * 1.1920928955078125e-07f;
+        const float rad = sqrtf(-2.f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        v[2 * j] = rad * cs; v[2 * j + 1] = rad * sn;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (q * 4 + j < n) out[q * 4 + j] = v[j];
+}
+
+hipError_t launch_randn_philox(hipStream_t st, float* out, long long n, unsigned long long seed, unsigned long long stream_id)
+{
+    const long long quads = (n + 3) / 4;
+    hipLaunchKernelGGL(randn_philox_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, out, n,
+                       (unsigned)seed, (unsigned)(seed >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32));
+    return hipGetLastError();
+}

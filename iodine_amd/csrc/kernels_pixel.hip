@@ -237,7 +237,7 @@ void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict_
 template <int K>
 __global__ __launch_bounds__(PIX_BLOCK)
 void final_out_kernel(const float4* __restrict__ dec, float* __restrict__ pred, float* __restrict__ mask,
-                      float* __restrict__ mean, int P)
+                      float* __restrict__ mean, float* __restrict__ logits, int P)
 {
     const int b = blockIdx.y;
     const int p = blockIdx.x * PIX_BLOCK + threadIdx.x;
@@ -258,6 +258,7 @@ void final_out_kernel(const float4* __restrict__ dec, float* __restrict__ pred, 
         const float mu[3] = {sigmoidf_(d[k].x), sigmoidf_(d[k].y), sigmoidf_(d[k].z)};
         const size_t n = (size_t)b * K + k;
         if (mask) mask[n * P + p] = m[k];
+        if (logits) logits[n * P + p] = d[k].w;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             if (mean) mean[(n * 3 + c) * P + p] = mu[c];
@@ -318,13 +319,13 @@ hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec,
     return hipGetLastError();
 }
 
-hipError_t launch_final_out(hipStream_t st, const float* dec, float* pred, float* mask, float* mean, int B, int K,
-                            int P)
+hipError_t launch_final_out(hipStream_t st, const float* dec, float* pred, float* mask, float* mean, float* logits,
+                            int B, int K, int P)
 {
     const dim3 grid((P + PIX_BLOCK - 1) / PIX_BLOCK, B);
     switch (K) {
 #define CASE(KK) case KK: hipLaunchKernelGGL((final_out_kernel<KK>), grid, dim3(PIX_BLOCK), 0, st, \
-        (const float4*)dec, pred, mask, mean, P); break;
+        (const float4*)dec, pred, mask, mean, logits, P); break;
         FOR_EACH_K(CASE)
 #undef CASE
         default: return hipErrorInvalidValue;

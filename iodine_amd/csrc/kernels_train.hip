@@ -597,6 +597,39 @@ __global__ void axpy_kernel(const float* __restrict__ x, float alpha, float* __r
     if (i < n) y[i] += alpha * x[i];
 }
 
+// y = (accumulate ? y : 0) + alpha * (*alpha_dev) * x : the hand-over of the accumulated gradients to the caller's flat
+// buffer with autograd's incoming grad_output read from device memory (no host round trip, no separate zero-fill)
+__global__ void axpy_dev_kernel(const float* __restrict__ x, float alpha, const float* __restrict__ alpha_dev,
+                                float* __restrict__ y, int n, int accumulate)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = alpha_dev ? alpha * alpha_dev[0] : alpha;
+    y[i] = accumulate ? y[i] + a * x[i] : a * x[i];
+}
+
+hipError_t launch_axpy_dev(hipStream_t st, const float* x, float alpha, const float* alpha_dev, float* y, int n, int accumulate)
+{
+    hipLaunchKernelGGL(axpy_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, alpha, alpha_dev, y, n, accumulate);
+    return hipGetLastError();
+}
+
+// out[0] = mean(a[0..n)), out[1] = mean(b[0..n)): the two logger scalars of IODINE.forward (iodine.py:156-157)
+__global__ void mean2_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float* __restrict__ out)
+{
+    const float* src = blockIdx.x == 0 ? a : b;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += (double)src[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)(s / n);
+}
+
+hipError_t launch_mean2(hipStream_t st, const float* a, const float* b, int n, float* out)
+{
+    hipLaunchKernelGGL(mean2_kernel, dim3(2), dim3(64), 0, st, a, b, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_axpy(hipStream_t st, const float* x, float alpha, float* y, int n)
 {
     IOD_XSKIP(64);

@@ -12,7 +12,9 @@ a ROCm device and the shared library must be built.
 
 Extensions over the reference: every entry point takes an optional ``eps`` tensor of shape
 (T+1, B, K, L) replacing the ``torch.randn_like`` draws of ``Gaussian.sample``
-(iodine.py:632) in call order, so that results can be compared with the CPU oracle.
+(iodine.py:632) in call order, so that results can be compared with the CPU oracle.  Without
+``eps`` the draws come from the library's own counter-based generator (Philox4x32-10,
+``iodine_randn``; seed with ``model.manual_seed``) - no ATen kernel runs on the product path.
 """
 from __future__ import annotations
 
@@ -98,13 +100,14 @@ class _TrainStep(torch.autograd.Function):
     def forward(ctx, module, x, eps, *params):
         loss, elbo_iter = module._train_forward(x, eps)
         ctx.module = module
+        ctx.serial = module._call_serial            # identity of the saved forward (the library keeps exactly one)
         ctx.n = len(params)
         ctx.mark_non_differentiable(elbo_iter)
         return loss, elbo_iter
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_elbo):
-        grads = ctx.module._train_backward(grad_loss)
+        grads = ctx.module._train_backward(grad_loss, ctx.serial)
         return (None, None, None, *grads)
 
 
@@ -150,8 +153,11 @@ class IODINE(nn.Module):
         self._param_versions = None
         self._workspace = None
         self._ws_key = None
-        self.generator: Optional[torch.Generator] = None
         self._options: Dict[str, float] = {}
+        self._seed = 0                  # Philox key of the library's normal generator (manual_seed)
+        self._draws = 0                 # Philox stream id: one per eps draw
+        self._call_serial = 0           # bumped by every compute call; a backward must match the forward that saved state
+        self._graph_stream = None
 
     # ---- bookkeeping identical to the reference -------------------------------------------------
     def get_input_size(self):
@@ -206,6 +212,31 @@ class IODINE(nn.Module):
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    def _launch(self, device, fn):
+        """Run ``fn()`` (library calls on the current stream) with ``device`` current.  With option ``graph`` the calls go to
+        a private non-default stream (the legacy null stream cannot be captured), ordered after / before the caller's."""
+        with torch.cuda.device(device):
+            if not self._options.get('graph'):
+                return fn()
+            if self._graph_stream is None or self._graph_stream.device != device:
+                self._graph_stream = torch.cuda.Stream(device=device)
+            cur = torch.cuda.current_stream()
+            self._graph_stream.wait_stream(cur)
+            with torch.cuda.stream(self._graph_stream):
+                out = fn()
+            cur.wait_stream(self._graph_stream)
+            return out
+
+    def manual_seed(self, seed: int):
+        """Seed of the library's generator for the ``eps=None`` draws (Philox4x32-10; give every rank its own seed)."""
+        self._seed, self._draws = int(seed) & (2 ** 64 - 1), 0
+        return self
+
+    def mark_params_dirty(self):
+        """Force a re-pack of the weights on the next call.  Needed only after writes that bypass autograd's version counter
+        (``p.data.copy_(...)``, ``dist.broadcast(p.data, 0)``); optimizers, ``load_state_dict`` and ``.to()`` are seen."""
+        self._param_versions = None
+
     def _sync_params(self, device):
         h = self._ensure_handle(device)
         params = self._ordered_params()
@@ -240,8 +271,15 @@ class IODINE(nn.Module):
 
     def _eps(self, eps, B, device):
         shape = (self.n_iters + 1, B, self.K, self.dim_latent)
+        return self._normals(eps, shape, device)
+
+    def _normals(self, eps, shape, device):
         if eps is None:
-            return torch.randn(shape, device=device, dtype=torch.float32, generator=self.generator)
+            out = torch.empty(shape, device=device, dtype=torch.float32)
+            self._launch(device, lambda: _lib.check(_lib.lib().iodine_randn(self._stream(), _lib.ptr(out), out.numel(),
+                                                                          self._seed, self._draws), None, 'iodine_randn'))
+            self._draws += 1
+            return out
         if tuple(eps.shape) != shape:
             raise RuntimeError(f'eps must have shape {shape}, got {tuple(eps.shape)}')
         return eps.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -274,6 +312,22 @@ class IODINE(nn.Module):
         return tot.value, cnt.value
 
     # ---- inference: iodine.py:59-112 ------------------------------------------------------------
+    def _fetch_last_elbo(self, h, x, terms, count=None):
+        """State the reference leaves on ``self`` after an ``elbo()`` call (iodine.py:171-187) and its logger entries
+        (iodine.py:225-239): z, mean, mask, mask_logits of the whole batch and pred/image of image 0."""
+        dev, B = x.device, x.shape[0]
+        K, L, S = self.K, self.dim_latent, self.img_size
+        f = dict(device=dev, dtype=torch.float32)
+        z, mean = torch.empty((B, K, L), **f), torch.empty((B, K, 3, S, S), **f)
+        mask, logits, pred = torch.empty((B, K, 1, S, S), **f), torch.empty((B, K, 1, S, S), **f), torch.empty((B, 3, S, S), **f)
+        self._launch(dev, lambda: _lib.check(_lib.lib().iodine_last_elbo_outputs(
+            h, self._stream(), B, _lib.ptr(z), _lib.ptr(mean), _lib.ptr(mask), _lib.ptr(logits), _lib.ptr(pred)),
+            h, 'iodine_last_elbo_outputs'))
+        self.z, self.mean, self.mask, self.mask_logits = z, mean, mask, logits
+        logger.update(image=x[0], pred=pred[0], kl=terms[1], likelihood=terms[2])
+        logger.update(**{f'mask_{i}': mask[0, i, 0] for i in range(K)})
+        logger.update(**{f'pred_{i}': mean[0, i] for i in range(K)})
+
     @torch.no_grad()
     def _reconstruct(self, x, eps, want_images=True):
         x = self._check_x(x)
@@ -288,15 +342,16 @@ class IODINE(nn.Module):
         mean = torch.empty((B, K, 3, S, S), **f) if want_images else None
         z = torch.empty((B, K, L), **f)
         pm, plv = torch.empty((B, K, L), **f), torch.empty((B, K, L), **f)
-        elbo = torch.empty((T, 3), **f)
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().iodine_reconstruct(h, self._stream(), B, _lib.ptr(x), _lib.ptr(eps), _lib.ptr(pred),
-                                                     _lib.ptr(mask), _lib.ptr(mean), _lib.ptr(z), _lib.ptr(pm),
-                                                     _lib.ptr(plv), _lib.ptr(elbo)), h, 'iodine_reconstruct')
-        self.z, self.posterior.mean, self.posterior.logvar, self.elbo_terms = z, pm, plv, elbo
-        if want_images:
-            self.mean, self.mask = mean, mask
-            self._publish(x, pred, mask, mean, elbo[-1])
+        stop = int(self._options.get('stop_after_iters', -1))
+        n_it = stop if 0 <= stop <= T else T
+        elbo = torch.empty((n_it, 3), **f)
+        self._call_serial += 1
+        self._launch(dev, lambda: _lib.check(_lib.lib().iodine_reconstruct(
+            h, self._stream(), B, _lib.ptr(x), _lib.ptr(eps), _lib.ptr(pred), _lib.ptr(mask), _lib.ptr(mean), _lib.ptr(z),
+            _lib.ptr(pm), _lib.ptr(plv), _lib.ptr(elbo)), h, 'iodine_reconstruct'))
+        self.posterior.mean, self.posterior.logvar, self.elbo_terms = pm, plv, elbo
+        if n_it > 0:
+            self._fetch_last_elbo(h, x, elbo[-1])        # what the reference's last elbo() call left behind
         return pred, mask, mean, z
 
     def encode(self, x, eps=None):
@@ -318,10 +373,36 @@ class IODINE(nn.Module):
         K, S = self.K, self.img_size
         f = dict(device=dev, dtype=torch.float32)
         pred, mask, mean = torch.empty((B, 3, S, S), **f), torch.empty((B, K, 1, S, S), **f), torch.empty((B, K, 3, S, S), **f)
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().iodine_decode(h, self._stream(), B, _lib.ptr(z), _lib.ptr(pred), _lib.ptr(mask),
-                                                _lib.ptr(mean)), h, 'iodine_decode')
+        self._call_serial += 1
+        self._launch(dev, lambda: _lib.check(_lib.lib().iodine_decode(h, self._stream(), B, _lib.ptr(z), _lib.ptr(pred),
+                                                                      _lib.ptr(mask), _lib.ptr(mean)), h, 'iodine_decode'))
         return pred, mask, mean
+
+    @torch.no_grad()
+    def elbo(self, x, eps=None):
+        """Single-pass ELBO (iodine.py:161-241): one sample from the current posterior (``self.posterior.mean / logvar`` as
+        left by the last call for this batch size; otherwise the initial posterior of ``init_unit``, iodine.py:607-618),
+        decode, mixture log-likelihood minus KL.  Sets ``self.z / mean / mask / mask_logits`` and the logger entries like the
+        reference.  ``eps`` (B, K, L) replaces the ``torch.randn_like`` draw.  Returns the scalar ELBO (no autograd graph:
+        the gradients the reference takes from it are what reconstruct / forward compute in closed form)."""
+        x = self._check_x(x)
+        dev, B = x.device, x.shape[0]
+        h = self._sync_params(dev)
+        self._ensure_workspace(h, B, 0, dev)
+        shape = (B, self.K, self.dim_latent)
+        eps = self._normals(eps, shape, dev)
+        pm, plv = self.posterior.mean, self.posterior.logvar
+        if pm is None or plv is None or tuple(pm.shape) != shape or pm.device != dev:
+            pm = plv = None
+        else:
+            pm, plv = pm.detach().to(torch.float32).contiguous(), plv.detach().to(torch.float32).contiguous()
+        terms = torch.empty((3,), device=dev, dtype=torch.float32)
+        self._call_serial += 1
+        self._launch(dev, lambda: _lib.check(_lib.lib().iodine_elbo(h, self._stream(), B, _lib.ptr(x), _lib.ptr(pm), _lib.ptr(plv),
+                                                                    _lib.ptr(eps), _lib.ptr(terms)), h, 'iodine_elbo'))
+        self.elbo_terms = terms.view(1, 3)
+        self._fetch_last_elbo(h, x, terms)
+        return terms[0]
 
     # ---- training: iodine.py:115-158 + lib/engine/train.py:60-63 -------------------------------------
     def forward(self, x, eps=None):
@@ -330,9 +411,12 @@ class IODINE(nn.Module):
         eps = self._eps(eps, x.shape[0], x.device)
         loss, elbo_iter = _TrainStep.apply(self, x, eps, *self._ordered_params())
         self.elbo_terms = elbo_iter
-        logger.update(init_mean=self.posterior.init_mean.detach().mean(),
-                      init_logvar=self.posterior.init_logvar.detach().mean())          # iodine.py:156-157
-        logger.update(kl=elbo_iter[-1, 1], likelihood=elbo_iter[-1, 2])
+        with torch.no_grad():
+            h, dev = self._handle, x.device
+            self._fetch_last_elbo(h, x, elbo_iter[-1])                                 # final elbo(): iodine.py:226-239
+            stats = torch.empty((2,), device=dev, dtype=torch.float32)
+            self._launch(dev, lambda: _lib.check(_lib.lib().iodine_logger_scalars(h, self._stream(), _lib.ptr(stats)), h))
+            logger.update(init_mean=stats[0], init_logvar=stats[1])                    # iodine.py:156-157
         return loss
 
     def _train_forward(self, x, eps):
@@ -341,31 +425,30 @@ class IODINE(nn.Module):
         self._ensure_workspace(h, B, 1, dev)
         loss = torch.empty((), device=dev, dtype=torch.float32)
         elbo_iter = torch.empty((self.n_iters + 1, 3), device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().iodine_train_forward(h, self._stream(), B, _lib.ptr(x), _lib.ptr(eps), _lib.ptr(loss),
-                                                       _lib.ptr(elbo_iter)), h, 'iodine_train_forward')
+        self._call_serial += 1
+        self._launch(dev, lambda: _lib.check(_lib.lib().iodine_train_forward(h, self._stream(), B, _lib.ptr(x), _lib.ptr(eps),
+                                                                             _lib.ptr(loss), _lib.ptr(elbo_iter)),
+                                             h, 'iodine_train_forward'))
         return loss, elbo_iter
 
-    def _train_backward(self, grad_loss):
+    def _train_backward(self, grad_loss, serial):
+        if serial != self._call_serial:
+            raise RuntimeError('IODINE: backward of a stale forward - the library keeps the saved state of ONE forward pass and '
+                               'another forward / reconstruct / decode / elbo call has re-used it since (the reference would '
+                               'hold a second autograd graph; call loss.backward() before the next model call)')
         h, dev = self._handle, self._handle_device
         params = self._ordered_params()
         sizes = [p.numel() for p in params]
-        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
         views, off = [], 0
         for p, n in zip(params, sizes):
             views.append(flat[off:off + n].view_as(p))
             off += n
-        arr = (C.c_void_p * len(views))(*[v.data_ptr() for v in views])
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().iodine_train_backward(h, self._stream(), 1.0, arr, len(views)), h, 'iodine_train_backward')
-        flat.mul_(grad_loss.to(torch.float32))
+        gl = grad_loss.detach().to(device=dev, dtype=torch.float32).contiguous()
+        self._launch(dev, lambda: _lib.check(_lib.lib().iodine_train_backward_flat(h, self._stream(), _lib.ptr(gl), _lib.ptr(flat), 0),
+                                             h, 'iodine_train_backward'))
+        self._call_serial += 1                      # the saved forward is consumed (no retain_graph)
         return views
-
-    # ---- logger side channel (iodine.py:226-239) ----------------------------------------------------
-    def _publish(self, x, pred, mask, mean, terms):
-        logger.update(image=x[0], pred=pred[0], kl=terms[1], likelihood=terms[2])
-        logger.update(**{f'mask_{i}': mask[0, i, 0] for i in range(self.K)})
-        logger.update(**{f'pred_{i}': mean[0, i] for i in range(self.K)})
 
 
 def arch_namespace(dim_latent, iters, slots, img_size, ref, dec, sigma=0.10, layernorm=True,

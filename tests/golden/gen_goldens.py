@@ -214,6 +214,43 @@ def dump_stages(model, x, e, out):
             out[f'stage{i}.{k}'] = v.numpy()
 
 
+def run_logger_case():
+    """The observability side channel (iodine.py:156-157,226-239): every entry the reference leaves in
+    ``lib.utils.vis_logger.logger`` after a training forward and after ``reconstruct`` (tiny case, fp32), plus the state
+    ``elbo()`` leaves on ``self`` (z, mean, mask, mask_logits) and a stand-alone ``model.elbo(x)`` on the initial posterior."""
+    from lib.utils.vis_logger import logger as ref_logger            # the reference's global logger object
+    fam, K, T, B, kind = CASES['tiny']
+    S, L = ARCHS[fam]['S'], ARCHS[fam]['L']
+    imgs = synth.make_images(B, S, seed=SEED_X, kind='uniform')
+    eps = synth.make_eps(T, B, K, L, seed=SEED_E)
+    model, _ = build_reference(fam, K, T, torch.float32)
+    x, e = torch.from_numpy(imgs), torch.from_numpy(eps)
+    out = dict(meta_case='tiny')
+
+    def dump(tag):
+        for k, v in ref_logger.things.items():
+            out[f'{tag}.logger.{k}'] = v.detach().double().numpy().copy() if torch.is_tensor(v) else np.float64(v)
+        for k in ('z', 'mean', 'mask', 'mask_logits'):
+            out[f'{tag}.self.{k}'] = getattr(model, k).detach().double().numpy().copy()
+        ref_logger.things.clear()
+
+    model.train()
+    with EpsReplay(e):
+        model(x)
+    dump('train')
+    model.eval()
+    with EpsReplay(e):
+        model.reconstruct(x)
+    dump('recon')
+    # stand-alone elbo(x) on the initial posterior (what forward() does first: init_unit, then elbo)
+    model.posterior.init_unit(B, K)
+    with EpsReplay(e):
+        v = model.elbo(x)
+    out['elbo.value'] = np.float64(v.item())
+    dump('elbo')
+    return out
+
+
 def ari_known_answer():
     table = np.array([[3, 0, 1], [1, 2, 1], [0, 2, 2]])       # lib/utils/ari.py:56-63
     extra = []
@@ -232,10 +269,10 @@ def ari_known_answer():
 
 def main():
     torch.set_num_threads(8)
-    want = sys.argv[1:] or (list(CASES) + ['ari'])
+    want = sys.argv[1:] or (list(CASES) + ['ari', 'tiny_logger'])
     for case in want:
         t0 = time.time()
-        out = ari_known_answer() if case == 'ari' else run_case(case)
+        out = ari_known_answer() if case == 'ari' else run_logger_case() if case == 'tiny_logger' else run_case(case)
         path = os.path.join(HERE, case + '.npz')
         np.savez_compressed(path, **out)
         print(f'{case}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB, {time.time() - t0:.1f}s)')

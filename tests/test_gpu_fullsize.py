@@ -42,7 +42,7 @@ def test_full_size_reconstruct(case, B):
     xd, ed = x.to(DEV), eps.to(DEV)
     pred, mask, mean = m.reconstruct(xd, ed)
     full = m.elbo_terms.clone()
-    z = m.z.clone() if hasattr(m, 'z') and m.z is not None else None
+    z = m.encode(xd, ed)                                                   # the final sample (iodine.py:103)
     p2, k2, m2 = m.reconstruct(xd, ed)                                     # determinism
     assert torch.equal(p2, pred) and torch.equal(k2, mask) and torch.equal(m2, mean)
     assert torch.equal(m.elbo_terms, full)

@@ -65,8 +65,8 @@ def test_tiny_reconstruct_full_tensors():
     assert rel_err(mask.cpu(), g['f32.recon.mask']) < 1e-4
     assert rel_err(mean.cpu(), g['f32.recon.mean']) < 1e-4
     assert rel_err(m.posterior.mean.cpu(), g['f32.recon.post_mean']) < 1e-4
-    # decode(z) reproduces the same images from the returned sample
-    p2, k2, m2 = m.decode(m.z)
+    # decode(encode(x)) reproduces the same images (iodine.py:107-112: reconstruct = decode(encode(x)))
+    p2, k2, m2 = m.decode(m.encode(x.to(DEV), eps.to(DEV)))
     assert torch.equal(p2, pred) and torch.equal(k2, mask) and torch.equal(m2, mean)
 
 

@@ -1,3 +1,5 @@
+// EXPERIMENT, not part of libiodine_hip.so: eight-wave form of the split-fp16 tile conv (round 1, "conv_variant=4").
+// Same results bit for bit, same time; kept for reference only.
 // Eight-wave form of the split-fp16 stride-1 tile conv (decoder 64->64 / 32->32 layers, lib/modeling/iodine.py:583,592
 // forward and the autograd data gradient).  Same arithmetic, data layout, LDS image and per-accumulator MFMA order as
 // conv3x3_tile_f16x3_kernel (kernels_conv.hip) - results are bitwise identical - but a 16x16 tile is worked on by 512

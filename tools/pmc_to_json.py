@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 PMC passes of tools/pmc_traffic.sh into profiles/r02_pmc.json: per-launch HBM bytes
+(FETCH_SIZE x2 [gfx950: 16 B/lane reads are tallied at half, MI355X_MICROARCH.md "HBM"] + WRITE_SIZE, both reported in KB)
+and matrix-pipe utilisation for the forward / data-gradient / weight-gradient launches of the decoder 3x3 conv, keyed by the
+bench.py category names, with the digest of the kernel sources they were measured on (bench.py quotes the numbers only while
+that digest matches the tree).
+
+    python tools/pmc_to_json.py gpurun_out/pmc_r02 [--config dsprites ...]
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def category(name):
+    if 'conv3x3_wgrad_f16x3_ws_kernel' in name or 'conv3x3_wgrad_f16x3_kernel' in name:
+        return 'conv_tile_wgrad'
+    if 'conv3x3_tile_f16x3_kernel' in name:
+        targs = name.split('<', 1)[1].split('>')[0].replace(' ', '').split(',')
+        if targs[0] != targs[1]:
+            return None
+        return 'conv_tile_fwd' if targs[2] == '0' else 'conv_tile_dgrad'
+    return None
+
+
+def per_launch(outdir, tag):
+    files = glob.glob(os.path.join(outdir, tag, '**', '*counter_collection.csv'), recursive=True)
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    names = {}
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            c = category(r['Kernel_Name'])
+            if c:
+                acc[c][r['Counter_Name']].append(float(r['Counter_Value']))
+                names[c] = r['Kernel_Name'][:120]
+    return acc, names
+
+
+def main():
+    outdir = sys.argv[1]
+    cfg = 'dsprites' if 'dsprites' in sys.argv[2:] else 'clevr6'
+    from iodine_amd.build import source_digest
+    try:
+        commit = subprocess.run(['git', 'rev-parse', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip() or 'unknown'
+    except Exception:
+        commit = 'unknown'
+    fetch, names = per_launch(outdir, 'FETCH_SIZE')
+    write, _ = per_launch(outdir, 'WRITE_SIZE')
+    mfma, _ = per_launch(outdir, 'SQ_VALU_MFMA_BUSY_CYCLES')
+    kernels = {}
+    for c in ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad'):
+        if c not in fetch or c not in write:
+            continue
+        f = fetch[c]['FETCH_SIZE']
+        w = write[c]['WRITE_SIZE']
+        fkb, wkb = sum(f) / len(f), sum(w) / len(w)
+        k = dict(kernel=names[c], launches_sampled=len(f), fetch_size_kb_raw=round(fkb, 1), write_size_kb=round(wkb, 1),
+                 hbm_bytes_per_launch=round((2.0 * fkb + wkb) * 1024.0))
+        if c in mfma and mfma[c].get('GRBM_GUI_ACTIVE'):
+            busy = sum(mfma[c]['SQ_VALU_MFMA_BUSY_CYCLES']) / len(mfma[c]['SQ_VALU_MFMA_BUSY_CYCLES'])
+            gui = sum(mfma[c]['GRBM_GUI_ACTIVE']) / len(mfma[c]['GRBM_GUI_ACTIVE'])
+            k['mfma_busy_cycles'] = round(busy)
+            k['grbm_gui_active'] = round(gui)
+            k['mfma_util'] = round(busy / (gui / 8.0 * 1024.0), 4)        # busy cycles / (cycles per XCD x 1024 SIMDs)
+        kernels[c] = k
+    rec = dict(commit=commit, csrc_sha256=source_digest(),
+               shape=dict(config=cfg, batch=32, slots=7 if cfg == 'clevr6' else 6),
+               method='rocprofv3 --pmc <one set per run> --kernel-trace over bench.py --steps 2 --warmup 1; '
+                      'hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (tools/pmc_traffic.sh)',
+               kernels=kernels)
+    path = os.path.join(ROOT, 'gpurun_out', 'r02_pmc.json')
+    json.dump(rec, open(path, 'w'), indent=1)
+    print(json.dumps(rec, indent=1))
+    print('wrote', path, '(copy to profiles/r02_pmc.json)')
+
+
+if __name__ == '__main__':
+    main()
