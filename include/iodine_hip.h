@@ -168,8 +168,9 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * "conv_precision" (3x3 convs of the decoder and refinement stacks: 0 = exact fp32 MFMA, 1 = fp32 operands split into
  * fp16 hi+lo, 3 fp16 MFMAs, fp32 accumulate -- default; only the selected path's weight packs are maintained, so a change
  * must be followed by iodine_set_params before the next compute call),
- * "conv_variant" (split-fp16 stride-1 conv: 1 = 16x16 tiles, one per 4-wave block, two blocks per CU -- default; 5 = 8x16
- * tiles, three blocks per CU; same results bit for bit),
+ * "conv_variant" (split-fp16 stride-1 conv C -> C of the decoder: 6 = weight-stationary persistent kernel, weights in registers
+ * -- default for power-of-two image sizes; 1 = LDS-tiled kernel, 16x16 tiles, two blocks per CU -- the fallback for other sizes;
+ * 5 = the LDS-tiled kernel on 8x16 tiles; like conv_precision a change must be followed by iodine_set_params),
  * "fuse_l0" (1 -- default: in iodine_reconstruct the last decoder data gradient reduces its result to the broadcast layer's
  * row sums in its epilogue instead of storing it; 0 = store and reduce in a second kernel, as the training path does),
  * "out_variant" (output conv forward: 1 = streaming kernel -- default, 0 = LDS-staged),

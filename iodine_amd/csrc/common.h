@@ -157,7 +157,7 @@ hipError_t launch_dec_l0_prepare(hipStream_t st, const float* w, const float* bi
                                  int S, float* wcls, float* wclsT, float* cmap);
 hipError_t launch_dec_v(hipStream_t st, const float* pm, const float* plv, const float* eps, const float* z_in,
                         const float* wcls, float* z_out, float* V, int N, int L, int C);
-hipError_t launch_dec_l0(hipStream_t st, const float* V, const float* cmap, float* out, int N, int S, int C);
+hipError_t launch_dec_l0(hipStream_t st, const float* V, const float* cmap, float* out, int N, int S, int C, float* tmax = nullptr);
 // slot groups of the fused layer-0 reduction (each at most 32 slots); Dpart holds l0_dgroups(N) * P * C floats
 inline int l0_dgroups(int N) { const int g = (N + 31) / 32; return g < 8 ? 8 : g; }
 // several small device-to-device copies in ONE launch (iodine_set_params: biases and raw weight copies)
@@ -227,11 +227,20 @@ hipError_t launch_ari_table(hipStream_t st, const float* mask, const unsigned ch
 hipError_t launch_pack_dec_out_gemm(hipStream_t st, const float* w, int C, float* meta, void* dst);
 hipError_t launch_pack_dec_out_dgrad(hipStream_t st, const float* w, int C, const float* meta, void* dst);
 hipError_t launch_dec_out_dgrad_f16x3(hipStream_t st, const float* g, const void* wpk, const float* wmeta, const float* aux,
-                                      float* out, int N, int S, int C);
+                                      float* out, int N, int S, int C, float* tmax = nullptr);
 hipError_t launch_dec_out_stream_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                        const float* bias, float* out, int N, int S, int C);
 hipError_t launch_dec_out_gemm_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                      const float* bias, float* out, int N, int S, int C);
+
+// kernels_convws.hip: weight-stationary split-fp16 3x3 conv C -> C (weights in registers, persistent blocks)
+hipError_t launch_pack_conv_weights_ws(hipStream_t st, const float* src, int C, int tflip, float* meta, void* dst);
+hipError_t launch_cell_max(hipStream_t st, const float* x, float* tmax, int N, int S, int C);
+hipError_t launch_conv3x3_ws_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
+                                   const float* aux, float* out, const float* tmax_in, float* tmax_out, int N, int S, int c,
+                                   int epi, int rev);
+inline size_t conv_ws_wpk_bytes(int C) { return (size_t)(C / 16) * (C / 32) * 9 * 2 * 64 * 16; }
+inline size_t conv_ws_tmax_floats(int N, int S) { return (size_t)N * (S / 16) * (S / 8) * 4; }
 
 // kernels_refine.hip: split-fp16 stride-2 convs of the refinement network
 hipError_t launch_conv3x3_s2_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,

@@ -41,6 +41,8 @@ struct Buffers {               // workspace carve-up for one batch size / mode
     double* part;
     std::vector<float*> act;                   // decoder activations a[0..Dd-1]   (N,P,Cd)
     float* dpre[2];                            // ping-pong gradient wrt pre-activations
+    std::vector<float*> tmax_act;              // per-cell max |act[l]| (4 floats per 8 x 16 cell): tile scales of the weight-stationary conv
+    float* tmax_dpre[2] = {nullptr, nullptr};  // the same for the two gradient buffers
     // per-iteration buffers: index i (training keeps all T(+1) copies, inference aliases them)
     std::vector<float*> z, g_pm, g_plv, latent, enc, pooled, u, gates, xin, h, c;
     std::vector<std::vector<float*>> ract;     // [iter][layer] refinement activations
@@ -80,13 +82,15 @@ struct iodine_handle {
     float *wcls = nullptr, *wclsT = nullptr, *cmap = nullptr;
     std::vector<float*> dec_wf, dec_wb, dec_b;  // packed fwd / dgrad weights + bias copies for layers 1..Dd-1
     std::vector<float*> dec_wf16, dec_wb16, dec_wmeta;   // split-fp16 packs (+ {scale, 1/scale, scale_b, 1/scale_b})
+    std::vector<float*> dec_wsf, dec_wsb;                // the same weights in the register layout of the weight-stationary conv
     int precision = 1;                          // 0: exact fp32 MFMA, 1: 3 x fp16 MFMA split (fp32-class accuracy)
     int wgrad_ws = 2;                           // decoder 64->64 weight gradient: 0 one-role kernel, 1 warp-specialised (transposing stagers + v_alignbit), 2 warp-specialised with ds_read_b64_tr_b16
     int out_dgrad_variant = 1;                  // output conv data gradient: 1 = split-fp16 streaming kernel, 0 = generic fp32 tile kernel
     int fuse_l0 = 1;                            // inference: layer-1 data gradient reduces straight to the layer-0 row sums
     int out_variant = 1;                        // output conv forward: 1 = streaming (fragments straight from global), 0 = LDS-staged
     int zigzag = 1;                             // odd decoder layers walk the tiles backwards (Infinity Cache reuse)
-    int variant = 1;                            // split-fp16 tile conv: 1 = 16x16 tiles (2 blocks/CU), 5 = 8x16 tiles (3 blocks/CU)
+    int variant = 6;                            // split-fp16 stride-1 conv: 6 = weight-stationary persistent kernel (power-of-two image sizes;
+                                                // other sizes use 1), 1 = LDS-tiled 16x16 tiles (2 blocks/CU), 5 = the same on 8x16 tiles
     float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr, *dec_out_w16 = nullptr, *dec_out_meta = nullptr,
           *dec_out_wb16 = nullptr;               // split-fp16 pack of the output conv for its data gradient
     std::vector<float*> ref_w, ref_b;
@@ -125,8 +129,9 @@ int g_iod_xskip = 0;
 
 namespace {
 
-hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, const void* wpk, const float* wmeta,
-                      const float* bias, const float* aux, float* out, int N, int S, int cin, int cout, int epi, int layer);
+hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, const void* wpk, const void* wpk_ws,
+                      const float* wmeta, const float* bias, const float* aux, float* out, const float* tmax_in, float* tmax_out,
+                      int N, int S, int cin, int cout, int epi, int layer);
 
 #define HIPCHK(h, expr)                                                                          \
     do {                                                                                         \
@@ -154,9 +159,15 @@ hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, c
         if (e1_) HIPCHK(h, hipEventRecord(e1_, st));                                 \
     } while (0)
 
-hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, const void* wpk, const float* wmeta,
-                      const float* bias, const float* aux, float* out, int N, int S, int cin, int cout, int epi, int layer)
+bool conv_ws_ok(const iodine_handle* h) { return h->variant == 6 && h->precision == 1 && h->S >= 16 && (h->S & (h->S - 1)) == 0; }
+
+hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, const void* wpk, const void* wpk_ws,
+                      const float* wmeta, const float* bias, const float* aux, float* out, const float* tmax_in, float* tmax_out,
+                      int N, int S, int cin, int cout, int epi, int layer)
 {
+    if (conv_ws_ok(h) && cin == cout)
+        return launch_conv3x3_ws_f16x3(st, in, wpk_ws, wmeta, bias, aux, out, tmax_in, tmax_out, N, S, cout, epi,
+                                       h->zigzag ? (layer & 1) : 0);
     // zig-zag: odd decoder layers walk the slot-images backwards (forward pass: l0 writes forwards, layer 1 reads
     // backwards, layer 2 forwards, ...; backward pass the same by layer), so a launch starts on the part of its input
     // that the previous launch wrote last - still in the 256 MiB Infinity Cache - instead of the part written first.
@@ -268,6 +279,10 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
     for (int l = 0; l < h->Dd; ++l) b.act[l] = a.take<float>((size_t)N * P * Cd);
     b.dpre[0] = a.take<float>((size_t)N * P * Cd);
     b.dpre[1] = a.take<float>((size_t)N * P * Cd);
+    b.tmax_act.resize(h->Dd);
+    for (int l = 0; l < h->Dd; ++l) b.tmax_act[l] = a.take<float>(conv_ws_tmax_floats(N, h->S));
+    b.tmax_dpre[0] = a.take<float>(conv_ws_tmax_floats(N, h->S));
+    b.tmax_dpre[1] = a.take<float>(conv_ws_tmax_floats(N, h->S));
     const int ncopy = mode == 1 ? T + 1 : 1;
     auto per_iter = [&](std::vector<float*>& v, size_t n, int copies) {
         v.resize(T + 1);
@@ -367,11 +382,13 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N, float* out = nullpt
 {
     Buffers& b = h->buf;
     if (!out) out = b.dec_out;
-    PROF(h, st, "dec_l0", launch_dec_l0(st, b.V, h->cmap, b.act[0], N, h->S, h->Cd));
+    const bool ws = conv_ws_ok(h);
+    PROF(h, st, "dec_l0", launch_dec_l0(st, b.V, h->cmap, b.act[0], N, h->S, h->Cd, ws ? b.tmax_act[0] : nullptr));
     for (int l = 1; l < h->Dd; ++l) {
         if (h->precision == 1)
-            PROF(h, st, "conv_tile_fwd", conv_f16x3(h, st, b.act[l - 1], h->dec_wf16[l], h->dec_wmeta[l], h->dec_b[l],
-                                                    nullptr, b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU, l));
+            PROF(h, st, "conv_tile_fwd", conv_f16x3(h, st, b.act[l - 1], h->dec_wf16[l], h->dec_wsf[l], h->dec_wmeta[l], h->dec_b[l],
+                                                    nullptr, b.act[l], b.tmax_act[l - 1], b.tmax_act[l], N, h->S, h->Cd, h->Cd,
+                                                    EPI_BIAS_ELU, l));
         else
             PROF(h, st, "conv_tile_fwd", launch_conv3x3_tile(st, b.act[l - 1], h->dec_wf[l], h->dec_b[l], nullptr,
                                                              b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
@@ -410,7 +427,7 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
     {
         if (h->precision == 1 && h->out_dgrad_variant)
             PROF(h, st, "dec_out_dgrad", launch_dec_out_dgrad_f16x3(st, b.g, h->dec_out_wb16, h->dec_out_meta, b.act[Dd - 1],
-                                                                     b.dpre[cur], N, h->S, Cd));
+                                                                     b.dpre[cur], N, h->S, Cd, conv_ws_ok(h) ? b.tmax_dpre[cur] : nullptr));
         else
             PROF(h, st, "dec_out_dgrad", launch_conv3x3_tile(st, b.g, h->dec_out_wb, nullptr, b.act[Dd - 1], b.dpre[cur], N,
                                                              h->S, 4, Cd, EPI_MUL_ELUGRAD));
@@ -447,10 +464,11 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         }
         // Inference: nothing but the broadcast layer's row / class sums needs d(pre-activation 0), so the last data gradient
         // reduces its tile to per-row sums in its epilogue (EPI_L0ROWS) and the 0.94 GB tensor is neither written nor re-read.
-        fused_l0 = l == 1 && train_alpha == 0.f && h->precision == 1 && (h->variant == 1 || h->variant == 5) && h->fuse_l0;
+        fused_l0 = l == 1 && train_alpha == 0.f && h->precision == 1 && h->fuse_l0;
         if (h->precision == 1)
-            PROF(h, st, "conv_tile_dgrad", conv_f16x3(h, st, b.dpre[cur], h->dec_wb16[l], h->dec_wmeta[l] + 2, nullptr,
-                                                      b.act[l - 1], fused_l0 ? b.rows_p : b.dpre[cur ^ 1], N, h->S, Cd, Cd,
+            PROF(h, st, "conv_tile_dgrad", conv_f16x3(h, st, b.dpre[cur], h->dec_wb16[l], h->dec_wsb[l], h->dec_wmeta[l] + 2, nullptr,
+                                                      b.act[l - 1], fused_l0 ? b.rows_p : b.dpre[cur ^ 1], b.tmax_dpre[cur],
+                                                      b.tmax_dpre[cur ^ 1], N, h->S, Cd, Cd,
                                                       fused_l0 ? EPI_L0ROWS : EPI_MUL_ELUGRAD, l));
         else
             PROF(h, st, "conv_tile_dgrad", launch_conv3x3_tile(st, b.dpre[cur], h->dec_wb[l], nullptr, b.act[l - 1],
@@ -637,7 +655,10 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     ALLOC(h->cmap, (size_t)h->P * Cd);
     h->dec_wf.assign(h->Dd, nullptr); h->dec_wb.assign(h->Dd, nullptr); h->dec_b.assign(h->Dd, nullptr);
     h->dec_wf16.assign(h->Dd, nullptr); h->dec_wb16.assign(h->Dd, nullptr); h->dec_wmeta.assign(h->Dd, nullptr);
+    h->dec_wsf.assign(h->Dd, nullptr); h->dec_wsb.assign(h->Dd, nullptr);
     for (int l = 1; l < h->Dd; ++l) {
+        ALLOC(h->dec_wsf[l], conv_ws_wpk_bytes(Cd) / 4);
+        ALLOC(h->dec_wsb[l], conv_ws_wpk_bytes(Cd) / 4);
         ALLOC(h->dec_wf[l], conv_wpk_elems(Cd, Cd) * 4);
         ALLOC(h->dec_wb[l], conv_wpk_elems(Cd, Cd) * 4);
         ALLOC(h->dec_b[l], (size_t)Cd);
@@ -741,8 +762,14 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
             HIPCHK(h, launch_pack_conv_weights(st, w, Cd, Cd, Cd, Cd, 0, h->dec_wf[l]));
             HIPCHK(h, launch_pack_conv_weights(st, w, Cd, Cd, Cd, Cd, 1, h->dec_wb[l]));
         }
-        HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cd, Cd, Cd, Cd, 0, h->dec_wmeta[l], h->dec_wf16[l]));
-        HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cd, Cd, Cd, Cd, 1, h->dec_wmeta[l] + 2, h->dec_wb16[l]));
+        // only the selected kernel's packs are maintained (a change of conv_variant / conv_precision invalidates the parameters)
+        if (conv_ws_ok(h)) {                                   // weight-stationary register layout
+            HIPCHK(h, launch_pack_conv_weights_ws(st, w, Cd, 0, h->dec_wmeta[l], h->dec_wsf[l]));
+            HIPCHK(h, launch_pack_conv_weights_ws(st, w, Cd, 1, h->dec_wmeta[l] + 2, h->dec_wsb[l]));
+        } else {
+            HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cd, Cd, Cd, Cd, 0, h->dec_wmeta[l], h->dec_wf16[l]));
+            HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cd, Cd, Cd, Cd, 1, h->dec_wmeta[l] + 2, h->dec_wb16[l]));
+        }
         HIPCHK(h, queue_copy(h->dec_b[l], P("decoder.mlc.layers." + std::to_string(l) + ".bias"), Cd));
     }
     HIPCHK(h, launch_pack_dec_out(st, P("decoder.conv.weight"), h->dec_out_w, Cd));
@@ -829,7 +856,8 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "out_variant")) { h->out_variant = value != 0; return IODINE_OK; }
     if (!strcmp(key, "zigzag")) { h->zigzag = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {
-        if (value != 1 && value != 5) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1 or 5");
+        if (value != 1 && value != 5 && value != 6) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1, 5 or 6");
+        if (((int)value == 6) != (h->variant == 6)) h->params_set = false;   // the other kernel's weight packs are not kept up to date
         h->variant = (int)value;
         return IODINE_OK;
     }
@@ -1259,6 +1287,21 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, c
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
         (void)hipFree(wpk);
         if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(s2 f16x3): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
+        return IODINE_OK;
+    }
+    if (mode == 9 || mode == 10) {  // weight-stationary split-fp16 kernel (per-cell max side buffer from launch_cell_max)
+        if (cin_pad != cout || w_o != cout || w_i != cout || ih != iw || ih % 16 != 0) { g_create_error = "iodine_op_conv3x3(ws): shape"; return IODINE_ERR_INVALID; }
+        const size_t wb = conv_ws_wpk_bytes(cout), tf = conv_ws_tmax_floats(n, ih);
+        char* buf = nullptr;
+        if (hipMalloc((void**)&buf, wb + 64 + 2 * tf * sizeof(float)) != hipSuccess) return IODINE_ERR_HIP;
+        float* meta = (float*)(buf + wb);
+        float *tin = (float*)(buf + wb + 64), *tout = tin + tf;
+        hipError_t e2 = launch_pack_conv_weights_ws(st, w, cout, tflip, meta, buf);
+        if (e2 == hipSuccess) e2 = launch_cell_max(st, in, tin, n, ih, cout);
+        if (e2 == hipSuccess) e2 = launch_conv3x3_ws_f16x3(st, in, buf, meta, bias, aux, out, tin, tout, n, ih, cout, epi, 0);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+        (void)hipFree(buf);
+        if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(ws): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
         return IODINE_OK;
     }
     if (mode == 2 || mode == 8) {   // split-fp16 tile kernel (8 = 8x16 tiles)

@@ -157,9 +157,44 @@ void dec_l0_kernel(const float4* __restrict__ V, const float4* __restrict__ cmap
     }
 }
 
-hipError_t launch_dec_l0(hipStream_t st, const float* V, const float* cmap, float* out, int N, int S, int C)
+// The same with one block per 8 x 16 CELL of a slot-image (16 pixels x C floats = one contiguous run per row), which also
+// leaves the cell's max |act0| in the side buffer the weight-stationary conv reads its tile scale from (tmax[n][cell][4]).
+template <int C4>
+__global__ __launch_bounds__(256)
+void dec_l0_cells_kernel(const float4* __restrict__ V, const float4* __restrict__ cmap, float4* __restrict__ out,
+                         float* __restrict__ tmax, int S)
+{
+    const int cells_x = S >> 4;
+    const int cx = blockIdx.x % cells_x, cy = blockIdx.x / cells_x, n = blockIdx.y;
+    const float4* Vn = V + (size_t)n * 9 * C4;
+    float4* on = out + (size_t)n * S * S * C4;
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < 128 * C4 / 256; ++k) {
+        const int i = threadIdx.x + k * 256;
+        const int px = i / C4, c4 = i % C4;
+        const int y = cy * 8 + (px >> 4), x = cx * 16 + (px & 15);
+        const int cls = (y == 0 ? 0 : (y == S - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x == S - 1 ? 2 : 1));
+        const int gi = (y * S + x) * C4 + c4;
+        const float4 v = Vn[cls * C4 + c4];
+        const float4 m = cmap[gi];
+        const float4 o = make_float4(elu1_fast(v.x + m.x), elu1_fast(v.y + m.y), elu1_fast(v.z + m.z), elu1_fast(v.w + m.w));
+        on[gi] = o;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+    }
+    mx = wave_max_f32(mx);
+    if ((threadIdx.x & 63) == 0) tmax[((size_t)n * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = mx;
+}
+
+hipError_t launch_dec_l0(hipStream_t st, const float* V, const float* cmap, float* out, int N, int S, int C, float* tmax)
 {
     IOD_XSKIP(16);
+    if (tmax && S % 16 == 0 && (C == 64 || C == 32)) {
+        const dim3 grid((S / 16) * (S / 8), N);
+        if (C == 64) hipLaunchKernelGGL(dec_l0_cells_kernel<16>, grid, dim3(256), 0, st, (const float4*)V, (const float4*)cmap, (float4*)out, tmax, S);
+        else hipLaunchKernelGGL(dec_l0_cells_kernel<8>, grid, dim3(256), 0, st, (const float4*)V, (const float4*)cmap, (float4*)out, tmax, S);
+        return hipGetLastError();
+    }
     const int pc4 = S * S * (C / 4);
     hipLaunchKernelGGL(dec_l0_kernel, dim3((pc4 + 1023) / 1024, N), dim3(256), 0, st, (const float4*)V,
                        (const float4*)cmap, (float4*)out, S, C / 4, pc4);

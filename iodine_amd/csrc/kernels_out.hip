@@ -221,7 +221,7 @@ hipError_t launch_pack_dec_out_dgrad(hipStream_t st, const float* w, int C, cons
 template <int C>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void dec_out_dgrad_f16x3_kernel(const float4* __restrict__ g, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
-                                const float* __restrict__ aux, float* __restrict__ out, int S, int tiles)
+                                const float* __restrict__ aux, float* __restrict__ out, float* __restrict__ tmax, int S, int tiles)
 {
     constexpr int NT = C / 32;
     constexpr int HALO = 18, NPX = HALO * HALO;
@@ -272,6 +272,7 @@ void dec_out_dgrad_f16x3_kernel(const float4* __restrict__ g, const uint4* __res
     const float inv = wmeta[1] / scale;
 
     unsigned char* ep = s_ep + wv * 32 * EPS;
+    float omax = 0.f;                                               // max |output| of this wave's four tile rows
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         // accumulators of this half tile: rows = channels (weights are the first MFMA operand), columns = 32 pixels
@@ -321,27 +322,34 @@ void dec_out_dgrad_f16x3_kernel(const float4* __restrict__ g, const uint4* __res
             const f32x4 a4 = ax[mt][j];
             v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
             v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
+            omax = fmaxf(omax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
             *reinterpret_cast<f32x4*>(out_n + ((size_t)gy * S + gx) * C + seg * 4) = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    if (tmax) {
+        // side buffer for the weight-stationary conv that consumes `out`: max |x| per 8 x 16 cell, 4 floats per cell; the
+        // 16 x 16 tile is two cells (waves 0, 1 / 2, 3), each wave fills two of its cell's four slots
+        omax = wave_max_f32(omax);
+        if (lane < 2) tmax[(((size_t)n * 2 * tiles + 2 * ty + (wv >> 1)) * tiles + tx) * 4 + 2 * (wv & 1) + lane] = omax;
+    }
 }
 
 hipError_t launch_dec_out_dgrad_f16x3(hipStream_t st, const float* g, const void* wpk, const float* wmeta, const float* aux,
-                                      float* out, int N, int S, int C)
+                                      float* out, int N, int S, int C, float* tmax)
 {
     if (S % 16 != 0) return hipErrorInvalidValue;
     const int tiles = S / 16;
     if (C == 64) {
         constexpr size_t lds = (size_t)324 * 16 + 3 * 2 * 2 * 64 * 16 + 16 + 4 * 32 * (64 + 4) * 4;
         hipLaunchKernelGGL((dec_out_dgrad_f16x3_kernel<64>), dim3(N * tiles * tiles), dim3(256), lds, st, (const float4*)g,
-                           (const uint4*)wpk, wmeta, aux, out, S, tiles);
+                           (const uint4*)wpk, wmeta, aux, out, tmax, S, tiles);
     } else if (C == 32) {
         constexpr size_t lds = (size_t)324 * 16 + 3 * 2 * 2 * 32 * 16 + 16 + 4 * 32 * (32 + 4) * 4;
         hipLaunchKernelGGL((dec_out_dgrad_f16x3_kernel<32>), dim3(N * tiles * tiles), dim3(256), lds, st, (const float4*)g,
-                           (const uint4*)wpk, wmeta, aux, out, S, tiles);
+                           (const uint4*)wpk, wmeta, aux, out, tmax, S, tiles);
     } else {
         return hipErrorInvalidValue;
     }

@@ -37,8 +37,12 @@ def train(model, optimizer, dataloader, device, max_steps, print_every=10, check
     """train.py:44-108: loss = model(data); loss.mean(); zero_grad; backward; [all-reduce]; step.  Returns the losses."""
     model.train()
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-    losses, step = [], 0
+    losses, step, epoch = [], 0, 0
     while step < max_steps:
+        sampler = getattr(dataloader, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):
+            sampler.set_epoch(epoch)                                         # a new shuffle per pass over the data
+        epoch += 1
         for data in dataloader:
             start = time.perf_counter()
             x = data[0].to(device, non_blocking=True)                        # "first one is image" (train.py:49)
@@ -61,13 +65,26 @@ def train(model, optimizer, dataloader, device, max_steps, print_every=10, check
 
 
 def evaluate(model, dataloader, device, evaluator=None):
-    """eval.py:14-28 with the ARI evaluator of lib/eval/ari_eval.py (works under no_grad, unlike the reference)."""
+    """eval.py:14-28 with the ARI evaluator of lib/eval/ari_eval.py (works under no_grad, unlike the reference).  With
+    several ranks every rank evaluates its shard; the samples DistributedSampler appended to pad the shards to equal length
+    are dropped (they duplicate the first images) and ``evaluator.global_mean`` holds the ARI over the whole dataset."""
     evaluator = evaluator or ARIEvaluator()
     evaluator.reset()
     model.eval()
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    world = torch.distributed.get_world_size() if dist_on else 1
+    rank = torch.distributed.get_rank() if dist_on else 0
+    n_total = len(dataloader.dataset)
+    mine = len(range(rank, n_total, world)) if world > 1 else n_total       # un-padded share of this rank (sampler stride = world)
     with torch.no_grad():
         for image, masks in dataloader:
             evaluator.evaluate(model, (image.to(device), [m.numpy() for m in masks]))
+    del evaluator.aris[mine:]
+    stats = torch.tensor([float(sum(evaluator.aris)), float(len(evaluator.aris))], dtype=torch.float64,
+                         device=device if dist_on and torch.distributed.get_backend() == 'nccl' else 'cpu')
+    if world > 1:
+        torch.distributed.all_reduce(stats)
+    evaluator.global_mean = float(stats[0] / stats[1]) if float(stats[1]) > 0 else 0.0
     return evaluator
 
 
@@ -93,6 +110,7 @@ def main(argv=None):
     arch = clevr6_arch() if args.config == 'clevr6' else dsprites_arch()
     torch.manual_seed(0)                                                     # same initial replica on every rank
     model = IODINE(arch).to(device)
+    model.manual_seed(1000 + rank)                                           # ... but its own reparameterisation noise
     optimizer = make_optimizer(model, base_lr=args.lr)
     if args.resume:
         load_checkpoint(args.resume, model, optimizer)
@@ -107,7 +125,7 @@ def main(argv=None):
                    log=print if rank == 0 else (lambda *a: None))
     ev = evaluate(model, make_dataloader(ds, args.batch, shuffle=False, rank=rank, world_size=world), device)
     if rank == 0:
-        print('first loss {:.2f} -> last loss {:.2f}; {}'.format(losses[0], losses[-1], ev.get_results()))
+        print('first loss {:.2f} -> last loss {:.2f}; Ari over all ranks: {}'.format(losses[0], losses[-1], ev.global_mean))
 
 
 if __name__ == '__main__':

@@ -300,7 +300,7 @@ class IODINE(nn.Module):
         self._options[key] = float(value)
         if self._handle is not None:
             _lib.check(_lib.lib().iodine_set_option(self._handle, key.encode(), float(value)), self._handle)
-        if key == 'conv_precision':
+        if key in ('conv_precision', 'conv_variant'):
             self._param_versions = None          # the library keeps only the selected path's weight packs: re-send the parameters
 
     def profile_read(self, category: str, reset: bool = True):

@@ -1,4 +1,5 @@
-"""Parity at BASELINE.json's full sizes (cfg3: CLEVR6 arch, K=7, T=5, B=32; cfg5 per-GPU shard: K=11, T=7, B=8), where
+"""Parity at BASELINE.json's full sizes (cfg2: dSprites arch, K=6, T=5, B=32; cfg3: CLEVR6 arch, K=7, T=5, B=32; cfg5
+per-GPU shard: K=11, T=7, B=8), where
 the CPU oracle takes minutes per step: size-independent properties chain the full batch to cases the reference pinned.
 
   1. image independence: every image's outputs in the full batch are BITWISE those of a
@@ -31,11 +32,18 @@ def _full_batch(case, B):
     imgs = imgs[0] if kind == 'blobs' else imgs
     eps = synth.make_eps(arch.iters, B, arch.slots, arch.dim_latent, seed=se)
     x, eps = torch.from_numpy(imgs), torch.from_numpy(eps)
-    assert torch.equal(x[:1], x1[:1]) and torch.equal(eps[:, :1], eps1[:, :1])
+    gB = x1.shape[0]                                                       # batch of the golden case: its images lead the batch
+    assert torch.equal(x[:gB], x1) and torch.equal(eps[:, :gB], eps1)
+    if case.startswith('cfg2'):
+        # uniform-noise images are far from anything the dSprites decoder predicts: a third of them run into the 0/0 of the
+        # reference's un-stabilised mask posterior (iodine.py:286-293; the HIP path and the oracle go NaN at the same
+        # iteration - tests/test_gpu_boundary.py covers that edge).  The batch-mean identities below need finite images:
+        # lower the contrast of the images that are not part of the golden case.
+        x[gB:] = 0.5 + 0.35 * (x[gB:] - 0.5)
     return g, arch, params, x, eps
 
 
-@pytest.mark.parametrize('case,B', [('cfg3_clevr_k7_t5_b1', 32), ('cfg5_clevr_k11_t7_b1', 8)])
+@pytest.mark.parametrize('case,B', [('cfg3_clevr_k7_t5_b1', 32), ('cfg5_clevr_k11_t7_b1', 8), ('cfg2_dsprites_k6_t5_b2', 32)])
 def test_full_size_reconstruct(case, B):
     g, arch, params, x, eps = _full_batch(case, B)
     m = make_hip_model(arch, params)
@@ -52,12 +60,13 @@ def test_full_size_reconstruct(case, B):
         assert torch.equal(p, pred[b:b + 1]) and torch.equal(k, mask[b:b + 1]) and torch.equal(mm, mean[b:b + 1]), b
         singles.append(m.elbo_terms.clone())
     assert rel_err(torch.stack(singles).double().mean(0).cpu(), full.double().cpu()) < 1e-6
-    # image 0 == the reference-generated golden case
-    e0 = singles[0][:, 0].cpu().numpy()
+    # the leading image(s) == the reference-generated golden case (its ELBOs are the mean over its batch)
+    gB = int(g['meta_B'])
+    e0 = torch.stack(singles[:gB])[:, :, 0].double().mean(0).cpu().numpy()
     assert (np.abs(e0 - g['f32.recon.elbos']) / np.abs(g['f32.recon.elbos'])).max() < 1e-4
-    a = pred[0].double().cpu().flatten()
+    a = pred[:gB].double().cpu().flatten()
     assert abs(float((a * a).sum()) - float(g['f32.recon.pred.sumsq'])) <= 1e-4 * float(g['f32.recon.pred.sumsq'])
-    assert (mask[0, :, 0].argmax(dim=0).cpu().numpy() == g['f32.recon.argmax'][0]).mean() >= 0.999
+    assert (mask[:gB, :, 0].argmax(dim=1).cpu().numpy() == g['f32.recon.argmax']).mean() >= 0.999
     # another image through the CPU oracle
     b = B - 3
     ref = O.reconstruct(x[b:b + 1], eps[:, b:b + 1], params, arch)
@@ -77,7 +86,7 @@ def _train(m, x, eps):
     return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}
 
 
-@pytest.mark.parametrize('case,B', [('cfg3_clevr_k7_t5_b1', 32), ('cfg5_clevr_k11_t7_b1', 8)])
+@pytest.mark.parametrize('case,B', [('cfg3_clevr_k7_t5_b1', 32), ('cfg5_clevr_k11_t7_b1', 8), ('cfg2_dsprites_k6_t5_b2', 32)])
 def test_full_size_train_step(case, B):
     g, arch, params, x, eps = _full_batch(case, B)
     m = make_hip_model(arch, params)
@@ -88,6 +97,7 @@ def test_full_size_train_step(case, B):
     assert torch.equal(loss, loss2) and all(torch.equal(grads[n], grads2[n]) for n in grads)
     # the batch step is the mean of the single-image steps (loss is a batch mean of per-image sums, iodine.py:193,220)
     lsum, gsum, esum = 0.0, {n: torch.zeros_like(v, dtype=torch.float64) for n, v in grads.items()}, 0.0
+    gB = int(g['meta_B'])
     first = None
     for b in range(B):
         l1, g1 = _train(m, xd[b:b + 1], ed[:, b:b + 1].contiguous())
@@ -95,14 +105,14 @@ def test_full_size_train_step(case, B):
         esum = esum + m.elbo_terms[:, 0].double()
         for n in gsum:
             gsum[n] += g1[n].double()
-        if b == 0:
-            first = (l1, g1)
+        if b == gB - 1:                                                    # mean over the golden case's images so far
+            first = ((lsum / gB).clone(), {n: (v / gB).clone() for n, v in gsum.items()})
     assert abs((lsum / B - loss.double()).item()) <= 1e-6 * abs(loss.item())
     assert rel_err((esum / B).cpu(), elbos.double().cpu()) < 1e-6
     bad = [(n, rel_l2(grads[n].cpu().numpy(), (gsum[n] / B).cpu().numpy())) for n in grads
            if not rel_l2(grads[n].cpu().numpy(), (gsum[n] / B).cpu().numpy()) < 2e-5]
     assert not bad, bad
-    # image 0 == the reference-generated golden case (fp64 reference gradients)
+    # the leading image(s) == the reference-generated golden case (fp64 reference gradients)
     l0, g0 = first
     assert abs(l0.item() - float(g['f32.train.loss'])) <= 1e-4 * abs(float(g['f32.train.loss']))
     for n, a in g0.items():

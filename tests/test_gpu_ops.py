@@ -108,6 +108,36 @@ def test_conv_tile_f16x3_forward_and_dgrad(C_, S, N, mode):
         assert torch.equal(gotd, _conv_op(2, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 1, 1, nhwc(refd).shape))
 
 
+@pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 2), (64, 128, 2), (64, 16, 300), (32, 64, 9), (32, 32, 70)])
+def test_conv_weight_stationary_f16x3(C_, S, N):
+    """the weight-stationary persistent kernel (op mode 10: weights in registers, per-cell max side buffer, whole-pixel
+    epilogue through LDS): forward + bias + ELU, data gradient x ELU', and the EPI_L0ROWS form that reduces the data gradient
+    to per-row left / interior / right sums"""
+    x = _rand(N, C_, S, S, seed=21)
+    w = _rand(C_, C_, 3, 3, seed=22, scale=3.0 / (C_ * 9) ** 0.5)
+    b = _rand(C_, seed=23, scale=0.5)
+    ref = nhwc(F.elu(F.conv2d(x.double(), w.double(), b.double(), padding=1))).float()
+    got = _conv_op(10, nhwc(x), w, b, None, N, S, S, C_, C_, C_, C_, 1, 0, 0, ref.shape)
+    assert rel_err(got, ref) < 3e-6, rel_err(got, ref)
+    g = _rand(N, C_, S, S, seed=24, scale=1e-3)                  # small-magnitude gradients
+    g[N // 2:] *= 1e-4                                           # ... and tiles with very different ranges in one launch
+    a = F.elu(_rand(N, C_, S, S, seed=25, scale=2.0))
+    refd = nhwc((F.conv_transpose2d(g.double(), w.double(), padding=1) * torch.where(a > 0, torch.ones_like(a), a + 1).double()).float())
+    gotd = _conv_op(10, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 1, 1, refd.shape)
+    for half in (slice(0, N // 2), slice(N // 2, N)):
+        assert rel_err(gotd[half], refd[half]) < 3e-6, rel_err(gotd[half], refd[half])
+    tiles = S // 16
+    rows = _conv_op(10, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 4, 1, (N, S, tiles, 3, C_))
+    r = refd.view(N, S, tiles, 16, C_).double()
+    want = torch.zeros(N, S, tiles, 3, C_, dtype=torch.float64)
+    want[:, :, :, 1] = r.sum(3)
+    want[:, :, 0, 0] = r[:, :, 0, 0]; want[:, :, 0, 1] -= r[:, :, 0, 0]
+    want[:, :, -1, 2] = r[:, :, -1, 15]; want[:, :, -1, 1] -= r[:, :, -1, 15]
+    for half in (slice(0, N // 2), slice(N // 2, N)):
+        assert rel_err(rows[half], want[half].float()) < 5e-6, rel_err(rows[half], want[half].float())
+    assert torch.equal(gotd, _conv_op(10, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 1, 1, refd.shape))   # deterministic
+
+
 @pytest.mark.parametrize('cin,cpad,cout,S,N', [(17, 20, 64, 32, 3), (64, 64, 64, 16, 5), (17, 20, 32, 16, 2),
                                                 (32, 32, 32, 8, 7), (64, 64, 64, 128, 1), (32, 32, 32, 4, 3),
                                                 (17, 20, 64, 128, 2), (64, 64, 64, 64, 9)])
