@@ -372,6 +372,13 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
         if (hwid & 1u) __builtin_amdgcn_s_setprio(WS_ROLEPRIO);
     }
 #endif
+#ifndef WS_ALTPRIO
+#define WS_ALTPRIO 2
+#endif
+#if WS_ALTPRIO > 0
+    unsigned role;
+    { unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); role = hwid & 1u; }
+#endif
     TP_DECL;
     // ---- prologue: stage 0 into buffer 0, stage 1 in flight ----
     issue_stage(0);
@@ -385,6 +392,11 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
     __builtin_amdgcn_s_setprio(WS_PRIO);
 #endif
     for (int s0 = 0; s0 < nstage; s0 += NCHUNK) {
+#if WS_ALTPRIO > 0
+        // the older of the two waves of a SIMD wins every arbitration and runs ~1.5x faster than its partner (56 vs 37 tiles in
+        // the same time, then a long tail alone): swap the favoured role every WS_ALTPRIO tiles so that both progress alike
+        if ((((unsigned)(s0 / NCHUNK) / WS_ALTPRIO) ^ role) & 1u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
         const int t = t0 + (s0 / NCHUNK) * bpx;
         int n, ty, tx;
         tile_coords(t, n, ty, tx);
@@ -426,19 +438,31 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
             // chunk was read from: every wave must be done reading it (barrier), and the next stage's hooks write it again only
             // behind the next stage barrier.
             unsigned char* sb = smem_b + ((s0 + NCHUNK - 1) & 1) * BUFB;
+            const int seg = lane % SEGS, pl = lane / SEGS;
+            // wave wv moves tile rows 2 wv, 2 wv + 1: instruction j = pixels j * PPI .. of those 32
+            const unsigned vbase = (unsigned)(((((ty * 8 + 2 * wv) << lgS) + tx * 16 + pl) * C + seg * 4) * 4);
+            f32x4 ax[EPI == EPI_MUL_ELUGRAD ? NEP : 1];
+            if constexpr (EPI == EPI_MUL_ELUGRAD) {
+                // the ELU' operand (whole pixels, like the stores) is requested before the barriers: in the training step it
+                // comes from HBM, not from a cache
+                // (first half now - the fragment registers are free -, second half once the accumulators are in LDS)
+                const i32x4_ rsrc_aux = make_rsrc(aux + (size_t)n * S * S * C, (unsigned)(S * S * C * 4));
+#pragma unroll
+                for (int j = 0; j < NEP / 2; ++j) {
+                    const int soff = ((((j * PPI) / 16) << lgS) + (j * PPI) % 16) * C * 4;
+                    WS_SGPR_SETTLE(rsrc_aux, soff);
+                    WS_BLOAD4(ax[j], vbase, rsrc_aux, soff);
+                }
+            }
             __syncthreads();
             TP_STAMP(3);                                     // [3] barrier (tile buffer free)
 #pragma unroll
             for (int y = 0; y < RW; ++y)
                 *reinterpret_cast<f32x4*>(sb + ((pg * RW + y) * 16 + lpx) * EPS + (16 * cg + 4 * lkb) * 4) = acc[y] * inv;
-            const int seg = lane % SEGS, pl = lane / SEGS;
-            // wave wv moves tile rows 2 wv, 2 wv + 1: instruction j = pixels j * PPI .. of those 32
-            const unsigned vbase = (unsigned)(((((ty * 8 + 2 * wv) << lgS) + tx * 16 + pl) * C + seg * 4) * 4);
-            f32x4 ax[EPI == EPI_MUL_ELUGRAD ? NEP : 1];
-            if constexpr (EPI == EPI_MUL_ELUGRAD) {          // the accumulator registers are free now: fetch the ELU' operand
+            if constexpr (EPI == EPI_MUL_ELUGRAD) {
                 const i32x4_ rsrc_aux = make_rsrc(aux + (size_t)n * S * S * C, (unsigned)(S * S * C * 4));
 #pragma unroll
-                for (int j = 0; j < NEP; ++j) {
+                for (int j = NEP / 2; j < NEP; ++j) {
                     const int soff = ((((j * PPI) / 16) << lgS) + (j * PPI) % 16) * C * 4;
                     WS_SGPR_SETTLE(rsrc_aux, soff);
                     WS_BLOAD4(ax[j], vbase, rsrc_aux, soff);
@@ -453,10 +477,20 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
             TP_STAMP(4);                                     // [4] tile -> LDS + barrier
             float vmax = 0.f;
             const unsigned char* sr = sb + ((2 * wv) * 16 + pl) * EPS + seg * 16;
+            // all LDS reads first (the asm stores below are memory barriers for the compiler: interleaved with them every
+            // read would be issued, and waited for, on its own)
+            // (data-gradient form: in two batches - the ELU' operand occupies NEP float4s of its own)
+            constexpr int PB = EPI == EPI_MUL_ELUGRAD ? NEP / 2 : NEP;
+            f32x4 pv[PB];
             ws_static_for<0, NEP>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                f32x4 v = *reinterpret_cast<const f32x4*>(sr + j * PPI * EPS);
+                if constexpr (j % PB == 0) {
+#pragma unroll
+                    for (int i = 0; i < PB; ++i) pv[i] = *reinterpret_cast<const f32x4*>(sr + (j + i) * PPI * EPS);
+                }
+                f32x4 v = pv[j % PB];
                 if constexpr (EPI == EPI_BIAS_ELU) {
+                    // (the compare form of ELU: a max / min formulation would turn NaN inputs into 0 - the reference propagates them)
                     v = f32x4{elu1_fast(v.x + b4.x), elu1_fast(v.y + b4.y), elu1_fast(v.z + b4.z), elu1_fast(v.w + b4.w)};
                 } else {
                     // aux loads return in order; behind ax[j]: NEP - 1 - j younger aux loads + the j stores already issued
