@@ -22,6 +22,9 @@ sys.path.insert(0, ROOT)
 def category(name):
     if 'conv3x3_wgrad_f16x3_ws_kernel' in name or 'conv3x3_wgrad_f16x3_kernel' in name:
         return 'conv_tile_wgrad'
+    if 'conv3x3_ws_f16x3_kernel' in name:                    # <C, EPI>: 0 = forward, 1 / 4 = data gradient (stored / row sums)
+        targs = name.split('<', 1)[1].split('>')[0].replace(' ', '').split(',')
+        return 'conv_tile_fwd' if targs[1] == '0' else 'conv_tile_dgrad'
     if 'conv3x3_tile_f16x3_kernel' in name:
         targs = name.split('<', 1)[1].split('>')[0].replace(' ', '').split(',')
         if targs[0] != targs[1]:
