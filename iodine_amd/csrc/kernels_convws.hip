@@ -146,7 +146,8 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
     constexpr int BUFB = ((NPX + 1) * PXB > 128 * EPS ? (NPX + 1) * PXB : 128 * EPS);    // one LDS buffer (input halo / output tile)
     constexpr int NIN = (NPX * 8 + 255) / 256;   // float4 loads per thread per chunk (6)
     constexpr int NS = (RW + 2) * 3;             // fragment steps per chunk: halo rows x column shifts
-    constexpr bool XPOSE = EPI != EPI_L0ROWS;    // epilogue through LDS: whole-pixel (1 KB contiguous) loads / stores
+    constexpr bool XPOSE = true;                 // epilogue through LDS: whole-pixel (1 KB contiguous) loads / stores (every form)
+    constexpr bool GRADF = EPI == EPI_MUL_ELUGRAD || EPI == EPI_L0ROWS;   // data-gradient forms: x ELU'(aux)
     constexpr int SEGS = C / 4, PPI = 64 / SEGS, NEP = 32 / PPI;      // whole-pixel layout: float4 segments, pixels / instruction
     static_assert(C == 64 || C == 32, "channel counts of the shipped decoders");
     static_assert(EPI == EPI_BIAS_ELU || EPI == EPI_MUL_ELUGRAD || EPI == EPI_L0ROWS, "epilogue");
@@ -283,7 +284,7 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
     };
 
     // stores (and the tile-max store) an epilogue leaves in flight: YOUNGER than the input loads of the stage after it
-    constexpr int NST = XPOSE ? NEP + 1 : 0;
+    constexpr int NST = EPI == EPI_L0ROWS ? 0 : NEP + 1;
 
 #define WS_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
     struct Frag { f16x8 h, l; };
@@ -441,8 +442,8 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
             const int seg = lane % SEGS, pl = lane / SEGS;
             // wave wv moves tile rows 2 wv, 2 wv + 1: instruction j = pixels j * PPI .. of those 32
             const unsigned vbase = (unsigned)(((((ty * 8 + 2 * wv) << lgS) + tx * 16 + pl) * C + seg * 4) * 4);
-            f32x4 ax[EPI == EPI_MUL_ELUGRAD ? NEP : 1];
-            if constexpr (EPI == EPI_MUL_ELUGRAD) {
+            f32x4 ax[GRADF ? NEP : 1];
+            if constexpr (GRADF) {
                 // the ELU' operand (whole pixels, like the stores) is requested before the barriers: in the training step it
                 // comes from HBM, not from a cache
                 // (first half now - the fragment registers are free -, second half once the accumulators are in LDS)
@@ -459,7 +460,7 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
 #pragma unroll
             for (int y = 0; y < RW; ++y)
                 *reinterpret_cast<f32x4*>(sb + ((pg * RW + y) * 16 + lpx) * EPS + (16 * cg + 4 * lkb) * 4) = acc[y] * inv;
-            if constexpr (EPI == EPI_MUL_ELUGRAD) {
+            if constexpr (GRADF) {
                 const i32x4_ rsrc_aux = make_rsrc(aux + (size_t)n * S * S * C, (unsigned)(S * S * C * 4));
 #pragma unroll
                 for (int j = NEP / 2; j < NEP; ++j) {
@@ -480,8 +481,10 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
             // all LDS reads first (the asm stores below are memory barriers for the compiler: interleaved with them every
             // read would be issued, and waited for, on its own)
             // (data-gradient form: in two batches - the ELU' operand occupies NEP float4s of its own)
-            constexpr int PB = EPI == EPI_MUL_ELUGRAD ? NEP / 2 : NEP;
+            constexpr int PB = GRADF ? NEP / 2 : NEP;
             f32x4 pv[PB];
+            f32x4 rtot = f32x4{0.f, 0.f, 0.f, 0.f}, rleft = rtot;      // (row-sum form) running sums of the current tile row
+            (void)rtot; (void)rleft;
             ws_static_for<0, NEP>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 if constexpr (j % PB == 0) {
@@ -493,84 +496,61 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
                     // (the compare form of ELU: a max / min formulation would turn NaN inputs into 0 - the reference propagates them)
                     v = f32x4{elu1_fast(v.x + b4.x), elu1_fast(v.y + b4.y), elu1_fast(v.z + b4.z), elu1_fast(v.w + b4.w)};
                 } else {
-                    // aux loads return in order; behind ax[j]: NEP - 1 - j younger aux loads + the j stores already issued
+                    // aux loads return in order; behind ax[j]: NEP - 1 - j younger aux loads + (storing form) the j stores already issued
                     f32x4& axj = ax[j];
-                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NEP - 1) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(EPI == EPI_MUL_ELUGRAD ? NEP - 1 : NEP - 1 - j) : "memory");
                     asm volatile("" : "+v"(axj));
                     v.x *= elu1_grad_from_out(axj.x); v.y *= elu1_grad_from_out(axj.y);
                     v.z *= elu1_grad_from_out(axj.z); v.w *= elu1_grad_from_out(axj.w);
                 }
-                vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-                const unsigned vb = vbase; const i32x4_ ro = rsrc_out;
-                const int soff = ((((j * PPI) / 16) << lgS) + (j * PPI) % 16) * C * 4;
+                if constexpr (EPI == EPI_L0ROWS) {
+                    // EPI_L0ROWS (inference, layer 1): d(pre-activation 0) is not stored but reduced to per-row left-border /
+                    // interior / right-border column sums rows_p[n][gy][tx][3][C] (the input of l0_reduce_cls_tiles).
+                    // Instruction j = pixels (j % IPR) * PPI + pl of tile row j / IPR; the sum over the PPI pixel lanes is xor
+                    // shuffles (lane = pl * SEGS + seg); border pixels exist only in the first / last tile column.
+                    constexpr int IPR = 16 / PPI;
+                    const bool lt = tx == 0, rt = tx == tiles_x - 1;
+                    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (j % IPR == 0) { rtot = v; rleft = (lt && pl == 0) ? v : zero; }
+                    else rtot += v;
+                    if constexpr (j % IPR == IPR - 1) {
+                        f32x4 Rb = (rt && pl == PPI - 1) ? v : zero, Lb = rleft, tot = rtot;
+#pragma unroll
+                        for (int off = SEGS; off < 64; off <<= 1)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) tot[e] += __shfl_xor(tot[e], off, 64);
+                        if (lt || rt) {                               // block-uniform
+#pragma unroll
+                            for (int off = SEGS; off < 64; off <<= 1)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { Lb[e] += __shfl_xor(Lb[e], off, 64); Rb[e] += __shfl_xor(Rb[e], off, 64); }
+                        }
+                        if (pl == 0) {
+                            float* rp = out + ((((size_t)n * S + ty * 8 + 2 * wv + j / IPR) * tiles_x + tx) * 3) * C + seg * 4;
+                            *reinterpret_cast<f32x4*>(rp) = Lb;
+                            *reinterpret_cast<f32x4*>(rp + C) = tot - Lb - Rb;
+                            *reinterpret_cast<f32x4*>(rp + 2 * C) = Rb;
+                        }
+                    }
+                } else {
+                    vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                    const unsigned vb = vbase; const i32x4_ ro = rsrc_out;
+                    const int soff = ((((j * PPI) / 16) << lgS) + (j * PPI) % 16) * C * 4;
 #ifdef WS_ABL_NOSTORE
-                asm volatile("" :: "v"(v), "v"(vb), "s"(ro), "s"(soff) : "memory");
+                    asm volatile("" :: "v"(v), "v"(vb), "s"(ro), "s"(soff) : "memory");
 #else
-                WS_BSTORE4(v, vb, ro, soff);
+                    WS_BSTORE4(v, vb, ro, soff);
 #endif
+                }
             });
-            // the wave's share of the cell max of this OUTPUT tile (side buffer for the consumer of `out`)
-            vmax = wave_max_f32(vmax);
-            const int tt = rev ? ntiles - 1 - t : t;
-            float* tp = tmax_out + (size_t)tt * 4 + wv;
-            asm volatile("global_store_dword %0, %1, off\n\ts_nop 1" :: "v"(tp), "v"(vmax) : "memory");
-            TP_STAMP(5);                                     // [5] whole-pixel epilogue
-        } else {
-            // EPI_L0ROWS (inference, layer 1): d(pre-activation 0) is not stored but reduced to per-row left-border / interior /
-            // right-border column sums rows_p[n][gy][tx][3][C] (the input of l0_reduce_cls_tiles).  Lane = (pixel lpx, channels
-            // co4 ..); the ELU' operand arrives 16 pixels x 64 bytes per instruction, in two halves (register budget).
-            const int co4 = 16 * cg + 4 * lkb;
-            const int gy0 = ty * 8 + pg * RW, gx = tx * 16 + lpx;
-            const unsigned obase = (unsigned)(((((gy0 << lgS) + gx) * C) + co4) * 4);
-            const i32x4_ rsrc_aux = make_rsrc(aux + (size_t)n * S * S * C, (unsigned)(S * S * C * 4));
-            constexpr int HALF = RW / 2;
-            f32x4 ax[HALF];
-            auto dpp_shr = [](float x, auto ctrl) {
-                return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
-            };
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-                for (int y = 0; y < HALF; ++y) {
-                    const int soff = ((hh * HALF + y) << lgS) * C * 4;
-                    WS_SGPR_SETTLE(rsrc_aux, soff);
-                    WS_BLOAD4(ax[y], obase, rsrc_aux, soff);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int y = 0; y < HALF; ++y) asm volatile("" : "+v"(ax[y]));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int y = 0; y < HALF; ++y) {
-                    f32x4 v = acc[hh * HALF + y] * inv;
-                    const f32x4 a4 = ax[y];
-                    v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
-                    v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
-                    // sum over the 16 pixel lanes by DPP row shifts (the total lands in pixel lane 15); pixel 0's value is
-                    // fetched there by row_shr:15
-                    f32x4 tot = v, v0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float s1 = tot[e];
-                        s1 += dpp_shr(s1, integral_constant<int, 0x111>{});
-                        s1 += dpp_shr(s1, integral_constant<int, 0x112>{});
-                        s1 += dpp_shr(s1, integral_constant<int, 0x114>{});
-                        s1 += dpp_shr(s1, integral_constant<int, 0x118>{});
-                        tot[e] = s1;
-                        v0[e] = dpp_shr(v[e], integral_constant<int, 0x11F>{});
-                    }
-                    if (lpx == 15) {
-                        const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-                        const f32x4 Lb = tx == 0 ? v0 : zero, Rb = tx == tiles_x - 1 ? v : zero, Mb = tot - Lb - Rb;
-                        float* rp = out + ((((size_t)n * S + gy0 + hh * HALF + y) * tiles_x + tx) * 3) * C + co4;
-                        *reinterpret_cast<f32x4*>(rp) = Lb;
-                        *reinterpret_cast<f32x4*>(rp + C) = Mb;
-                        *reinterpret_cast<f32x4*>(rp + 2 * C) = Rb;
-                    }
-                }
+            if constexpr (EPI != EPI_L0ROWS) {
+                // the wave's share of the cell max of this OUTPUT tile (side buffer for the consumer of `out`)
+                vmax = wave_max_f32(vmax);
+                const int tt = rev ? ntiles - 1 - t : t;
+                float* tp = tmax_out + (size_t)tt * 4 + wv;
+                asm volatile("global_store_dword %0, %1, off\n\ts_nop 1" :: "v"(tp), "v"(vmax) : "memory");
             }
-            (void)rsrc_out;
-            TP_STAMP(5);
+            TP_STAMP(5);                                     // [5] whole-pixel epilogue
         }
     }
     TP_FLUSH(g_ws_prof);
