@@ -293,7 +293,14 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
     per_iter(b.g_pm, (size_t)N * L, ncopy);
     per_iter(b.g_plv, (size_t)N * L, ncopy);
     per_iter(b.latent, (size_t)N * 4 * L, ncopy);
-    per_iter(b.enc, (size_t)N * P * 20, mode == 1 ? T : 1);
+    {
+        // training keeps the refinement inputs of all T iterations, back to back: the conv stack of the refinement network is
+        // back-propagated for all iterations in ONE batch of T * N slot-images (iodine_train_backward)
+        const size_t n_enc = (size_t)N * P * 20;
+        float* base = a.take<float>(n_enc * (mode == 1 ? T : 1));
+        b.enc.resize(T + 1);
+        for (int i = 0; i <= T; ++i) b.enc[i] = (mode == 1 && i < T) ? (base ? base + (size_t)i * n_enc : nullptr) : base;
+    }
     per_iter(b.pooled, (size_t)N * Cr, ncopy);
     per_iter(b.u, (size_t)N * H, ncopy);
     per_iter(b.gates, (size_t)N * 4 * H, ncopy);
@@ -308,11 +315,13 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
         for (int i = 0; i <= T + 1; ++i) { b.h[i] = hh[i & 1]; b.c[i] = cc[i & 1]; }
     }
     b.ract.assign(T + 1, std::vector<float*>(h->Dr));
-    for (int i = 0; i <= T; ++i) {
+    {
         int s = h->S;
         for (int l = 0; l < h->Dr; ++l) {
             s = ref_out_size(s);
-            b.ract[i][l] = (i == 0 || (mode == 1 && i < T)) ? a.take<float>((size_t)N * s * s * Cr) : b.ract[0][l];
+            const size_t n_l = (size_t)N * s * s * Cr;
+            float* base = a.take<float>(n_l * (mode == 1 ? T : 1));         // [T][N][s][s][Cr] in training (see enc)
+            for (int i = 0; i <= T; ++i) b.ract[i][l] = (mode == 1 && i < T) ? (base ? base + (size_t)i * n_l : nullptr) : base;
         }
     }
     if (mode == 1) {
@@ -329,11 +338,11 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
         b.ddm = a.take<float>((size_t)N * L); b.ddv = a.take<float>((size_t)N * L);
         b.dc1 = a.take<float>((size_t)N * H); b.dgates = a.take<float>((size_t)N * 4 * H);
         b.dxin = a.take<float>((size_t)N * H); b.ds = a.take<float>((size_t)N * H);
-        b.dpooled = a.take<float>((size_t)N * Cr);
+        b.dpooled = a.take<float>((size_t)T * N * Cr);                     // all iterations (batched conv-stack backward)
         for (int j = 0; j < 2; ++j) { b.carry_h[j] = a.take<float>((size_t)N * H); b.carry_c[j] = a.take<float>((size_t)N * H); }
         b.rdpre.resize(h->Dr);
         int s = h->S;
-        for (int l = 0; l < h->Dr; ++l) { s = ref_out_size(s); b.rdpre[l] = a.take<float>((size_t)N * s * s * Cr); }
+        for (int l = 0; l < h->Dr; ++l) { s = ref_out_size(s); b.rdpre[l] = a.take<float>((size_t)T * N * s * s * Cr); }
     }
     b.bytes = (a.off + 255) & ~(size_t)255;
 }
@@ -995,6 +1004,10 @@ int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float*
     int rc = check_ready(h, batch);
     if (rc) return rc;
     if (!x || !eps || !loss) return h->fail(IODINE_ERR_INVALID, "iodine_train_forward: x, eps and loss are required");
+    // the backward pass runs the refinement conv stack over all T iterations as one batch of T * N slot-images
+    if ((size_t)batch * h->K * h->T * h->P * 20 >= ((size_t)1 << 31) || (size_t)batch * h->K * h->T * (h->P / 4) * h->Cr >= ((size_t)1 << 31))
+        return h->fail(IODINE_ERR_INVALID, "batch too large for one device in training: batch * slots * iters * pixels * 20 must stay below "
+                                           "2^31 (shard the images over ranks, iodine_amd.parallel)");
     rc = ensure_workspace(h, batch, 1);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -1083,38 +1096,44 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
         HIPCHK(h, launch_mlp_bwd_pointwise(st, b.dxin, H, b.u[i], b.ds, N, H));
         HIPCHK(h, launch_sgemm(st, 1, 0, H, Cr, N, 1.f, b.ds, H, b.pooled[i], Cr, 1.f, G("refine.mlp.layers.0.weight"), Cr));
         HIPCHK(h, launch_colsum(st, b.ds, N, H, H, 1.f, G("refine.mlp.layers.0.bias")));
-        HIPCHK(h, launch_sgemm(st, 0, 0, N, Cr, H, 1.f, b.ds, H, h->raw_mlp_w, Cr, 0.f, b.dpooled, Cr));
-        // conv stack, last layer first
+        HIPCHK(h, launch_sgemm(st, 0, 0, N, Cr, H, 1.f, b.ds, H, h->raw_mlp_w, Cr, 0.f, b.dpooled + (size_t)i * N * Cr, Cr));
+    }
+    {
+        // Conv stack of the refinement network, last layer first, for ALL iterations at once: its inputs are detached
+        // (iodine.py:343), so the T passes only meet in the weight gradients - one batch of T * N slot-images per layer
+        // (saved inputs / activations of the iterations lie back to back, plan()) instead of T launches over N each: the
+        // 8 x 8 ... 64 x 64 layers fill the chip 5x better and 4 (T - 1) x 3 launches disappear.
+        const int NT = T * N;
         std::vector<int> sz(h->Dr + 1);
         sz[0] = h->S;
         for (int l = 0; l < h->Dr; ++l) sz[l + 1] = ref_out_size(sz[l]);
         const int sl = sz[h->Dr];
-        HIPCHK(h, launch_pool_bwd(st, b.dpooled, b.ract[i][h->Dr - 1], b.rdpre[h->Dr - 1], N, sl * sl, Cr));
+        HIPCHK(h, launch_pool_bwd(st, b.dpooled, b.ract[0][h->Dr - 1], b.rdpre[h->Dr - 1], NT, sl * sl, Cr));
         for (int l = h->Dr - 1; l >= 0; --l) {
-            const float* in = l == 0 ? b.enc[i] : b.ract[i][l - 1];
+            const float* in = l == 0 ? b.enc[0] : b.ract[0][l - 1];
             const int cip = l == 0 ? 20 : Cr, ireal = l == 0 ? 17 : Cr;
             int nparts = 0, cipad = 0;
             const std::string base = "refine.mlc.layers." + std::to_string(l);
             if (h->precision == 1 && refine_f16_ok(h)) {
                 int nb = 0;
-                PROF(h, st, "refine_wgrad", launch_conv3x3_s2_wgrad_f16x3(st, in, b.rdpre[l], b.wg_part, b.wg_part_b, N, sz[l],
+                PROF(h, st, "refine_wgrad", launch_conv3x3_s2_wgrad_f16x3(st, in, b.rdpre[l], b.wg_part, b.wg_part_b, NT, sz[l],
                                                                           cip, Cr, &nparts, &cipad, &nb));
                 HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, G(base + ".weight"), b.wg_fold,
                                               b.wg_part_b, nb, G(base + ".bias")));
             } else {
-                PROF(h, st, "refine_wgrad", launch_conv3x3_wgrad_gather(st, in, b.rdpre[l], b.wg_part, N, sz[l], sz[l], cip, Cr, 2,
+                PROF(h, st, "refine_wgrad", launch_conv3x3_wgrad_gather(st, in, b.rdpre[l], b.wg_part, NT, sz[l], sz[l], cip, Cr, 2,
                                                                         &nparts, &cipad));
                 HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, G(base + ".weight"), b.wg_fold));
-                PROF(h, st, "refine_bias_grad", launch_colsum_tall(st, b.rdpre[l], N * sz[l + 1] * sz[l + 1], Cr, 1.f,
+                PROF(h, st, "refine_bias_grad", launch_colsum_tall(st, b.rdpre[l], NT * sz[l + 1] * sz[l + 1], Cr, 1.f,
                                                                    G(base + ".bias"), b.wg_part_b, (size_t)512 * 64));
             }
             if (l > 0) {
                 if (h->precision == 1 && refine_f16_ok(h))
                     PROF(h, st, "refine_dgrad", launch_conv3x3_s2_dgrad_f16x3(st, b.rdpre[l], h->ref_wb16[l], h->ref_wmeta[l] + 2,
-                                                                              b.ract[i][l - 1], b.rdpre[l - 1], N, sz[l], Cr));
+                                                                              b.ract[0][l - 1], b.rdpre[l - 1], NT, sz[l], Cr));
                 else
-                    PROF(h, st, "refine_dgrad", launch_conv3x3_gather_dgrad(st, b.rdpre[l], h->ref_wb[l], b.ract[i][l - 1],
-                                                                            b.rdpre[l - 1], N, sz[l], sz[l], Cr, 2));
+                    PROF(h, st, "refine_dgrad", launch_conv3x3_gather_dgrad(st, b.rdpre[l], h->ref_wb[l], b.ract[0][l - 1],
+                                                                            b.rdpre[l - 1], NT, sz[l], sz[l], Cr, 2));
             }
         }
     }
