@@ -284,9 +284,10 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
     b.tmax_dpre[0] = a.take<float>(conv_ws_tmax_floats(N, h->S));
     b.tmax_dpre[1] = a.take<float>(conv_ws_tmax_floats(N, h->S));
     const int ncopy = mode == 1 ? T + 1 : 1;
-    auto per_iter = [&](std::vector<float*>& v, size_t n, int copies) {
+    auto per_iter = [&](std::vector<float*>& v, size_t n, int copies) {      // `copies` instances back to back, the rest alias [0]
         v.resize(T + 1);
-        for (int i = 0; i <= T; ++i) v[i] = (i < copies) ? a.take<float>(n) : v[0];
+        float* base = a.take<float>(n * (size_t)copies);
+        for (int i = 0; i <= T; ++i) v[i] = (i < copies && base) ? base + (size_t)i * n : base;
     };
     per_iter(b.z, (size_t)N * L, ncopy);
     if (mode != 1) b.z[T] = a.take<float>((size_t)N * L);   // the final sample must not overwrite the last elbo()'s z (self.z)
@@ -308,7 +309,10 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
     // LSTM state: h[i], c[i] = state BEFORE iteration i; inference ping-pongs two copies
     b.h.resize(T + 2); b.c.resize(T + 2);
     if (mode == 1) {
-        for (int i = 0; i <= T + 1; ++i) { b.h[i] = a.take<float>((size_t)N * H); b.c[i] = a.take<float>((size_t)N * H); }
+        // (each array contiguous over the iterations: the head's weight gradients are one GEMM over all T * N rows)
+        float* hb = a.take<float>((size_t)(T + 2) * N * H);
+        float* cb = a.take<float>((size_t)(T + 2) * N * H);
+        for (int i = 0; i <= T + 1; ++i) { b.h[i] = hb ? hb + (size_t)i * N * H : nullptr; b.c[i] = cb ? cb + (size_t)i * N * H : nullptr; }
     } else {
         float* hh[2] = {a.take<float>((size_t)N * H), a.take<float>((size_t)N * H)};
         float* cc[2] = {a.take<float>((size_t)N * H), a.take<float>((size_t)N * H)};
@@ -335,9 +339,10 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
         b.Dpart = a.take<float>((size_t)l0_dgroups(N) * P * Cd);
         b.RT = a.take<float>((size_t)N * 9 * Cd);
         b.tmp_lz = a.take<float>((size_t)L * 9 * Cd);
-        b.ddm = a.take<float>((size_t)N * L); b.ddv = a.take<float>((size_t)N * L);
-        b.dc1 = a.take<float>((size_t)N * H); b.dgates = a.take<float>((size_t)N * 4 * H);
-        b.dxin = a.take<float>((size_t)N * H); b.ds = a.take<float>((size_t)N * H);
+        // ddm / ddv / dgates / ds: one instance per iteration (weight gradients of the head in one pass over all of them)
+        b.ddm = a.take<float>((size_t)T * N * L); b.ddv = a.take<float>((size_t)T * N * L);
+        b.dc1 = a.take<float>((size_t)N * H); b.dgates = a.take<float>((size_t)T * N * 4 * H);
+        b.dxin = a.take<float>((size_t)N * H); b.ds = a.take<float>((size_t)T * N * H);
         b.dpooled = a.take<float>((size_t)T * N * Cr);                     // all iterations (batched conv-stack backward)
         for (int j = 0; j < 2; ++j) { b.carry_h[j] = a.take<float>((size_t)N * H); b.carry_c[j] = a.take<float>((size_t)N * H); }
         b.rdpre.resize(h->Dr);
@@ -1072,31 +1077,38 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
     for (int i = T - 1; i >= 0; --i) {
         // d loss / d delta_i = -w_{i+1}/B * d(B*ELBO_{i+1})/d lambda_{i+1}   (lambda_{i+1} = detach(lambda_i) + delta_i)
         const float alpha = -((float)(i + 2) / (float)(T + 1)) / (float)B;
-        HIPCHK(h, launch_scale(st, b.g_pm[i + 1], alpha, b.ddm, N * L));
-        HIPCHK(h, launch_scale(st, b.g_plv[i + 1], alpha, b.ddv, N * L));
+        float *ddm = b.ddm + (size_t)i * N * L, *ddv = b.ddv + (size_t)i * N * L;
+        float *dgates = b.dgates + (size_t)i * N * 4 * H, *ds = b.ds + (size_t)i * N * H;
+        HIPCHK(h, launch_scale(st, b.g_pm[i + 1], alpha, ddm, N * L));
+        HIPCHK(h, launch_scale(st, b.g_plv[i + 1], alpha, ddv, N * L));
         const float* c1 = b.c[i + 1];
         // read-out layers act on the cell state (iodine.py:488-492)
-        HIPCHK(h, launch_sgemm(st, 1, 0, L, H, N, 1.f, b.ddm, L, c1, H, 1.f, G("refine.mean_update.weight"), H));
-        HIPCHK(h, launch_sgemm(st, 1, 0, L, H, N, 1.f, b.ddv, L, c1, H, 1.f, G("refine.logvar_update.weight"), H));
-        HIPCHK(h, launch_colsum(st, b.ddm, N, L, L, 1.f, G("refine.mean_update.bias")));
-        HIPCHK(h, launch_colsum(st, b.ddv, N, L, L, 1.f, G("refine.logvar_update.bias")));
-        HIPCHK(h, launch_sgemm(st, 0, 0, N, H, L, 1.f, b.ddm, L, h->raw_wm, H, 0.f, b.dc1, H));
-        HIPCHK(h, launch_sgemm(st, 0, 0, N, H, L, 1.f, b.ddv, L, h->raw_wv, H, 1.f, b.dc1, H));
+        HIPCHK(h, launch_sgemm(st, 0, 0, N, H, L, 1.f, ddm, L, h->raw_wm, H, 0.f, b.dc1, H));
+        HIPCHK(h, launch_sgemm(st, 0, 0, N, H, L, 1.f, ddv, L, h->raw_wv, H, 1.f, b.dc1, H));
         const bool last = (i == T - 1);
         HIPCHK(h, launch_lstm_bwd_pointwise(st, b.gates[i], b.c[i], c1, b.dc1, last ? nullptr : b.carry_h[cf],
-                                            last ? nullptr : b.carry_c[cf], b.dgates, b.carry_c[cf ^ 1], N, H));
-        HIPCHK(h, launch_sgemm(st, 1, 0, 4 * H, IN, N, 1.f, b.dgates, 4 * H, b.xin[i], IN, 1.f, G("refine.lstm.weight_ih"), IN));
-        HIPCHK(h, launch_sgemm(st, 1, 0, 4 * H, H, N, 1.f, b.dgates, 4 * H, b.h[i], H, 1.f, G("refine.lstm.weight_hh"), H));
-        HIPCHK(h, launch_colsum(st, b.dgates, N, 4 * H, 4 * H, 1.f, G("refine.lstm.bias_ih")));
-        HIPCHK(h, launch_colsum(st, b.dgates, N, 4 * H, 4 * H, 1.f, G("refine.lstm.bias_hh")));
-        HIPCHK(h, launch_sgemm(st, 0, 0, N, H, 4 * H, 1.f, b.dgates, 4 * H, h->raw_whh, H, 0.f, b.carry_h[cf ^ 1], H));
+                                            last ? nullptr : b.carry_c[cf], dgates, b.carry_c[cf ^ 1], N, H));
+        HIPCHK(h, launch_sgemm(st, 0, 0, N, H, 4 * H, 1.f, dgates, 4 * H, h->raw_whh, H, 0.f, b.carry_h[cf ^ 1], H));
         cf ^= 1;
         // MLP (double ELU) and average pool
-        HIPCHK(h, launch_sgemm(st, 0, 0, N, H, 4 * H, 1.f, b.dgates, 4 * H, h->raw_wih, IN, 0.f, b.dxin, H));
-        HIPCHK(h, launch_mlp_bwd_pointwise(st, b.dxin, H, b.u[i], b.ds, N, H));
-        HIPCHK(h, launch_sgemm(st, 1, 0, H, Cr, N, 1.f, b.ds, H, b.pooled[i], Cr, 1.f, G("refine.mlp.layers.0.weight"), Cr));
-        HIPCHK(h, launch_colsum(st, b.ds, N, H, H, 1.f, G("refine.mlp.layers.0.bias")));
-        HIPCHK(h, launch_sgemm(st, 0, 0, N, Cr, H, 1.f, b.ds, H, h->raw_mlp_w, Cr, 0.f, b.dpooled + (size_t)i * N * Cr, Cr));
+        HIPCHK(h, launch_sgemm(st, 0, 0, N, H, 4 * H, 1.f, dgates, 4 * H, h->raw_wih, IN, 0.f, b.dxin, H));
+        HIPCHK(h, launch_mlp_bwd_pointwise(st, b.dxin, H, b.u[i], ds, N, H));
+        HIPCHK(h, launch_sgemm(st, 0, 0, N, Cr, H, 1.f, ds, H, h->raw_mlp_w, Cr, 0.f, b.dpooled + (size_t)i * N * Cr, Cr));
+    }
+    {
+        // Weight gradients of the head: sums over the iterations of X_i^T D_i = ONE GEMM per parameter over all T * N rows
+        // (the per-iteration operands lie back to back: c[1..T], xin[0..T-1], h[0..T-1], pooled[0..T-1] and ddm / ddv / dgates / ds)
+        const int R = T * N;
+        HIPCHK(h, launch_sgemm(st, 1, 0, L, H, R, 1.f, b.ddm, L, b.c[1], H, 1.f, G("refine.mean_update.weight"), H));
+        HIPCHK(h, launch_sgemm(st, 1, 0, L, H, R, 1.f, b.ddv, L, b.c[1], H, 1.f, G("refine.logvar_update.weight"), H));
+        HIPCHK(h, launch_colsum(st, b.ddm, R, L, L, 1.f, G("refine.mean_update.bias")));
+        HIPCHK(h, launch_colsum(st, b.ddv, R, L, L, 1.f, G("refine.logvar_update.bias")));
+        HIPCHK(h, launch_sgemm(st, 1, 0, 4 * H, IN, R, 1.f, b.dgates, 4 * H, b.xin[0], IN, 1.f, G("refine.lstm.weight_ih"), IN));
+        HIPCHK(h, launch_sgemm(st, 1, 0, 4 * H, H, R, 1.f, b.dgates, 4 * H, b.h[0], H, 1.f, G("refine.lstm.weight_hh"), H));
+        HIPCHK(h, launch_colsum(st, b.dgates, R, 4 * H, 4 * H, 1.f, G("refine.lstm.bias_ih")));
+        HIPCHK(h, launch_colsum(st, b.dgates, R, 4 * H, 4 * H, 1.f, G("refine.lstm.bias_hh")));
+        HIPCHK(h, launch_sgemm(st, 1, 0, H, Cr, R, 1.f, b.ds, H, b.pooled[0], Cr, 1.f, G("refine.mlp.layers.0.weight"), Cr));
+        HIPCHK(h, launch_colsum(st, b.ds, R, H, H, 1.f, G("refine.mlp.layers.0.bias")));
     }
     {
         // Conv stack of the refinement network, last layer first, for ALL iterations at once: its inputs are detached
