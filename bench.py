@@ -39,7 +39,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA pe
 SPLIT_PASSES = 3                   # fp32 product = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, three f16 MFMAs, fp32 accumulate
 PUBLISHED_TRAIN_ITERS_PER_S = 94.0  # 1.7 s / 32-image T=5 training step on 4 unknown GPUs (log.md:3)
 DOMINANT = ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad')
-CATS = DOMINANT + ('dec_out', 'dec_out_dgrad', 'dec_out_wgrad', 'dec_l0', 'l0_reduce', 'l0_slot_sum', 'pixel_pass1',
+CATS = DOMINANT + ('dec_out', 'dec_out_dgrad', 'dec_out_wgrad', 'dec_out_bwd', 'dec_l0', 'l0_reduce', 'l0_slot_sum', 'pixel_pass1',
                    'pixel_pass2', 'refine_conv', 'refine_head', 'refine_wgrad', 'refine_dgrad', 'refine_bias_grad', 'head_bwd')
 
 

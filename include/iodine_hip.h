@@ -175,6 +175,8 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * row sums in its epilogue instead of storing it; 0 = store and reduce in a second kernel, as the training path does),
  * "out_variant" (output conv forward: 1 = streaming kernel -- default, 0 = LDS-staged),
  * "out_dgrad_variant" (output conv data gradient: 1 = split-fp16 streaming kernel -- default, 0 = generic fp32 tile kernel),
+ * "out_bwd_fused" (1 -- default: in training the output conv's data gradient and weight / bias gradient come from ONE pass
+ * over the saved activation; 0 = two kernels, as iodine_reconstruct's data gradient + the GEMM-form weight gradient),
  * "zigzag" (1 -- default: odd decoder layers walk their tiles backwards so that a launch starts on what the previous one
  * wrote last; 0 = every launch in ascending order; results identical),
  * "wgrad_ws" (split-fp16 64->64 / 32->32 weight gradient: 2 = warp-specialised, natural-order staging + transposing LDS
@@ -182,7 +184,8 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * arithmetic; the non-default ones exist for same-box A/B timing (tools/ab_bench.py). */
 int iodine_set_option(iodine_handle* h, const char* key, double value);
 /* Sum of event-measured durations (ms) and number of launches of one kernel category since the last reset:
- * "conv_tile_fwd", "conv_tile_dgrad", "conv_tile_wgrad", "dec_out", "dec_out_dgrad", "dec_l0", "l0_reduce",
+ * "conv_tile_fwd", "conv_tile_dgrad", "conv_tile_wgrad", "dec_out", "dec_out_dgrad", "dec_out_wgrad", "dec_out_bwd", "dec_l0",
+ * "l0_reduce",
  * "pixel_pass1", "pixel_pass2", "refine_conv", "refine_head".  Synchronises on the recorded events. */
 int iodine_profile_read(iodine_handle* h, const char* category, double* total_ms, long long* launches, int reset);
 /* Copy an internal buffer of the last call (name as listed in DESIGN.md "workspace") to dst (device). */

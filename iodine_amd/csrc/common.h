@@ -251,5 +251,8 @@ hipError_t launch_conv3x3_s2_wgrad_f16x3(hipStream_t st, const float* a, const f
                                          int S, int ci_real, int nco, int* nparts, int* cipad, int* nbias_parts);
 hipError_t launch_dec_out_wgrad_gemm_f16x3(hipStream_t st, const float* a, const float* g, float* part, float* part_b, int N,
                                            int S, int c, int* nparts, int* nbias_parts);
+hipError_t launch_dec_out_bwd_fused_f16x3(hipStream_t st, const float* a, const float* g, const void* wpk, const float* wmeta,
+                                          float* out, float* tmax, float* part, float* part_b, int N, int S, int c,
+                                          int* nparts, int* nbias_parts);
 hipError_t launch_conv3x3_wgrad_f16x3_ws(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
                                          int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts, int variant);

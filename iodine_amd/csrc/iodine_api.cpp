@@ -86,6 +86,7 @@ struct iodine_handle {
     int precision = 1;                          // 0: exact fp32 MFMA, 1: 3 x fp16 MFMA split (fp32-class accuracy)
     int wgrad_ws = 2;                           // decoder 64->64 weight gradient: 0 one-role kernel, 1 warp-specialised (transposing stagers + v_alignbit), 2 warp-specialised with ds_read_b64_tr_b16
     int out_dgrad_variant = 1;                  // output conv data gradient: 1 = split-fp16 streaming kernel, 0 = generic fp32 tile kernel
+    int out_bwd_fused = 1;                      // training: output conv data + weight gradient in one pass over the activation
     int fuse_l0 = 1;                            // inference: layer-1 data gradient reduces straight to the layer-0 row sums
     int out_variant = 1;                        // output conv forward: 1 = streaming (fragments straight from global), 0 = LDS-staged
     int zigzag = 1;                             // odd decoder layers walk the tiles backwards (Infinity Cache reuse)
@@ -435,9 +436,19 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
     const int Cd = h->Cd, Dd = h->Dd;
     int cur = 0, nparts = 0, ncop = 0, nb = 0, rc;
     bool fused_l0 = false;
+    // training: one pass over the last hidden activation gives the data gradient AND the weight / bias gradient
+    const bool out_fused = train_alpha != 0.f && h->precision == 1 && h->out_dgrad_variant && h->out_bwd_fused;
 #ifdef IODINE_XSKIP_HOOK
     if (!(g_iod_xskip & 256))
 #endif
+    if (out_fused) {
+        const int wi = param_index(h, "decoder.conv.weight"), bi = param_index(h, "decoder.conv.bias");
+        PROF(h, st, "dec_out_bwd", launch_dec_out_bwd_fused_f16x3(st, b.act[Dd - 1], b.g, h->dec_out_wb16, h->dec_out_meta,
+                                                                   b.dpre[cur], conv_ws_ok(h) ? b.tmax_dpre[cur] : nullptr,
+                                                                   b.wg_part, b.wg_part_b, N, h->S, Cd, &nparts, &nb));
+        HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, Cd, 4, 4, Cd, Cd, train_alpha, h->gacc[wi], b.wg_fold,
+                                      b.wg_part_b, nb, h->gacc[bi]));
+    } else
     {
         if (h->precision == 1 && h->out_dgrad_variant)
             PROF(h, st, "dec_out_dgrad", launch_dec_out_dgrad_f16x3(st, b.g, h->dec_out_wb16, h->dec_out_meta, b.act[Dd - 1],
@@ -446,7 +457,7 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
             PROF(h, st, "dec_out_dgrad", launch_conv3x3_tile(st, b.g, h->dec_out_wb, nullptr, b.act[Dd - 1], b.dpre[cur], N,
                                                              h->S, 4, Cd, EPI_MUL_ELUGRAD));
     }
-    if (train_alpha != 0.f) {
+    if (train_alpha != 0.f && !out_fused) {
         const int wi = param_index(h, "decoder.conv.weight"), bi = param_index(h, "decoder.conv.bias");
         if (h->precision == 1) {                           // GEMM form: rows (tap, co), no N = 4 -> 32 padding
             PROF(h, st, "dec_out_wgrad", launch_dec_out_wgrad_gemm_f16x3(st, b.act[Dd - 1], b.g, b.wg_part, b.wg_part_b, N, h->S,
@@ -630,7 +641,7 @@ std::vector<uintptr_t> graph_key(const iodine_handle* h, int entry, int batch, s
 {
     std::vector<uintptr_t> k = {(uintptr_t)entry, (uintptr_t)batch, (uintptr_t)h->stop_after, (uintptr_t)h->precision,
                                 (uintptr_t)h->variant, (uintptr_t)h->wgrad_ws, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_variant,
-                                (uintptr_t)h->out_dgrad_variant, (uintptr_t)h->zigzag, (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
+                                (uintptr_t)h->out_dgrad_variant, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->zigzag, (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
     for (const void* p : ptrs) k.push_back((uintptr_t)p);
     return k;
 }
@@ -866,6 +877,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "xskip")) { g_iod_xskip = (int)value; return IODINE_OK; }       // timing-only ablation builds (common.h)
 #endif
     if (!strcmp(key, "out_dgrad_variant")) { h->out_dgrad_variant = value != 0; return IODINE_OK; }
+    if (!strcmp(key, "out_bwd_fused")) { h->out_bwd_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "fuse_l0")) { h->fuse_l0 = value != 0; return IODINE_OK; }
     if (!strcmp(key, "out_variant")) { h->out_variant = value != 0; return IODINE_OK; }
     if (!strcmp(key, "zigzag")) { h->zigzag = value != 0; return IODINE_OK; }

@@ -1176,6 +1176,306 @@ hipError_t launch_dec_out_wgrad_gemm_f16x3(hipStream_t st, const float* a, const
 }
 
 // =========================================================================================
+// Output conv backward in ONE pass over the saved activation (training): the data gradient of dec_out_dgrad_f16x3_kernel
+// (kernels_out.hip; 4 -> C channels, times ELU') and the weight / bias gradient of dec_out_wgrad_gemm_f16x3_kernel above
+// both stream the same 0.94 GB tensor (cfg3) and the same 4-channel gradient; run back to back they are 0.35 + 0.23 ms per
+// decoder pass, both HBM-bound.  Here a persistent block takes 4 x 16-pixel tiles: the activation tile is fetched once
+// (whole pixels, kept in registers for the ELU' factor), split into the transposed fp16 planes of the weight-gradient GEMM
+// (K = pixels), the gradient halo is staged twice (fp16 planes for the weight gradient, fp32 for the data gradient's
+// [pixels x 36] operand), and after the MFMAs of both products the data-gradient tile is transposed through the plane buffer
+// and leaves as whole pixels.  The next tile's loads are issued before the MFMAs.  Same arithmetic per product as the two
+// kernels it replaces (same packs, same three passes; the data gradient's power-of-two scale is a function of the tile's own
+// halo only, so its result does not depend on which block ran the tile).
+// =========================================================================================
+template <int C>
+__global__ __launch_bounds__(256, C == 64 ? 3 : 4)
+void dec_out_bwd_fused_f16x3_kernel(const float* __restrict__ a, const float* __restrict__ g, const uint4* __restrict__ wpk,
+                                    const float* __restrict__ wmeta, float* __restrict__ out, float* __restrict__ tmax,
+                                    float* __restrict__ part, float* __restrict__ part_b, int S, int ntiles, int tiles_x,
+                                    int tiles_y)
+{
+    constexpr int NTT = C / 32;                          // ci tiles
+    constexpr int KS = 2 / NTT;                          // waves = 2 (j tiles) x NTT x KS
+    constexpr int TH = 4, RW = TH / KS;
+    constexpr int BPL = TH * 8 + 4;                      // dwords per activation channel plane (BPL/4 odd)
+    constexpr int GROW = 12, GPL = (TH + 2) * GROW;      // g planes: 6 halo rows x (18 columns = 9 dwords, padded to 12)
+    constexpr int A4 = C / 4;
+    constexpr int NB_UNITS = TH * 8 * A4, NBU = NB_UNITS / 256;
+    constexpr int NG_UNITS = (TH + 2) * 9;
+    constexpr int HW = 18;                               // fp32 gradient halo: 6 rows x 18 columns
+    constexpr int W_U4 = 3 * 2 * 2 * C;                  // packed data-gradient weights (pack_dec_out_dgrad_kernel)
+    constexpr int EPD = C + 4;                           // dwords per transposed pixel
+    constexpr int NDW = 2 * NTT;                         // waves that own a 32 channel x 32 pixel block of the data gradient
+    static_assert(NB_UNITS % 256 == 0, "activation tile units");
+    static_assert(2 * C * BPL >= TH * 16 * EPD, "transposition region fits the plane buffer");
+
+    __shared__ __attribute__((aligned(16))) unsigned s_b[2 * C * BPL];   // fp16 planes, then the transposed output tile
+    __shared__ __attribute__((aligned(16))) unsigned s_g[2 * 4 * GPL];
+    __shared__ __attribute__((aligned(16))) float4 s_g32[(TH + 2) * HW];
+    __shared__ __attribute__((aligned(16))) uint4 s_w[W_U4];
+    __shared__ float s_max[8];
+    __shared__ float s_omax[4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, kh = lane >> 5, li = lane & 31;
+    const int mj = wv & 1, ni = (wv >> 1) % NTT, ks = wv / (2 * NTT);
+    const int j = mj * 32 + li, tap = j >> 2, co = j & 3;
+    const bool j_ok = tap < 9;
+    const int ky = j_ok ? tap / 3 : 1, kx = j_ok ? tap % 3 : 1;
+    const int h0 = 8 * kh + 2 - kx;                      // first half-word (column + 1) of this lane's 8 pixels
+    const unsigned sh = (h0 & 1) * 16;
+    const int g_base = co * GPL + (2 - ky) * GROW + (h0 >> 1);
+    const int ci = ni * 32 + li;
+    // data gradient: wave -> (channel half dch, pixel half dph); lane li = pixel of the half (row 2*dph + li/16, column li%16)
+    const bool d_on = wv < NDW;
+    const int dch = wv % NTT, dph = (wv / NTT) & 1;
+    const int dpy = 2 * dph + (li >> 4), dpx = li & 15;
+
+    for (int idx = tid; idx < W_U4; idx += 256) s_w[idx] = wpk[idx];
+    const float winv = wmeta[1];
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sa = 1.f, sd = 1.f, acc_prod = 1.f;
+
+    float4 rb[NBU][2], rg[2];
+    auto fetch = [&](int tile, float4 (&fb)[NBU][2], float4 (&fg)[2]) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int n = t / tiles_y;
+        const float* a_n = a + (size_t)n * S * S * C;
+        const float4* g_n = reinterpret_cast<const float4*>(g) + (size_t)n * S * S;
+#pragma unroll
+        for (int k = 0; k < NBU; ++k) {
+            const int u = tid + k * 256;
+            const int c4 = u % A4, tt = u / A4, p = tt % 8, row = tt / 8;
+            const float* src = a_n + ((size_t)(ty * TH + row) * S + tx * 16 + 2 * p) * C + c4 * 4;
+            fb[k][0] = *reinterpret_cast<const float4*>(src);
+            fb[k][1] = *reinterpret_cast<const float4*>(src + C);
+        }
+        fg[0] = fg[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < NG_UNITS) {                              // g halo tile: pixel pairs (columns 2p-1, 2p), one float4 = 4 channels
+            const int p = tid % 9, row = tid / 9;
+            const int gy = ty * TH - 1 + row, gx = tx * 16 - 1 + 2 * p;
+            if (gy >= 0 && gy < S) {
+                if (gx >= 0 && gx < S) fg[0] = g_n[(size_t)gy * S + gx];
+                if (gx + 1 < S) fg[1] = g_n[(size_t)gy * S + gx + 1];
+            }
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x, rb, rg);
+    int prev_tm = -1;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int n = t / tiles_y;
+        float* out_n = out + (size_t)n * S * S * C;
+
+        float ma = 0.f, md = 0.f;
+#pragma unroll
+        for (int k = 0; k < NBU; ++k)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                ma = fmaxf(ma, fmaxf(fmaxf(fabsf(rb[k][q].x), fabsf(rb[k][q].y)), fmaxf(fabsf(rb[k][q].z), fabsf(rb[k][q].w))));
+        if (tid < NG_UNITS) {
+            const int p = tid % 9, row = tid / 9;
+            const bool rin = row >= 1 && row <= TH;        // bias gradient: interior pixels only (each pixel once per launch)
+            if (rin && p >= 1) { bsum.x += rg[0].x; bsum.y += rg[0].y; bsum.z += rg[0].z; bsum.w += rg[0].w; }
+            if (rin && p <= 7) { bsum.x += rg[1].x; bsum.y += rg[1].y; bsum.z += rg[1].z; bsum.w += rg[1].w; }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                md = fmaxf(md, fmaxf(fmaxf(fabsf(rg[q].x), fabsf(rg[q].y)), fmaxf(fabsf(rg[q].z), fabsf(rg[q].w))));
+        }
+        ma = wave_max_f32(ma);
+        md = wave_max_f32(md);
+        if (lane == 0) { s_max[wv] = ma; s_max[4 + wv] = md; }
+        __syncthreads();                                   // (A) every wave is also done with the previous tile's LDS
+        if (tmax && prev_tm >= 0 && tid < 2)               // side buffer of the previous tile (its wave maxima are visible now)
+            tmax[prev_tm + tid] = fmaxf(fmaxf(s_omax[0], s_omax[1]), fmaxf(s_omax[2], s_omax[3]));
+        ma = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        md = fmaxf(fmaxf(s_max[4], s_max[5]), fmaxf(s_max[6], s_max[7]));
+        sa = tile_scale(ma, sa);
+        sd = tile_scale(md, sd);
+        const float sdg = tile_scale(md, 1.f);             // data gradient: a function of this tile's halo only
+        const float prod = sa * sd;
+        if (prod != acc_prod) {                            // block-uniform; exact (powers of two)
+            const float r = prod / acc_prod;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] *= r;
+            acc_prod = prod;
+        }
+#pragma unroll
+        for (int k = 0; k < NBU; ++k) {
+            const int u = tid + k * 256;
+            const int c4 = u % A4, tt = u / A4, p = tt % 8, row = tt / 8;
+            const int rot = c4 & 3;
+            const float4 q0 = rot4(rb[k][0], rot), q1 = rot4(rb[k][1], rot);
+            const float x0[4] = {q0.x, q0.y, q0.z, q0.w}, x1[4] = {q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned lo;
+                const unsigned hi = pack_hi_lo(x0[e] * sa, x1[e] * sa, lo);
+                const int ch = c4 * 4 + ((e + rot) & 3);
+                s_b[(0 * C + ch) * BPL + row * 8 + p] = hi;
+                s_b[(1 * C + ch) * BPL + row * 8 + p] = lo;
+            }
+        }
+        if (tid < NG_UNITS) {
+            const int p = tid % 9, row = tid / 9;
+            const float x0[4] = {rg[0].x, rg[0].y, rg[0].z, rg[0].w}, x1[4] = {rg[1].x, rg[1].y, rg[1].z, rg[1].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned lo;
+                const unsigned hi = pack_hi_lo(x0[e] * sd, x1[e] * sd, lo);
+                s_g[(0 * 4 + e) * GPL + row * GROW + p] = hi;
+                s_g[(1 * 4 + e) * GPL + row * GROW + p] = lo;
+            }
+            s_g32[row * HW + 2 * p] = rg[0];
+            s_g32[row * HW + 2 * p + 1] = rg[1];
+        }
+        __syncthreads();                                   // (B)
+
+        // next tile's loads fly under the MFMAs and the epilogue (rg is free; the activation goes to a second set)
+        float4 rbn[NBU][2], rgn[2];
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        if (has_next) fetch(tile + gridDim.x, rbn, rgn);
+
+        // ---- weight gradient: rows j = (tap, co), columns ci, K = the pixels of one tile row per MFMA ----
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int r = ks * RW + rr;
+            h16x8 A[2], B[2];
+#pragma unroll
+            for (int term = 0; term < 2; ++term) {
+                const unsigned* pg = s_g + term * 4 * GPL + g_base + r * GROW;
+                const unsigned v0 = pg[0], v1 = pg[1], v2 = pg[2], v3 = pg[3], v4 = pg[4];
+                uint4 m;
+                m.x = __builtin_amdgcn_alignbit(v1, v0, sh);
+                m.y = __builtin_amdgcn_alignbit(v2, v1, sh);
+                m.z = __builtin_amdgcn_alignbit(v3, v2, sh);
+                m.w = __builtin_amdgcn_alignbit(v4, v3, sh);
+                if (!j_ok) m = make_uint4(0u, 0u, 0u, 0u);
+                __builtin_memcpy(&A[term], &m, 16);
+                const uint4 vb = *reinterpret_cast<const uint4*>(s_b + (term * C + ci) * BPL + r * 8 + 4 * kh);
+                __builtin_memcpy(&B[term], &vb, 16);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], B[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[0], acc, 0, 0, 0);
+        }
+        // ---- data gradient: rows = channels (weights first), columns = 32 pixels, K = (tap, co) padded to 48 ----
+        f32x16 dacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+        if (d_on) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int t0 = 4 * c + 2 * kh;                      // this lane's two taps of the chunk
+                float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+                if (t0 < 9) q0 = s_g32[(dpy + t0 / 3) * HW + dpx + t0 % 3];
+                if (t0 + 1 < 9) q1 = s_g32[(dpy + (t0 + 1) / 3) * HW + dpx + (t0 + 1) % 3];
+                unsigned l0, l1, l2, l3;
+                const unsigned u0 = pack_hi_lo(q0.x * sdg, q0.y * sdg, l0), u1 = pack_hi_lo(q0.z * sdg, q0.w * sdg, l1);
+                const unsigned u2 = pack_hi_lo(q1.x * sdg, q1.y * sdg, l2), u3 = pack_hi_lo(q1.z * sdg, q1.w * sdg, l3);
+                const uint4 uh = make_uint4(u0, u1, u2, u3), ul = make_uint4(l0, l1, l2, l3);
+                h16x8 ah, al, bh, bl;
+                __builtin_memcpy(&ah, &uh, 16); __builtin_memcpy(&al, &ul, 16);
+                const uint4 wh = s_w[((c * 2 + 0) * 2 + kh) * C + dch * 32 + li];
+                const uint4 wl = s_w[((c * 2 + 1) * 2 + kh) * C + dch * 32 + li];
+                __builtin_memcpy(&bh, &wh, 16); __builtin_memcpy(&bl, &wl, 16);
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, dacc, 0, 0, 0);
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, dacc, 0, 0, 0);
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, dacc, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // (C) the planes are dead: the buffer becomes the transposed tile
+        float* ep = reinterpret_cast<float*>(s_b);
+        if (d_on) {
+            const float inv = winv / sdg;
+            // lane (li, kh) holds channels dch*32 + 8*g4 + 4*kh .. +3 of pixel dph*32 + li
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<f32x4*>(ep + (dph * 32 + li) * EPD + dch * 32 + 8 * g4 + 4 * kh) =
+                    f32x4{dacc[4 * g4] * inv, dacc[4 * g4 + 1] * inv, dacc[4 * g4 + 2] * inv, dacc[4 * g4 + 3] * inv};
+        }
+        __syncthreads();                                   // (D)
+        float omax = 0.f;
+#pragma unroll
+        for (int k = 0; k < NBU; ++k) {
+            const int u = tid + k * 256;
+            const int c4 = u % A4, tt = u / A4, p = tt % 8, row = tt / 8;
+            float* dst = out_n + ((size_t)(ty * TH + row) * S + tx * 16 + 2 * p) * C + c4 * 4;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(ep + (row * 16 + 2 * p + q) * EPD + c4 * 4);
+                const float4 a4 = rb[k][q];
+                v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
+                v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
+                omax = fmaxf(omax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                *reinterpret_cast<f32x4*>(dst + q * C) = v;
+            }
+        }
+        omax = wave_max_f32(omax);
+        if (lane == 0) s_omax[wv] = omax;
+        // 8 x 16 cells of the side buffer: this 4-row tile owns two of its cell's four slots
+        prev_tm = (((n * (S / 8) + (ty >> 1)) * tiles_x + tx) * 4) + 2 * (ty & 1);
+        if (has_next) {
+#pragma unroll
+            for (int k = 0; k < NBU; ++k) { rb[k][0] = rbn[k][0]; rb[k][1] = rbn[k][1]; }
+            rg[0] = rgn[0]; rg[1] = rgn[1];
+        }
+    }
+    __syncthreads();
+    if (tmax && prev_tm >= 0 && tid < 2)
+        tmax[prev_tm + tid] = fmaxf(fmaxf(s_omax[0], s_omax[1]), fmaxf(s_omax[2], s_omax[3]));
+
+    // rows of the accumulator are j = tap*4 + co: registers 4q .. 4q+3 of a lane are the 4 output channels of one tap
+    const float inv = 1.f / acc_prod;
+    float* pw = part + (size_t)(blockIdx.x * KS + ks) * 9 * C * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tp = mj * 8 + 2 * q + kh;
+        if (tp < 9)
+            *reinterpret_cast<float4*>(pw + ((size_t)tp * C + ci) * 4) =
+                make_float4(acc[4 * q] * inv, acc[4 * q + 1] * inv, acc[4 * q + 2] * inv, acc[4 * q + 3] * inv);
+    }
+    __syncthreads();
+    float4* s_red = reinterpret_cast<float4*>(s_b);
+    s_red[tid] = bsum;
+    __syncthreads();
+    if (tid == 0) {
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 256; ++q) { const float4 v = s_red[q]; t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w; }
+        *reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * 4) = t4;
+    }
+}
+
+// part: nparts x [9][c][4], part_b: nbias_parts x [4]; out = d(pre-activation) of the last hidden layer, tmax its side buffer
+hipError_t launch_dec_out_bwd_fused_f16x3(hipStream_t st, const float* a, const float* g, const void* wpk, const float* wmeta,
+                                          float* out, float* tmax, float* part, float* part_b, int N, int S, int c,
+                                          int* nparts, int* nbias_parts)
+{
+    if (S % 16 != 0 || (c != 64 && c != 32)) return hipErrorInvalidValue;
+    const int tiles_x = S / 16, tiles_y = S / 4, ntiles = N * tiles_x * tiles_y;
+    const int cap = c == 64 ? 768 : 1024;                 // resident blocks: 3 resp. 4 per CU (register budget), persistent
+    const int blocks = ntiles < cap ? ntiles : cap;
+    if (c == 64)
+        hipLaunchKernelGGL((dec_out_bwd_fused_f16x3_kernel<64>), dim3(blocks), dim3(256), 0, st, a, g, (const uint4*)wpk, wmeta,
+                           out, tmax, part, part_b, S, ntiles, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL((dec_out_bwd_fused_f16x3_kernel<32>), dim3(blocks), dim3(256), 0, st, a, g, (const uint4*)wpk, wmeta,
+                           out, tmax, part, part_b, S, ntiles, tiles_x, tiles_y);
+    *nparts = blocks * (c == 64 ? 1 : 2);
+    *nbias_parts = blocks;
+    return hipGetLastError();
+}
+
+// =========================================================================================
 // Warp-specialised form of conv3x3_wgrad_f16x3_kernel (same arithmetic, same partial-tile output).
 // The one-role kernel spends 42 % of a tile waiting for its global loads and 31 % splitting / transposing them into
 // LDS; only 21 % is MFMA (tools/tile_phase_prof.md), and its 144 accumulator registers leave no room to prefetch.

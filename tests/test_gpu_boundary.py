@@ -162,7 +162,7 @@ def test_hip_graph_replay_is_bit_identical(case):
 
 
 OPTIONS = [('conv_precision', 0), ('conv_variant', 1), ('conv_variant', 5), ('wgrad_ws', 0), ('wgrad_ws', 1), ('out_variant', 0),
-           ('out_dgrad_variant', 0), ('fuse_l0', 0), ('zigzag', 0)]
+           ('out_dgrad_variant', 0), ('out_bwd_fused', 0), ('fuse_l0', 0), ('zigzag', 0)]
 
 
 @pytest.mark.parametrize('opt,val', OPTIONS)
@@ -188,6 +188,27 @@ def test_every_kernel_option_end_to_end(opt, val):
         if abs(ss - ref_ss) > 2e-3 * ref_ss + 1e-12:
             bad.append((n, ss, ref_ss))
     assert not bad, bad
+
+
+@pytest.mark.parametrize('case', ['cfg1_dsprites_k4_t3_b4', 'cfg3_clevr_k7_t5_b1'])
+def test_fused_output_conv_backward_equals_the_two_kernel_form(case):
+    """Training: dec_out_bwd_fused_f16x3_kernel (one pass over the saved activation) against dec_out_dgrad_f16x3_kernel +
+    dec_out_wgrad_gemm_f16x3_kernel (same packs, same three split passes; only tile shapes / summation order differ)."""
+    g = load_golden(case)
+    arch, params, x, eps, _ = golden_setup(g)
+    m = make_hip_model(arch, params)
+    xd, ed = x.to(DEV), eps.to(DEV)
+    grads = []
+    for fused in (1, 0):
+        m.set_option('out_bwd_fused', fused)
+        m.zero_grad(set_to_none=True)
+        loss = m(xd, ed)
+        loss.backward()
+        grads.append((loss.item(), {n: p.grad.double().cpu() for n, p in m.named_parameters()}))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[1][0])
+    for n in grads[0][1]:
+        a, b = grads[0][1][n], grads[1][1][n]
+        assert float((a - b).norm()) <= 2e-5 * float(b.norm()) + 1e-12, (n, float((a - b).norm()), float(b.norm()))
 
 
 def test_reference_written_checkpoint_continues_on_the_gpu():
