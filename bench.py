@@ -123,6 +123,9 @@ def cpu_baseline(args, arch, params, mode):
     return cb, (x, eps, ref_elbos, ref_grads)
 
 
+PMC_PIPE = None      # matrix-pipe utilisation and shader clock of the same PMC passes (the chip clocks to its power budget)
+
+
 def pmc_traffic(args, B, K):
     """HBM bytes per launch of the dominant kernels from the tracked PMC file (tools/pmc_to_json.py writes it from rocprofv3
     --pmc passes: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  Quoted only while the file describes THIS tree (source
@@ -139,6 +142,9 @@ def pmc_traffic(args, B, K):
         if (shape.get('config'), shape.get('batch'), shape.get('slots')) != (args.config, B, K) or args.conv_precision != 1:
             return None, 'profiles/r02_pmc.json was measured on another shape'
         per = {k: v['hbm_bytes_per_launch'] for k, v in rec['kernels'].items()}
+        global PMC_PIPE
+        PMC_PIPE = {k: {f: v[f] for f in ('mfma_util', 'clock_ghz', 'mfma_rate_of_2p4ghz_peak') if f in v}
+                    for k, v in rec['kernels'].items()}
         return per, f"profiles/r02_pmc.json ({rec.get('commit', '?')[:10]})"
     except Exception as e:                                  # a malformed file must not break the bench line
         return None, f'profiles/r02_pmc.json unreadable: {e}'
@@ -273,7 +279,7 @@ def main():
         # the kernel executes SPLIT_PASSES f16 MFMAs per algorithmic (fp32-class) multiply-add: the peak for ALGORITHMIC
         # FLOPs is the dense f16 MFMA peak divided by the number of passes
         peak = PEAK_F16_MFMA_TFLOPS / SPLIT_PASSES
-        kname = (f'conv3x3_tile_f16x3_kernel<{C_},{C_}> + conv3x3_wgrad_f16x3_ws_kernel<{C_},{C_}> (decoder 3x3 conv {C_}->{C_}: '
+        kname = (f'conv3x3_ws_f16x3_kernel<{C_},EPI> + conv3x3_wgrad_f16x3_ws_kernel<{C_},{C_}> (decoder 3x3 conv {C_}->{C_}: '
                  f'fwd, dgrad, wgrad launches; fp32 in/out, operands split into f16 hi+lo, 3 f16 MFMAs, fp32 accumulate)')
     else:
         peak = PEAK_F32_MFMA_TFLOPS
@@ -291,7 +297,7 @@ def main():
                 for c in DOMINANT if c in prof}
     roofline = dict(bound='mfma', kernel=kname, achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
                     frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_src,
-                    traffic_per_kernel=per_kernel_traffic,
+                    traffic_per_kernel=per_kernel_traffic, matrix_pipe_pmc=PMC_PIPE,
                     flops_per_launch=flops_per_launch, avg_launch_ms=round(dom_ms / max(dom_n, 1), 4),
                     launches=dom_n, events_in_timed_region=timed_events, per_form=per_form,
                     kernel_time_share=round(dom_ms / max(dom_n, 1) * (dom_n / (args.steps if timed_events else 2)) / ms_per_step, 4),

@@ -127,7 +127,9 @@ __host__ __device__ constexpr size_t conv_wpk_elems(int cin, int cout) {
 
 // EPI_L0ROWS: data-gradient form whose result is not stored but reduced to per-row left / interior / right sums
 // (rows_p[n][y][tile x][3][C]): the input of the broadcast layer's backward when nothing else needs d(pre-activation 0)
-enum ConvEpilogue { EPI_BIAS_ELU = 0, EPI_MUL_ELUGRAD = 1, EPI_NONE = 2, EPI_OUT4 = 3, EPI_L0ROWS = 4 };
+// EPI_L0ROWSX (training): the same plus a fourth sum per row and tile, sum_x lin[x] * value over ALL the tile's columns
+// (rows_p[n][y][tile x][4][C]): with it the coordinate-channel gradients of the broadcast layer follow from row sums too
+enum ConvEpilogue { EPI_BIAS_ELU = 0, EPI_MUL_ELUGRAD = 1, EPI_NONE = 2, EPI_OUT4 = 3, EPI_L0ROWS = 4, EPI_L0ROWSX = 5 };
 
 // ---- launchers (each returns hipError_t from the launch) -------------------------------
 hipError_t launch_pack_conv_weights(hipStream_t st, const float* src_oihw, int O, int I, int cin_pad,
@@ -165,6 +167,10 @@ constexpr int MCOPY_MAX = 24;
 struct MultiCopy { const float* src[MCOPY_MAX]; float* dst[MCOPY_MAX]; int n[MCOPY_MAX]; int count; };
 hipError_t launch_multi_copy(hipStream_t st, const MultiCopy& mc);
 hipError_t launch_l0_reduce_cls_tiles(hipStream_t st, const float* rows_p, float* Rc, int N, int S, int C);
+hipError_t launch_l0_reduce_cls_tiles_x(hipStream_t st, const float* rows_p, float* Rc, float* rown, int N, int S, int C);
+hipError_t launch_l0_rowsum_acc(hipStream_t st, const float* rown, int N, int S, int C, float alpha, int first, float* Rsum);
+hipError_t launch_l0_coord_grads_rows(hipStream_t st, const float* Rsum, const float* lin, int S, int C, int L, float alpha,
+                                      float* gw, float* gb);
 hipError_t launch_l0_reduce(hipStream_t st, const float* dpre, float* rows, float* Rc, int N, int S, int C, float* Dpart,
                             float* Dacc, float alpha, int first);
 hipError_t launch_dz_latent(hipStream_t st, const float* Rc, const float* wclsT, const float* pm, const float* plv,

@@ -48,6 +48,7 @@ struct Buffers {               // workspace carve-up for one batch size / mode
     std::vector<std::vector<float*>> ract;     // [iter][layer] refinement activations
     // training only
     float *wg_part = nullptr, *wg_part_b = nullptr, *wg_fold = nullptr, *Dsum = nullptr, *Dpart = nullptr, *RT = nullptr, *tmp_lz = nullptr;
+    float *rown = nullptr, *Rsum = nullptr;     // training row-sum form of the broadcast layer's backward (EPI_L0ROWSX)
     float *ddm = nullptr, *ddv = nullptr, *dc1 = nullptr, *dgates = nullptr, *dxin = nullptr, *ds = nullptr,
           *dpooled = nullptr;
     float* carry_h[2] = {nullptr, nullptr};
@@ -272,7 +273,7 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
     b.img_terms = a.take<float>((size_t)(T + 1) * B * 2);
     b.scal = a.take<float>((size_t)(T + 1) * 3 + 4);
     b.rows = a.take<float>((size_t)N * h->S * 3 * Cd);
-    b.rows_p = a.take<float>((size_t)N * h->S * (h->S / 16 > 0 ? h->S / 16 : 1) * 3 * Cd);   // per-tile row sums (EPI_L0ROWS)
+    b.rows_p = a.take<float>((size_t)N * h->S * (h->S / 16 > 0 ? h->S / 16 : 1) * (mode == 1 ? 4 : 3) * Cd);   // per-tile row sums (EPI_L0ROWS / EPI_L0ROWSX)
     b.Rc = a.take<float>((size_t)N * 9 * Cd);
     b.pm = a.take<float>((size_t)N * L);
     b.plv = a.take<float>((size_t)N * L);
@@ -338,6 +339,8 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
         b.wg_fold = a.take<float>((size_t)WGRAD_FOLD * 9 * Cmax * Cmax);
         b.Dsum = a.take<float>((size_t)P * Cd);
         b.Dpart = a.take<float>((size_t)l0_dgroups(N) * P * Cd);
+        b.rown = a.take<float>((size_t)N * h->S * 4 * Cd);
+        b.Rsum = a.take<float>((size_t)h->S * 4 * Cd);
         b.RT = a.take<float>((size_t)N * 9 * Cd);
         b.tmp_lz = a.take<float>((size_t)L * 9 * Cd);
         // ddm / ddv / dgates / ds: one instance per iteration (weight gradients of the head in one pass over all of them)
@@ -453,9 +456,12 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         if (h->precision == 1 && h->out_dgrad_variant)
             PROF(h, st, "dec_out_dgrad", launch_dec_out_dgrad_f16x3(st, b.g, h->dec_out_wb16, h->dec_out_meta, b.act[Dd - 1],
                                                                      b.dpre[cur], N, h->S, Cd, conv_ws_ok(h) ? b.tmax_dpre[cur] : nullptr));
-        else
+        else {
             PROF(h, st, "dec_out_dgrad", launch_conv3x3_tile(st, b.g, h->dec_out_wb, nullptr, b.act[Dd - 1], b.dpre[cur], N,
                                                              h->S, 4, Cd, EPI_MUL_ELUGRAD));
+            // the generic kernel leaves no per-cell max for the weight-stationary conv that consumes its output
+            if (conv_ws_ok(h)) HIPCHK(h, launch_cell_max(st, b.dpre[cur], b.tmax_dpre[cur], N, h->S, Cd));
+        }
     }
     if (train_alpha != 0.f && !out_fused) {
         const int wi = param_index(h, "decoder.conv.weight"), bi = param_index(h, "decoder.conv.bias");
@@ -489,22 +495,28 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         }
         // Inference: nothing but the broadcast layer's row / class sums needs d(pre-activation 0), so the last data gradient
         // reduces its tile to per-row sums in its epilogue (EPI_L0ROWS) and the 0.94 GB tensor is neither written nor re-read.
-        fused_l0 = l == 1 && train_alpha == 0.f && h->precision == 1 && h->fuse_l0;
+        // Training: the same with one more sum per row (EPI_L0ROWSX, weight-stationary kernel only): class sums for dz and the
+        // latent-channel weights, slot-summed row sums for the coordinate-channel weights and the bias.
+        fused_l0 = l == 1 && h->precision == 1 && h->fuse_l0 && (train_alpha == 0.f || conv_ws_ok(h));
         if (h->precision == 1)
             PROF(h, st, "conv_tile_dgrad", conv_f16x3(h, st, b.dpre[cur], h->dec_wb16[l], h->dec_wsb[l], h->dec_wmeta[l] + 2, nullptr,
                                                       b.act[l - 1], fused_l0 ? b.rows_p : b.dpre[cur ^ 1], b.tmax_dpre[cur],
                                                       b.tmax_dpre[cur ^ 1], N, h->S, Cd, Cd,
-                                                      fused_l0 ? EPI_L0ROWS : EPI_MUL_ELUGRAD, l));
+                                                      fused_l0 ? (train_alpha != 0.f ? EPI_L0ROWSX : EPI_L0ROWS) : EPI_MUL_ELUGRAD, l));
         else
             PROF(h, st, "conv_tile_dgrad", launch_conv3x3_tile(st, b.dpre[cur], h->dec_wb[l], nullptr, b.act[l - 1],
                                                                b.dpre[cur ^ 1], N, h->S, Cd, Cd, EPI_MUL_ELUGRAD));
         cur ^= 1;
     }
     *dpre0 = b.dpre[cur];
-    if (fused_l0) {
+    if (fused_l0 && train_alpha == 0.f) {
         PROF(h, st, "l0_reduce", launch_l0_reduce_cls_tiles(st, b.rows_p, b.Rc, N, h->S, Cd));
         return IODINE_OK;
     }
+    if (fused_l0) {
+        PROF(h, st, "l0_reduce", launch_l0_reduce_cls_tiles_x(st, b.rows_p, b.Rc, b.rown, N, h->S, Cd));
+        HIPCHK(h, launch_l0_rowsum_acc(st, b.rown, N, h->S, Cd, train_alpha, it == 0, b.Rsum));
+    } else
     // row / class sums of dpre0 for dz; in training the same read also feeds the slot-summed gradient map, which is
     // accumulated (with this pass's factor) over the T+1 passes and consumed once after the last one
     PROF(h, st, "l0_reduce", launch_l0_reduce(st, *dpre0, b.rows, b.Rc, N, h->S, Cd, train_alpha != 0.f ? b.Dpart : nullptr,
@@ -516,8 +528,10 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         HIPCHK(h, launch_l0_tap_sums(st, b.Rc, b.RT, N, Cd));
         HIPCHK(h, launch_sgemm(st, 1, 0, h->L, 9 * Cd, N, 1.f, b.z[it], h->L, b.RT, 9 * Cd, 0.f, b.tmp_lz, 9 * Cd));
         HIPCHK(h, launch_l0_scatter_z(st, b.tmp_lz, h->L, Cd, train_alpha, h->gacc[wi]));
-        if (it == h->T)
-            HIPCHK(h, launch_l0_coord_grads(st, b.Dsum, h->lin, h->S, Cd, h->L, 1.f, h->gacc[wi], h->gacc[bi], b.wg_part));
+        if (it == h->T) {
+            if (fused_l0) HIPCHK(h, launch_l0_coord_grads_rows(st, b.Rsum, h->lin, h->S, Cd, h->L, 1.f, h->gacc[wi], h->gacc[bi]));
+            else HIPCHK(h, launch_l0_coord_grads(st, b.Dsum, h->lin, h->S, Cd, h->L, 1.f, h->gacc[wi], h->gacc[bi], b.wg_part));
+        }
     }
     return IODINE_OK;
 }

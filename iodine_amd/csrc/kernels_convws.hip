@@ -130,6 +130,23 @@ IOD_DEVINL float fresh_scale(float mx)
     return __uint_as_float((unsigned)(127 + se) << 23);
 }
 
+// sum over the pixel lanes of the whole-pixel layout (lane = pl * SEGS + seg): all lanes with the same seg, result in every
+// lane.  gfx950 lane swaps / DPP, no LDS: v_permlane32_swap (halves), v_permlane16_swap (odd / even rows of 16), row_ror:8.
+template <int SEGS>
+IOD_DEVINL float pixel_lane_sum(float v)
+{
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    if constexpr (SEGS == 8) v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));
+    return v;
+}
+
 template <int C, int EPI>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
@@ -147,10 +164,12 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
     constexpr int NIN = (NPX * 8 + 255) / 256;   // float4 loads per thread per chunk (6)
     constexpr int NS = (RW + 2) * 3;             // fragment steps per chunk: halo rows x column shifts
     constexpr bool XPOSE = true;                 // epilogue through LDS: whole-pixel (1 KB contiguous) loads / stores (every form)
-    constexpr bool GRADF = EPI == EPI_MUL_ELUGRAD || EPI == EPI_L0ROWS;   // data-gradient forms: x ELU'(aux)
+    constexpr bool ROWS = EPI == EPI_L0ROWS || EPI == EPI_L0ROWSX;        // row-sum forms: nothing stored per pixel
+    constexpr int NQ = EPI == EPI_L0ROWSX ? 4 : 3;                        // sums per row and tile
+    constexpr bool GRADF = EPI == EPI_MUL_ELUGRAD || ROWS;                // data-gradient forms: x ELU'(aux)
     constexpr int SEGS = C / 4, PPI = 64 / SEGS, NEP = 32 / PPI;      // whole-pixel layout: float4 segments, pixels / instruction
     static_assert(C == 64 || C == 32, "channel counts of the shipped decoders");
-    static_assert(EPI == EPI_BIAS_ELU || EPI == EPI_MUL_ELUGRAD || EPI == EPI_L0ROWS, "epilogue");
+    static_assert(EPI == EPI_BIAS_ELU || EPI == EPI_MUL_ELUGRAD || ROWS, "epilogue");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
 
@@ -194,6 +213,9 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
             for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(wh[c][t]), "+v"(wl[c][t]));      // opaque: stay in registers
     }
     const float inv_w = wmeta[1];
+    // (training row-sum form) step of torch.linspace(-1, 1, S), wave-uniform: computed once, kept in a scalar register
+    const float xstep_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(__fdiv_rn(2.f, (float)(S - 1)))));
+    (void)xstep_u;
 
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_b;
     // staging: float4 k of this thread = halo pixel (tid >> 3) + 32 k, channel quad tid & 7 (idle lanes of the last one write
@@ -284,7 +306,8 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
     };
 
     // stores (and the tile-max store) an epilogue leaves in flight: YOUNGER than the input loads of the stage after it
-    constexpr int NST = EPI == EPI_L0ROWS ? 0 : NEP + 1;
+    // (row-sum forms: per wave and tile 2 rows x {left, interior, right [, weighted]} float4 stores by the lanes of pixel lane 0)
+    constexpr int NST = ROWS ? 2 * NQ : NEP + 1;
 
 #define WS_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
     struct Frag { f16x8 h, l; };
@@ -482,9 +505,29 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
             // read would be issued, and waited for, on its own)
             // (data-gradient form: in two batches - the ELU' operand occupies NEP float4s of its own)
             constexpr int PB = GRADF ? NEP / 2 : NEP;
+            // (training row-sum form) x-coordinate-weighted row sum: a fourth running sum next to the others does not fit the
+            // register budget while the first half of the ELU' operand is live (3 - 11 spilled loop invariants, each reload a
+            // vmcnt(0) inside the load-issue hook: +30 % kernel time), so the wave's FIRST tile row leaves its finished values
+            // in LDS and is weighted in a short second pass; the second row is weighted on the fly.
+            constexpr int XJ0 = EPI == EPI_L0ROWSX ? NEP / 2 : NEP;    // instructions j >= XJ0 accumulate the weighted sum directly
+            f32x4 rxw = f32x4{0.f, 0.f, 0.f, 0.f};
+            (void)rxw;
+            // torch.linspace(-1, 1, S)[x] as iodine_linspace_host builds it (separately rounded multiply and add)
+            auto lin_at = [&](int x) {
+                return x < (S >> 1) ? __fadd_rn(-1.f, __fmul_rn(xstep_u, (float)x)) : __fsub_rn(1.f, __fmul_rn(xstep_u, (float)(S - 1 - x)));
+            };
+            auto xw_row_done = [&](int row) {                          // lane sums + store of one row's weighted sum
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rxw[e] = pixel_lane_sum<SEGS>(rxw[e]);
+                if (pl == 0) {
+                    float* rpx = out + ((((size_t)n * S + ty * 8 + 2 * wv + row) * tiles_x + tx) * NQ) * C + seg * 4;
+                    *reinterpret_cast<f32x4*>(rpx + 3 * C) = rxw;
+                }
+            };
+            (void)lin_at; (void)xw_row_done;
             f32x4 pv[PB];
-            f32x4 rtot = f32x4{0.f, 0.f, 0.f, 0.f}, rleft = rtot;      // (row-sum form) running sums of the current tile row
-            (void)rtot; (void)rleft;
+            f32x4 rtot = f32x4{0.f, 0.f, 0.f, 0.f};                    // (row-sum forms) running interior sum of the current tile row
+            (void)rtot;
             ws_static_for<0, NEP>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 if constexpr (j % PB == 0) {
@@ -498,39 +541,60 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
                 } else {
                     // aux loads return in order; behind ax[j]: NEP - 1 - j younger aux loads + (storing form) the j stores already issued
                     f32x4& axj = ax[j];
-                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(EPI == EPI_MUL_ELUGRAD ? NEP - 1 : NEP - 1 - j) : "memory");
+                    // (row-sum forms: + the row-sum stores issued so far - 3 per finished row, the left-border one of this row;
+                    // vmcnt counts in issue order, so younger stores need not be waited for)
+                    constexpr int IPRW = 16 / PPI;
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ROWS ? NEP - 1 - j + 3 * (j / IPRW) + (j % IPRW ? 1 : 0) : NEP - 1) : "memory");
                     asm volatile("" : "+v"(axj));
                     v.x *= elu1_grad_from_out(axj.x); v.y *= elu1_grad_from_out(axj.y);
                     v.z *= elu1_grad_from_out(axj.z); v.w *= elu1_grad_from_out(axj.w);
                 }
-                if constexpr (EPI == EPI_L0ROWS) {
-                    // EPI_L0ROWS (inference, layer 1): d(pre-activation 0) is not stored but reduced to per-row left-border /
-                    // interior / right-border column sums rows_p[n][gy][tx][3][C] (the input of l0_reduce_cls_tiles).
-                    // Instruction j = pixels (j % IPR) * PPI + pl of tile row j / IPR; the sum over the PPI pixel lanes is xor
-                    // shuffles (lane = pl * SEGS + seg); border pixels exist only in the first / last tile column.
+                if constexpr (EPI == EPI_L0ROWSX) {
+                    constexpr int IPRX = 16 / PPI;
+                    if constexpr (j < XJ0) {          // first row: the finished value goes back to this lane's own LDS slot
+#ifndef WS_ABL_X_NOWB
+                        *reinterpret_cast<f32x4*>(const_cast<unsigned char*>(sr) + j * PPI * EPS) = v;
+#endif
+                    } else {
+#ifndef WS_ABL_X_NOINLINE
+                        const float xwj = lin_at(tx * 16 + pl + (j % IPRX) * PPI);
+                        if constexpr (j % IPRX == 0) rxw = v * xwj;
+                        else rxw += v * xwj;
+                        if constexpr (j % IPRX == IPRX - 1) xw_row_done(j / IPRX);
+#endif
+                    }
+                }
+                if constexpr (ROWS) {
+                    // Row-sum forms (layer 1): d(pre-activation 0) is not stored but reduced to per-row left-border / interior /
+                    // right-border column sums rows_p[n][gy][tx][NQ][C] (the input of l0_reduce_cls_tiles); the training form
+                    // adds sum_x lin[x] * v over all columns of the tile (coordinate-channel gradients of the broadcast layer).
+                    // Instruction j = pixels (j % IPR) * PPI + pl of tile row j / IPR; the sum over the PPI pixel lanes is lane
+                    // swaps in the VALU (lane = pl * SEGS + seg; __shfl_xor would go through the LDS crossbar); border pixels
+                    // exist only in the first / last tile column.
                     constexpr int IPR = 16 / PPI;
                     const bool lt = tx == 0, rt = tx == tiles_x - 1;
                     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if constexpr (j % IPR == 0) { rtot = v; rleft = (lt && pl == 0) ? v : zero; }
-                    else rtot += v;
-                    if constexpr (j % IPR == IPR - 1) {
-                        f32x4 Rb = (rt && pl == PPI - 1) ? v : zero, Lb = rleft, tot = rtot;
+                    float* rp = out + ((((size_t)n * S + ty * 8 + 2 * wv + j / IPR) * tiles_x + tx) * NQ) * C + seg * 4;
+                    if constexpr (j % IPR == 0) {
+                        // image column 0 is pixel lane 0 of the row's first instruction: stored at once, kept out of the interior sum
+                        const bool isl = lt && pl == 0;
+                        if (pl == 0) *reinterpret_cast<f32x4*>(rp) = isl ? v : zero;
+                        rtot = isl ? zero : v;
+                    } else if constexpr (j % IPR == IPR - 1) {
+                        const bool isr = rt && pl == PPI - 1;
+                        f32x4 Rb = isr ? v : zero, tot = rtot + (isr ? zero : v);
 #pragma unroll
-                        for (int off = SEGS; off < 64; off <<= 1)
+                        for (int e = 0; e < 4; ++e) tot[e] = pixel_lane_sum<SEGS>(tot[e]);
+                        if (rt) {                                     // block-uniform
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) tot[e] += __shfl_xor(tot[e], off, 64);
-                        if (lt || rt) {                               // block-uniform
-#pragma unroll
-                            for (int off = SEGS; off < 64; off <<= 1)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { Lb[e] += __shfl_xor(Lb[e], off, 64); Rb[e] += __shfl_xor(Rb[e], off, 64); }
+                            for (int e = 0; e < 4; ++e) Rb[e] = pixel_lane_sum<SEGS>(Rb[e]);
                         }
                         if (pl == 0) {
-                            float* rp = out + ((((size_t)n * S + ty * 8 + 2 * wv + j / IPR) * tiles_x + tx) * 3) * C + seg * 4;
-                            *reinterpret_cast<f32x4*>(rp) = Lb;
-                            *reinterpret_cast<f32x4*>(rp + C) = tot - Lb - Rb;
+                            *reinterpret_cast<f32x4*>(rp + C) = tot;
                             *reinterpret_cast<f32x4*>(rp + 2 * C) = Rb;
                         }
+                    } else {
+                        rtot += v;
                     }
                 } else {
                     vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
@@ -543,7 +607,23 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
 #endif
                 }
             });
-            if constexpr (EPI != EPI_L0ROWS) {
+#ifndef WS_ABL_X_NOPASSB
+            if constexpr (EPI == EPI_L0ROWSX) {
+                // second pass over the wave's first tile row (values left in LDS above; the ELU' operand is dead by now)
+                constexpr int IPRX = 16 / PPI;
+                static_assert(XJ0 == IPRX && XJ0 <= PB, "one tile row, one LDS read batch");
+#pragma unroll
+                for (int i = 0; i < XJ0; ++i) pv[i] = *reinterpret_cast<const f32x4*>(sr + i * PPI * EPS);
+#pragma unroll
+                for (int i = 0; i < XJ0; ++i) {
+                    const float xwj = lin_at(tx * 16 + pl + i * PPI);
+                    if (i == 0) rxw = pv[i] * xwj;
+                    else rxw += pv[i] * xwj;
+                }
+                xw_row_done(0);
+            }
+#endif
+            if constexpr (!ROWS) {
                 // the wave's share of the cell max of this OUTPUT tile (side buffer for the consumer of `out`)
                 vmax = wave_max_f32(vmax);
                 const int tt = rev ? ntiles - 1 - t : t;
@@ -641,10 +721,10 @@ hipError_t launch_conv3x3_ws_f16x3(hipStream_t st, const float* in, const void* 
                                    int epi, int rev)
 {
     // power-of-two image sizes only; the per-cell max of the INPUT (tmax_in, launch_cell_max or the producer's epilogue) is required
-    if (S < 16 || (S & (S - 1)) != 0 || !tmax_in || (epi != EPI_L0ROWS && !tmax_out)) return hipErrorInvalidValue;
+    if (S < 16 || (S & (S - 1)) != 0 || !tmax_in || (epi != EPI_L0ROWS && epi != EPI_L0ROWSX && !tmax_out)) return hipErrorInvalidValue;
 #define WS_CASE(CC, EP) if (c == CC && epi == EP) return launch_ws_inst<CC, EP>(st, in, wpk, wmeta, bias, aux, out, tmax_in, tmax_out, N, S, rev);
-    WS_CASE(64, EPI_BIAS_ELU) WS_CASE(64, EPI_MUL_ELUGRAD) WS_CASE(64, EPI_L0ROWS)
-    WS_CASE(32, EPI_BIAS_ELU) WS_CASE(32, EPI_MUL_ELUGRAD) WS_CASE(32, EPI_L0ROWS)
+    WS_CASE(64, EPI_BIAS_ELU) WS_CASE(64, EPI_MUL_ELUGRAD) WS_CASE(64, EPI_L0ROWS) WS_CASE(64, EPI_L0ROWSX)
+    WS_CASE(32, EPI_BIAS_ELU) WS_CASE(32, EPI_MUL_ELUGRAD) WS_CASE(32, EPI_L0ROWS) WS_CASE(32, EPI_L0ROWSX)
 #undef WS_CASE
     return hipErrorInvalidValue;
 }

@@ -295,6 +295,83 @@ __global__ void l0_reduce_cls_tiles_kernel(const float* __restrict__ rows_p, flo
     }
 }
 
+// Training form: rows_p[n][y][tile x][4][C] from the EPI_L0ROWSX epilogue (fourth value = x-coordinate-weighted sum).  Same
+// class sums Rc[n][9][C] (same order of additions as above), and the per-row sums over the tile columns go to
+// rown[n][y][4][C]: their sum over the slot-images (l0_rowsum_acc_kernel) is all the coordinate-channel and bias gradients
+// of the broadcast layer need, so d(pre-activation 0) is never stored in training either.
+__global__ __launch_bounds__(1024)
+void l0_reduce_cls_tiles_x_kernel(const float* __restrict__ rows_p, float* __restrict__ Rc, float* __restrict__ rown, int S, int C,
+                                  int tiles)
+{
+    __shared__ float s_mid[4][256];
+    const int n = blockIdx.x, W = 4 * C;
+    const int t = threadIdx.x % W, slice = threadIdx.x / W;      // t = q*C + co
+    const float* src = rows_p + (size_t)n * S * tiles * W + t;
+    float* dst = rown + (size_t)n * S * W + t;
+    auto row_sum = [&](int y) {
+        const float* p = src + (size_t)y * tiles * W;
+        float a = 0.f, b = 0.f;
+        int tx = 0;
+        for (; tx + 1 < tiles; tx += 2) { a += p[(size_t)tx * W]; b += p[(size_t)(tx + 1) * W]; }
+        if (tx < tiles) a += p[(size_t)tx * W];
+        return a + b;
+    };
+    const int per = (S - 2 + 3) / 4, y0 = 1 + slice * per, y1 = min(S - 1, y0 + per);
+    float a0 = 0.f, a1 = 0.f;
+    int y = y0;
+    for (; y + 1 < y1; y += 2) {
+        const float r0 = row_sum(y), r1 = row_sum(y + 1);
+        dst[(size_t)y * W] = r0; dst[(size_t)(y + 1) * W] = r1;
+        a0 += r0; a1 += r1;
+    }
+    if (y < y1) { const float r0 = row_sum(y); dst[(size_t)y * W] = r0; a0 += r0; }
+    s_mid[slice][t] = a0 + a1;
+    __syncthreads();
+    if (slice == 0) {
+        const float top = row_sum(0), bot = row_sum(S - 1);
+        dst[0] = top; dst[(size_t)(S - 1) * W] = bot;
+        if (t < 3 * C) {
+            float* o = Rc + (size_t)n * 9 * C;
+            const int cc = t / C, co = t % C;
+            o[(0 * 3 + cc) * C + co] = top;
+            o[(1 * 3 + cc) * C + co] = (s_mid[0][t] + s_mid[1][t]) + (s_mid[2][t] + s_mid[3][t]);
+            o[(2 * 3 + cc) * C + co] = bot;
+        }
+    }
+}
+
+// Rsum[i] = (first ? 0 : Rsum[i]) + alpha * sum_n rown[n][i], i < len: fixed order over the slot-images (four interleaved partial
+// sums), one thread per element
+__global__ void l0_rowsum_acc_kernel(const float* __restrict__ rown, int N, int len, float alpha, int first, float* __restrict__ Rsum)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const float* p = rown + i;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int n = 0;
+    for (; n + 3 < N; n += 4) {
+        a0 += p[(size_t)n * len]; a1 += p[(size_t)(n + 1) * len]; a2 += p[(size_t)(n + 2) * len]; a3 += p[(size_t)(n + 3) * len];
+    }
+    for (; n < N; ++n) a0 += p[(size_t)n * len];
+    const float s = alpha * ((a0 + a1) + (a2 + a3));
+    Rsum[i] = first ? s : Rsum[i] + s;
+}
+
+hipError_t launch_l0_reduce_cls_tiles_x(hipStream_t st, const float* rows_p, float* Rc, float* rown, int N, int S, int C)
+{
+    IOD_XSKIP(32);
+    if (C > 64 || S % 16 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(l0_reduce_cls_tiles_x_kernel, dim3(N), dim3(4 * 4 * C), 0, st, rows_p, Rc, rown, S, C, S / 16);
+    return hipGetLastError();
+}
+
+hipError_t launch_l0_rowsum_acc(hipStream_t st, const float* rown, int N, int S, int C, float alpha, int first, float* Rsum)
+{
+    const int len = S * 4 * C;
+    hipLaunchKernelGGL(l0_rowsum_acc_kernel, dim3((len + 255) / 256), dim3(256), 0, st, rown, N, len, alpha, first, Rsum);
+    return hipGetLastError();
+}
+
 hipError_t launch_l0_reduce_cls_tiles(hipStream_t st, const float* rows_p, float* Rc, int N, int S, int C)
 {
     IOD_XSKIP(32);

@@ -559,6 +559,64 @@ hipError_t launch_l0_coord_grads(hipStream_t st, const float* D, const float* li
     return hipGetLastError();
 }
 
+// The same gradients from Rsum[y][4][C] = sum over passes and slot-images of the per-row sums {left column, interior columns,
+// right column, sum_x lin[x] * d} of d = d(pre-activation 0) (EPI_L0ROWSX epilogue -> l0_reduce_cls_tiles_x -> l0_rowsum_acc):
+// no [pixels x C] gradient map is needed.  Per row y with L, M, R, X:
+//   bias                          += L + M + R
+//   y-channel, tap (ky, kx)       += lin[y + ky - 1] * {M + R, L + M + R, L + M}[kx]             (rows with y + ky - 1 inside)
+//   x-channel, tap (ky, kx)       += {(X - lin[0] L) - step (M + R),  X,  (X - lin[S-1] R) + step (L + M)}[kx]
+// where lin[x -+ 1] = lin[x] -+ step is used for the shifted weights (step = 2 / (S - 1); the table's own differences deviate
+// from it by rounding only, <= 1.2e-7 absolute on weights in [-1, 1]).  One block: thread = (channel, row slice).
+__global__ __launch_bounds__(256)
+void l0_coord_rows_kernel(const float* __restrict__ Rsum, const float* __restrict__ lin, int S, int C, int L, float alpha,
+                          float* __restrict__ gw, float* __restrict__ gb)
+{
+    __shared__ float s_cg[4 * 19 * 64];
+    const int tid = threadIdx.x, c = tid % C, sl = tid / C, NSL = 256 / C;
+    const float step = __fdiv_rn(2.f, (float)(S - 1)), lin0 = lin[0], linS = lin[S - 1];
+    float acc[19];
+#pragma unroll
+    for (int j = 0; j < 19; ++j) acc[j] = 0.f;
+    for (int y = sl; y < S; y += NSL) {
+        const float* r = Rsum + (size_t)y * 4 * C + c;
+        const float Lv = r[0], Mv = r[C], Rv = r[2 * C], Xv = r[3 * C];
+        const float rs[3] = {Mv + Rv, (Lv + Mv) + Rv, Lv + Mv};
+        const float ax[3] = {(Xv - lin0 * Lv) - step * (Mv + Rv), Xv, (Xv - linS * Rv) + step * (Lv + Mv)};
+        acc[18] += rs[1];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            if (yy < 0 || yy >= S) continue;
+            const float ly = lin[yy];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                acc[ky * 3 + kx] += ax[kx];
+                acc[9 + ky * 3 + kx] += ly * rs[kx];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 19; ++j) s_cg[(sl * 19 + j) * C + c] = acc[j];
+    __syncthreads();
+    for (int e = tid; e < 19 * C; e += 256) {
+        float t = 0.f;
+        for (int q = 0; q < NSL; ++q) t += s_cg[q * 19 * C + e];
+        t *= alpha;
+        const int j = e / C, co = e % C;
+        if (j < 9) gw[((size_t)co * (L + 2) + L) * 9 + j] += t;
+        else if (j < 18) gw[((size_t)co * (L + 2) + L + 1) * 9 + (j - 9)] += t;
+        else gb[co] += t;
+    }
+}
+
+hipError_t launch_l0_coord_grads_rows(hipStream_t st, const float* Rsum, const float* lin, int S, int C, int L, float alpha,
+                                      float* gw, float* gb)
+{
+    if (C > 64 || 256 % C != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(l0_coord_rows_kernel, dim3(1), dim3(256), 0, st, Rsum, lin, S, C, L, alpha, gw, gb);
+    return hipGetLastError();
+}
+
 // =========================================================================================
 // loss and pointwise pieces of the head backward
 // =========================================================================================
@@ -1187,8 +1245,8 @@ hipError_t launch_dec_out_wgrad_gemm_f16x3(hipStream_t st, const float* a, const
 // kernels it replaces (same packs, same three passes; the data gradient's power-of-two scale is a function of the tile's own
 // halo only, so its result does not depend on which block ran the tile).
 // =========================================================================================
-template <int C>
-__global__ __launch_bounds__(256, C == 64 ? 3 : 4)
+template <int C, bool PF>
+__global__ __launch_bounds__(256, (C == 64 && PF) ? 3 : 4)
 void dec_out_bwd_fused_f16x3_kernel(const float* __restrict__ a, const float* __restrict__ g, const uint4* __restrict__ wpk,
                                     const float* __restrict__ wmeta, float* __restrict__ out, float* __restrict__ tmax,
                                     float* __restrict__ part, float* __restrict__ part_b, int S, int ntiles, int tiles_x,
@@ -1343,7 +1401,7 @@ void dec_out_bwd_fused_f16x3_kernel(const float* __restrict__ a, const float* __
         // next tile's loads fly under the MFMAs and the epilogue (rg is free; the activation goes to a second set)
         float4 rbn[NBU][2], rgn[2];
         const bool has_next = tile + (int)gridDim.x < ntiles;
-        if (has_next) fetch(tile + gridDim.x, rbn, rgn);
+        if (PF && has_next) fetch(tile + gridDim.x, rbn, rgn);
 
         // ---- weight gradient: rows j = (tap, co), columns ci, K = the pixels of one tile row per MFMA ----
 #pragma unroll
@@ -1425,9 +1483,13 @@ void dec_out_bwd_fused_f16x3_kernel(const float* __restrict__ a, const float* __
         // 8 x 16 cells of the side buffer: this 4-row tile owns two of its cell's four slots
         prev_tm = (((n * (S / 8) + (ty >> 1)) * tiles_x + tx) * 4) + 2 * (ty & 1);
         if (has_next) {
+            if (PF) {
 #pragma unroll
-            for (int k = 0; k < NBU; ++k) { rb[k][0] = rbn[k][0]; rb[k][1] = rbn[k][1]; }
-            rg[0] = rgn[0]; rg[1] = rgn[1];
+                for (int k = 0; k < NBU; ++k) { rb[k][0] = rbn[k][0]; rb[k][1] = rbn[k][1]; }
+                rg[0] = rgn[0]; rg[1] = rgn[1];
+            } else {
+                fetch(tile + gridDim.x, rb, rg);
+            }
         }
     }
     __syncthreads();
@@ -1462,14 +1524,16 @@ hipError_t launch_dec_out_bwd_fused_f16x3(hipStream_t st, const float* a, const 
 {
     if (S % 16 != 0 || (c != 64 && c != 32)) return hipErrorInvalidValue;
     const int tiles_x = S / 16, tiles_y = S / 4, ntiles = N * tiles_x * tiles_y;
-    const int cap = c == 64 ? 768 : 1024;                 // resident blocks: 3 resp. 4 per CU (register budget), persistent
+    static const int pf = getenv("IODINE_OUTBWD_PF") ? atoi(getenv("IODINE_OUTBWD_PF")) : 1;
+    static const int capenv = getenv("IODINE_OUTBWD_CAP") ? atoi(getenv("IODINE_OUTBWD_CAP")) : 0;
+    const int cap = capenv ? capenv : ((c == 64 && pf) ? 768 : 1024);   // resident blocks: 3 resp. 4 per CU, persistent
     const int blocks = ntiles < cap ? ntiles : cap;
-    if (c == 64)
-        hipLaunchKernelGGL((dec_out_bwd_fused_f16x3_kernel<64>), dim3(blocks), dim3(256), 0, st, a, g, (const uint4*)wpk, wmeta,
-                           out, tmax, part, part_b, S, ntiles, tiles_x, tiles_y);
-    else
-        hipLaunchKernelGGL((dec_out_bwd_fused_f16x3_kernel<32>), dim3(blocks), dim3(256), 0, st, a, g, (const uint4*)wpk, wmeta,
-                           out, tmax, part, part_b, S, ntiles, tiles_x, tiles_y);
+#define IOD_LAUNCH_OUTBWD(CC, PFV)                                                                                            \
+    hipLaunchKernelGGL((dec_out_bwd_fused_f16x3_kernel<CC, PFV>), dim3(blocks), dim3(256), 0, st, a, g, (const uint4*)wpk, wmeta, \
+                       out, tmax, part, part_b, S, ntiles, tiles_x, tiles_y)
+    if (c == 64) { if (pf) IOD_LAUNCH_OUTBWD(64, true); else IOD_LAUNCH_OUTBWD(64, false); }
+    else { if (pf) IOD_LAUNCH_OUTBWD(32, true); else IOD_LAUNCH_OUTBWD(32, false); }
+#undef IOD_LAUNCH_OUTBWD
     *nparts = blocks * (c == 64 ? 1 : 2);
     *nbias_parts = blocks;
     return hipGetLastError();

@@ -46,6 +46,23 @@ def per_launch(outdir, tag):
     return acc, names
 
 
+def clocks(outdir, tag):
+    """Shader clock while each kernel category runs: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel duration of the same
+    dispatch (kernel trace of the same pass).  The chip clocks to its power budget (MI355X_MICROARCH.md "DVFS give-back"), so
+    matrix-pipe utilisation has to be read together with this number."""
+    acc = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(outdir, tag, '**', '*counter_collection.csv'), recursive=True):
+        kt = f.replace('counter_collection', 'kernel_trace')
+        if not os.path.exists(kt):
+            continue
+        dur = {r['Dispatch_Id']: int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in csv.DictReader(open(kt))}
+        for r in csv.DictReader(open(f)):
+            c = category(r['Kernel_Name'])
+            if c and r['Counter_Name'] == 'GRBM_GUI_ACTIVE' and dur.get(r['Dispatch_Id'], 0) > 0:
+                acc[c].append((float(r['Counter_Value']) / 8.0 / dur[r['Dispatch_Id']], dur[r['Dispatch_Id']] / 1e3))
+    return acc
+
+
 def main():
     outdir = sys.argv[1]
     cfg = 'dsprites' if 'dsprites' in sys.argv[2:] else 'clevr6'
@@ -57,6 +74,7 @@ def main():
     fetch, names = per_launch(outdir, 'FETCH_SIZE')
     write, _ = per_launch(outdir, 'WRITE_SIZE')
     mfma, _ = per_launch(outdir, 'SQ_VALU_MFMA_BUSY_CYCLES')
+    clk = clocks(outdir, 'SQ_VALU_MFMA_BUSY_CYCLES')
     kernels = {}
     for c in ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad'):
         if c not in fetch or c not in write:
@@ -72,6 +90,11 @@ def main():
             k['mfma_busy_cycles'] = round(busy)
             k['grbm_gui_active'] = round(gui)
             k['mfma_util'] = round(busy / (gui / 8.0 * 1024.0), 4)        # busy cycles / (cycles per XCD x 1024 SIMDs)
+            if clk.get(c):
+                k['clock_ghz'] = round(sum(v[0] for v in clk[c]) / len(clk[c]), 3)
+                k['us_in_pmc_pass'] = round(sum(v[1] for v in clk[c]) / len(clk[c]), 1)
+                # fraction of the 2.4 GHz matrix peak the launch sustains: utilisation x clock / 2.4
+                k['mfma_rate_of_2p4ghz_peak'] = round(k['mfma_util'] * k['clock_ghz'] / 2.4, 4)
         kernels[c] = k
     rec = dict(commit=commit, csrc_sha256=source_digest(),
                shape=dict(config=cfg, batch=32, slots=7 if cfg == 'clevr6' else 6),
