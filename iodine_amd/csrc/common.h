@@ -148,7 +148,7 @@ hipError_t launch_pixel_pass1(hipStream_t st, const float* x4, const float* dec,
 hipError_t launch_pixel_finalize(hipStream_t st, const double* part, int B, int K, int P, int use_ln,
                                  float* lnstat, float* ll_img);
 hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec, const float* lnstat,
-                              const float* lin, float* enc, int B, int K, int S, float sigma);
+                              const float* lin, float* enc, int B, int K, int S, float sigma, float* enc_sh = nullptr);
 hipError_t launch_final_out(hipStream_t st, const float* dec, float* pred, float* mask, float* mean, float* logits,
                             int B, int K, int P);
 // kernels_misc.hip
@@ -250,11 +250,15 @@ inline size_t conv_ws_tmax_floats(int N, int S) { return (size_t)N * (S / 16) * 
 
 // kernels_refine.hip: split-fp16 stride-2 convs of the refinement network
 hipError_t launch_conv3x3_s2_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
-                                   float* out, int N, int S, int cin_real, int cout);
+                                   float* out, int N, int S, int cin_real, int cout, const float* addmap = nullptr, int kdiv = 0);
+hipError_t launch_ref_split_weights(hipStream_t st, const float* w, int O, float* w_slot, float* w_sh);
+hipError_t launch_ref_unsplit_grad(hipStream_t st, const float* g20, int O, float* gw);
+hipError_t launch_enc_join(hipStream_t st, const float* enck, const float* encs, float* enc, int N, int K, int P);
 hipError_t launch_conv3x3_s2_dgrad_f16x3(hipStream_t st, const float* d, const void* wpk, const float* wmeta, const float* aux,
                                          float* out, int N, int S, int c);
 hipError_t launch_conv3x3_s2_wgrad_f16x3(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
-                                         int S, int ci_real, int nco, int* nparts, int* cipad, int* nbias_parts);
+                                         int S, int ci_real, int nco, int* nparts, int* cipad, int* nbias_parts,
+                                         const float* a2 = nullptr, int kdiv = 0);
 hipError_t launch_dec_out_wgrad_gemm_f16x3(hipStream_t st, const float* a, const float* g, float* part, float* part_b, int N,
                                            int S, int c, int* nparts, int* nbias_parts);
 hipError_t launch_dec_out_bwd_fused_f16x3(hipStream_t st, const float* a, const float* g, const void* wpk, const float* wmeta,

@@ -45,6 +45,8 @@ struct Buffers {               // workspace carve-up for one batch size / mode
     float* tmax_dpre[2] = {nullptr, nullptr};  // the same for the two gradient buffers
     // per-iteration buffers: index i (training keeps all T(+1) copies, inference aliases them)
     std::vector<float*> z, g_pm, g_plv, latent, enc, pooled, u, gates, xin, h, c;
+    std::vector<float*> enck, encs;             // split refinement input: per-slot [N][P][12], per-image [B][P][8] (alias enc's memory)
+    float* rmap = nullptr;                      // split first refinement layer: conv of the per-image channels, [B][S/2][S/2][Cr]
     std::vector<std::vector<float*>> ract;     // [iter][layer] refinement activations
     // training only
     float *wg_part = nullptr, *wg_part_b = nullptr, *wg_fold = nullptr, *Dsum = nullptr, *Dpart = nullptr, *RT = nullptr, *tmp_lz = nullptr;
@@ -89,6 +91,8 @@ struct iodine_handle {
     int out_dgrad_variant = 1;                  // output conv data gradient: 1 = split-fp16 streaming kernel, 0 = generic fp32 tile kernel
     int out_bwd_fused = 1;                      // training: output conv data + weight gradient in one pass over the activation
     int fuse_l0 = 1;                            // inference: layer-1 data gradient reduces straight to the layer-0 row sums
+    int refine_split = 1;                       // first refinement layer split into a per-slot and a per-image part (split-fp16 path)
+    bool fwd_split = false;                     // the form the saved training forward used
     int out_variant = 1;                        // output conv forward: 1 = streaming (fragments straight from global), 0 = LDS-staged
     int zigzag = 1;                             // odd decoder layers walk the tiles backwards (Infinity Cache reuse)
     int variant = 6;                            // split-fp16 stride-1 conv: 6 = weight-stationary persistent kernel (power-of-two image sizes;
@@ -102,6 +106,9 @@ struct iodine_handle {
     float *raw_mlp_w = nullptr, *raw_wih = nullptr, *raw_whh = nullptr, *raw_wm = nullptr, *raw_wv = nullptr;
     std::vector<float*> ref_wb;
     std::vector<float*> ref_wf16, ref_wb16, ref_wmeta;     // split-fp16 packs of the stride-2 convs (+ {scale, 1/scale} x {fwd, dgrad})
+    float *ref_wk = nullptr, *ref_wsh = nullptr;           // split first layer: weights in the internal channel order [Cr][12][9], [Cr][8][9]
+    float *ref_wk16 = nullptr, *ref_wsh16 = nullptr, *ref_wkmeta = nullptr, *ref_wshmeta = nullptr;   // and their packs
+    float* ref_g20 = nullptr;                              // [Cr][20][9] weight gradient in the internal order
     std::vector<float*> gacc;                   // one per parameter, reference shapes (slices of gacc_arena)
     float* gacc_arena = nullptr;
     size_t gacc_total = 0;
@@ -303,6 +310,17 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
         float* base = a.take<float>(n_enc * (mode == 1 ? T : 1));
         b.enc.resize(T + 1);
         for (int i = 0; i <= T; ++i) b.enc[i] = (mode == 1 && i < T) ? (base ? base + (size_t)i * n_enc : nullptr) : base;
+        // split form (refine_split): the same memory as per-slot tensors [N][P][12] of all kept iterations back to back,
+        // followed by the per-image tensors [B][P][8]
+        const size_t n_k = (size_t)N * P * 12, n_s = (size_t)B * P * 8;
+        const int keep = mode == 1 ? T : 1;
+        b.enck.resize(T + 1); b.encs.resize(T + 1);
+        for (int i = 0; i <= T; ++i) {
+            const int j = (mode == 1 && i < T) ? i : 0;
+            b.enck[i] = base ? base + (size_t)j * n_k : nullptr;
+            b.encs[i] = base ? base + (size_t)keep * n_k + (size_t)j * n_s : nullptr;
+        }
+        b.rmap = a.take<float>((size_t)B * (h->S / 2) * (h->S / 2) * Cr);
     }
     per_iter(b.pooled, (size_t)N * Cr, ncopy);
     per_iter(b.u, (size_t)N * H, ncopy);
@@ -558,6 +576,8 @@ int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps
     return IODINE_OK;
 }
 
+bool refine_split_on(const iodine_handle* h);
+
 bool refine_f16_ok(const iodine_handle* h)
 {
     if (h->Cr != 64 && h->Cr != 32) return false;
@@ -566,17 +586,27 @@ bool refine_f16_ok(const iodine_handle* h)
     return true;
 }
 
+bool refine_split_on(const iodine_handle* h) { return h->refine_split && h->precision == 1 && refine_f16_ok(h); }
+
 // refine() + posterior.update() for iteration i (iodine.py:95-100 / 144-145)
 int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
 {
     Buffers& b = h->buf;
     const int N = B * h->K;
-    PROF(h, st, "pixel_pass2", launch_pixel_pass2(st, b.x4, b.dec_out, b.lnstat, h->lin, b.enc[i], B, h->K, h->S,
-                                                  (float)h->cfg.sigma));
+    // split first layer: the channels every slot of an image shares are written and convolved once per image
+    const bool split = refine_split_on(h);
+    if (save) h->fwd_split = split;
+    PROF(h, st, "pixel_pass2", launch_pixel_pass2(st, b.x4, b.dec_out, b.lnstat, h->lin, split ? b.enck[i] : b.enc[i], B, h->K, h->S,
+                                                  (float)h->cfg.sigma, split ? b.encs[i] : nullptr));
     int s = h->S;
     const float* in = b.enc[i];
     for (int l = 0; l < h->Dr; ++l) {
-        if (h->precision == 1 && refine_f16_ok(h))
+        if (l == 0 && split) {
+            PROF(h, st, "refine_conv", launch_conv3x3_s2_f16x3(st, b.encs[i], h->ref_wsh16, h->ref_wshmeta, nullptr, b.rmap, B, s, 8,
+                                                               h->Cr));
+            PROF(h, st, "refine_conv", launch_conv3x3_s2_f16x3(st, b.enck[i], h->ref_wk16, h->ref_wkmeta, h->ref_b[0], b.ract[i][0], N,
+                                                               s, 12, h->Cr, b.rmap, h->K));
+        } else if (h->precision == 1 && refine_f16_ok(h))
             PROF(h, st, "refine_conv", launch_conv3x3_s2_f16x3(st, in, h->ref_wf16[l], h->ref_wmeta[l], h->ref_b[l],
                                                                b.ract[i][l], N, s, l == 0 ? 20 : h->Cr, h->Cr));
         else
@@ -655,7 +685,7 @@ std::vector<uintptr_t> graph_key(const iodine_handle* h, int entry, int batch, s
 {
     std::vector<uintptr_t> k = {(uintptr_t)entry, (uintptr_t)batch, (uintptr_t)h->stop_after, (uintptr_t)h->precision,
                                 (uintptr_t)h->variant, (uintptr_t)h->wgrad_ws, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_variant,
-                                (uintptr_t)h->out_dgrad_variant, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->zigzag, (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
+                                (uintptr_t)h->out_dgrad_variant, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)h->zigzag, (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
     for (const void* p : ptrs) k.push_back((uintptr_t)p);
     return k;
 }
@@ -730,6 +760,10 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
         ALLOC(h->ref_wmeta[l], (size_t)4);
         if (l > 0) ALLOC(h->ref_wb16[l], (size_t)(Cr / 16) * 9 * 2 * 2 * Cr * 4);
     }
+    // split first layer: one 16-channel chunk each for the per-slot (12 real) and the per-image (8 real) channels
+    ALLOC(h->ref_wk, (size_t)Cr * 12 * 9); ALLOC(h->ref_wsh, (size_t)Cr * 8 * 9); ALLOC(h->ref_g20, (size_t)Cr * 20 * 9);
+    ALLOC(h->ref_wk16, (size_t)9 * 2 * 2 * Cr * 4); ALLOC(h->ref_wsh16, (size_t)9 * 2 * 2 * Cr * 4);
+    ALLOC(h->ref_wkmeta, (size_t)4); ALLOC(h->ref_wshmeta, (size_t)4);
     // gradient accumulators: ONE buffer, parameters back to back in named_parameters() order (the layout the wrapper's
     // flat gradient buffer has too), so that zeroing and the final scale-and-add are one launch each
     h->gacc.assign(h->params.size(), nullptr);
@@ -834,6 +868,10 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
             if (l > 0)
                 HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cr, Cr, Cr, Cr, 2, h->ref_wmeta[l] + 2, h->ref_wb16[l]));
         }
+        // split first layer (refine_split): the same weights in the internal channel order, packed as two 16-channel convs
+        HIPCHK(h, launch_ref_split_weights(st, P("refine.mlc.layers.0.weight"), Cr, h->ref_wk, h->ref_wsh));
+        HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wk, Cr, 12, 16, Cr, 0, h->ref_wkmeta, h->ref_wk16));
+        HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wsh, Cr, 8, 16, Cr, 0, h->ref_wshmeta, h->ref_wsh16));
     }
     auto copy_raw = [&](float* dst, const std::string& name) {
         return queue_copy(dst, P(name), h->params[param_index(h, name)].numel());
@@ -893,6 +931,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "out_dgrad_variant")) { h->out_dgrad_variant = value != 0; return IODINE_OK; }
     if (!strcmp(key, "out_bwd_fused")) { h->out_bwd_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "fuse_l0")) { h->fuse_l0 = value != 0; return IODINE_OK; }
+    if (!strcmp(key, "refine_split")) { h->refine_split = value != 0; return IODINE_OK; }
     if (!strcmp(key, "out_variant")) { h->out_variant = value != 0; return IODINE_OK; }
     if (!strcmp(key, "zigzag")) { h->zigzag = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {
@@ -1152,7 +1191,17 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
             const int cip = l == 0 ? 20 : Cr, ireal = l == 0 ? 17 : Cr;
             int nparts = 0, cipad = 0;
             const std::string base = "refine.mlc.layers." + std::to_string(l);
-            if (h->precision == 1 && refine_f16_ok(h)) {
+            if (l == 0 && h->fwd_split) {
+                // split first layer: 12 per-slot + 8 per-image channels from two tensors, gradient in the internal channel
+                // order, then added to the reference layout
+                int nb = 0;
+                PROF(h, st, "refine_wgrad", launch_conv3x3_s2_wgrad_f16x3(st, b.enck[0], b.rdpre[0], b.wg_part, b.wg_part_b, NT, sz[0],
+                                                                          20, Cr, &nparts, &cipad, &nb, b.encs[0], h->K));
+                HIPCHK(h, hipMemsetAsync(h->ref_g20, 0, (size_t)Cr * 20 * 9 * sizeof(float), st));
+                HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, 20, 20, 1.f, h->ref_g20, b.wg_fold,
+                                              b.wg_part_b, nb, G(base + ".bias")));
+                HIPCHK(h, launch_ref_unsplit_grad(st, h->ref_g20, Cr, G(base + ".weight")));
+            } else if (h->precision == 1 && refine_f16_ok(h)) {
                 int nb = 0;
                 PROF(h, st, "refine_wgrad", launch_conv3x3_s2_wgrad_f16x3(st, in, b.rdpre[l], b.wg_part, b.wg_part_b, NT, sz[l],
                                                                           cip, Cr, &nparts, &cipad, &nb));
@@ -1230,7 +1279,17 @@ int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter
     if (s == "z") { src = b.z[iter]; n = N * L; }
     else if (s == "dec_out") { src = b.dec_out; n = N * P * 4; }
     else if (s == "g") { src = b.g; n = N * P * 4; }
-    else if (s == "enc") { src = b.enc[iter]; n = N * P * 20; }
+    else if (s == "enc") {
+        n = N * P * 20;
+        if (refine_split_on(h)) {                          // joined back into the reference's 17 (+3 pad) channel order
+            if (n_floats) *n_floats = n;
+            if (!dst) return IODINE_OK;
+            if (n > max_floats) return h->fail(IODINE_ERR_INVALID, "iodine_debug_copy: destination too small");
+            HIPCHK(h, launch_enc_join((hipStream_t)stream, b.enck[iter], b.encs[iter], dst, (int)N, h->K, (int)P));
+            return IODINE_OK;
+        }
+        src = b.enc[iter];
+    }
     else if (s == "latent") { src = b.latent[iter]; n = N * 4 * L; }
     else if (s == "g_pm") { src = b.g_pm[iter]; n = N * L; }
     else if (s == "g_plv") { src = b.g_plv[iter]; n = N * L; }

@@ -191,8 +191,21 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
     };
 #define WS_BLOAD4(dst, voff, rsrc, soff) \
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory")
+// cache policy of the output stores (experiment hook): 0 default, 1 nt, 2 sc1, 3 sc0 sc1
+#ifndef WS_STORE_POLICY
+#define WS_STORE_POLICY 0
+#endif
+#if WS_STORE_POLICY == 1
+#define WS_STORE_MOD " nt"
+#elif WS_STORE_POLICY == 2
+#define WS_STORE_MOD " sc1"
+#elif WS_STORE_POLICY == 3
+#define WS_STORE_MOD " sc0 sc1"
+#else
+#define WS_STORE_MOD ""
+#endif
 #define WS_BSTORE4(src, voff, rsrc, soff) \
-    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(src), "v"(voff), "s"(rsrc), "s"(soff) : "memory")
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen" WS_STORE_MOD "\n\ts_nop 1" :: "v"(src), "v"(voff), "s"(rsrc), "s"(soff) : "memory")
 #define WS_SGPR_SETTLE(rsrc, soff) asm volatile("s_nop 4" :: "s"(rsrc), "s"(soff) : "memory")
 
     // ---- this wave's weight slice -> registers (once per block) ----

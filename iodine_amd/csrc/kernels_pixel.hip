@@ -178,11 +178,16 @@ __global__ void pixel_finalize_kernel(const double* __restrict__ part, int nblk,
 }
 
 // ---- pass 2: write the refinement input, NHWC with 20 channels (17 + 3 zero pad) -----------------
-template <int K>
+// SPLIT form (split first refinement layer): the 11 channels that differ between the slots of an image go to
+//   enc[n][p][12]    = mean rgb, mask, mask logit, mask posterior, LN(d mean) rgb, LN(d mask), LN(leave-one-out), 0
+// and the 6 channels every slot of an image shares, once per image, to
+//   enc_sh[b][p][8]  = image rgb, LN(pixel likelihood), coordinate x, coordinate y, 0, 0
+// (294 -> 176 + 17 MB per iteration at cfg3; the shared part is convolved once per image instead of once per slot).
+template <int K, bool SPLIT>
 __global__ __launch_bounds__(PIX_BLOCK)
 void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict__ dec,
                         const float* __restrict__ lnstat, const float* __restrict__ lin, float* __restrict__ enc,
-                        int P, int S, int ppb, float inv2s2, float invs2, float lconst)
+                        float* __restrict__ enc_sh, int P, int S, int ppb, float inv2s2, float invs2, float lconst)
 {
     const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
     const float4* dec_b = dec + (size_t)b * K * P;
@@ -207,6 +212,45 @@ void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict_
 #pragma unroll
         for (int k = 0; k < K; ++k) psum += t.pk[k];
         const float cx = lin[p % S], cy = lin[p / S];
+        if constexpr (SPLIT) {
+            float4* tw8 = reinterpret_cast<float4*>(s_tr[wv] + lane * 8);
+            tw8[0] = make_float4(xv.x, xv.y, xv.z, (t.like - s_ln[6]) * s_ln[7]);      // LN statistics of slot 0: the same for every slot
+            tw8[1] = make_float4(cx, cy, 0.f, 0.f);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float4* o = reinterpret_cast<float4*>(enc_sh + ((size_t)b * P + p0) * 8);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = lane + 64 * j;
+                if (q < nvalid * 2) o[q] = trd[q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float* ln = s_ln + k * 8;
+                const float loo = (t.mix - t.m[k] * t.pk[k]) / (1.f - t.m[k] + 1e-5f);
+                float4* tw12 = reinterpret_cast<float4*>(s_tr[wv] + lane * 12);
+                tw12[0] = make_float4(t.mu[k][0], t.mu[k][1], t.mu[k][2], t.m[k]);
+                tw12[1] = make_float4(t.logit[k], t.pk[k] / psum, (t.g1[k][0] - ln[0]) * ln[1], (t.g1[k][1] - ln[0]) * ln[1]);
+                tw12[2] = make_float4((t.g1[k][2] - ln[0]) * ln[1], (t.g2[k] - ln[2]) * ln[3], (loo - ln[4]) * ln[5], 0.f);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float4* ok = reinterpret_cast<float4*>(enc + (((size_t)b * K + k) * P + p0) * 12);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int q = lane + 64 * j;
+                    if (q < nvalid * 3) ok[q] = trd[q];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float* ln = s_ln + k * 8;
@@ -302,7 +346,7 @@ hipError_t launch_pixel_finalize(hipStream_t st, const double* part, int B, int 
 }
 
 hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec, const float* lnstat,
-                              const float* lin, float* enc, int B, int K, int S, float sigma)
+                              const float* lin, float* enc, int B, int K, int S, float sigma, float* enc_sh)
 {
     IOD_XSKIP(8);
     const int P = S * S;
@@ -310,8 +354,12 @@ hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec,
     const float inv2s2 = 1.f / (2.f * sigma * sigma), invs2 = 1.f / (sigma * sigma);
     const float lconst = (float)(-log((double)sigma) - 0.5 * log(2.0 * M_PI));
     switch (K) {
-#define CASE(KK) case KK: hipLaunchKernelGGL((pixel_pass2_kernel<KK>), dim3(nblk, B), dim3(PIX_BLOCK), 0, st, \
-        (const float4*)x4, (const float4*)dec, lnstat, lin, enc, P, S, ppb, inv2s2, invs2, lconst); break;
+#define CASE(KK) case KK: \
+        if (enc_sh) hipLaunchKernelGGL((pixel_pass2_kernel<KK, true>), dim3(nblk, B), dim3(PIX_BLOCK), 0, st, \
+            (const float4*)x4, (const float4*)dec, lnstat, lin, enc, enc_sh, P, S, ppb, inv2s2, invs2, lconst); \
+        else hipLaunchKernelGGL((pixel_pass2_kernel<KK, false>), dim3(nblk, B), dim3(PIX_BLOCK), 0, st, \
+            (const float4*)x4, (const float4*)dec, lnstat, lin, enc, enc_sh, P, S, ppb, inv2s2, invs2, lconst); \
+        break;
         FOR_EACH_K(CASE)
 #undef CASE
         default: return hipErrorInvalidValue;

@@ -38,7 +38,7 @@ __host__ __device__ constexpr int s2_fwd_sb(int i) { return 3 - i; }
 template <int CIN_REAL, int CIN, int COUT, int MODE, int SBT>
 IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
                              const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
-                             int Sc, int tiles, unsigned char* smem_b)
+                             int Sc, int tiles, int kdiv, unsigned char* smem_b)
 {
     constexpr int NC16 = CIN / 16;
     constexpr int NSTAGE = MODE == 0 ? 4 * NC16 : NC16;
@@ -242,9 +242,15 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
                 float4 v = make_float4(acc[mt][nt][4 * g4] * inv_ws, acc[mt][nt][4 * g4 + 1] * inv_ws,
                                        acc[mt][nt][4 * g4 + 2] * inv_ws, acc[mt][nt][4 * g4 + 3] * inv_ws);
                 if (MODE == 0) {
+                    float4* dst = reinterpret_cast<float4*>(out + (size_t)((n * Sc + Y) * Sc + X) * COUT + c0);
+                    if (!bias) { *dst = v; continue; }       // raw form (block-uniform): the per-image part of a split first layer
                     const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
-                    *reinterpret_cast<float4*>(out + (size_t)((n * Sc + Y) * Sc + X) * COUT + c0) =
-                        make_float4(elu1_fast_r(v.x + bv.x), elu1_fast_r(v.y + bv.y), elu1_fast_r(v.z + bv.z), elu1_fast_r(v.w + bv.w));
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (kdiv) {                              // + the per-image map of the channels all slots of an image share
+                        const float4 mv = *reinterpret_cast<const float4*>(aux + (size_t)(((n / kdiv) * Sc + Y) * Sc + X) * COUT + c0);
+                        v.x += mv.x; v.y += mv.y; v.z += mv.z; v.w += mv.w;
+                    }
+                    *dst = make_float4(elu1_fast_r(v.x), elu1_fast_r(v.y), elu1_fast_r(v.z), elu1_fast_r(v.w));
                 } else {
                     const size_t o = (size_t)((n * Sf + 2 * Y + (SBT >> 1)) * Sf + 2 * X + (SBT & 1)) * COUT + c0;
                     const float4 a4 = *reinterpret_cast<const float4*>(aux + o);
@@ -262,24 +268,24 @@ template <int CIN_REAL, int CIN, int COUT, int MODE>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_s2_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
                              const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
-                             int Sc, int tiles)
+                             int Sc, int tiles, int kdiv)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s2[];
     if (MODE == 0) {
-        conv_s2_body<CIN_REAL, CIN, COUT, 0, 0>(in, wpk, wmeta, bias, aux, out, Sc, tiles, smem_s2);
+        conv_s2_body<CIN_REAL, CIN, COUT, 0, 0>(in, wpk, wmeta, bias, aux, out, Sc, tiles, kdiv, smem_s2);
     } else {
         switch (3 - (int)blockIdx.y) {                       // heaviest class (4 taps) is dispatched first
-        case 0: conv_s2_body<CIN_REAL, CIN, COUT, 1, 0>(in, wpk, wmeta, bias, aux, out, Sc, tiles, smem_s2); break;
-        case 1: conv_s2_body<CIN_REAL, CIN, COUT, 1, 1>(in, wpk, wmeta, bias, aux, out, Sc, tiles, smem_s2); break;
-        case 2: conv_s2_body<CIN_REAL, CIN, COUT, 1, 2>(in, wpk, wmeta, bias, aux, out, Sc, tiles, smem_s2); break;
-        default: conv_s2_body<CIN_REAL, CIN, COUT, 1, 3>(in, wpk, wmeta, bias, aux, out, Sc, tiles, smem_s2); break;
+        case 0: conv_s2_body<CIN_REAL, CIN, COUT, 1, 0>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2); break;
+        case 1: conv_s2_body<CIN_REAL, CIN, COUT, 1, 1>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2); break;
+        case 2: conv_s2_body<CIN_REAL, CIN, COUT, 1, 2>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2); break;
+        default: conv_s2_body<CIN_REAL, CIN, COUT, 1, 3>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2); break;
         }
     }
 }
 
 template <int CIN_REAL, int CIN, int COUT, int MODE>
 hipError_t launch_s2_inst(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
-                          const float* aux, float* out, int N, int Sc)
+                          const float* aux, float* out, int N, int Sc, int kdiv = 0)
 {
     constexpr size_t lds = (size_t)(17 * 17 + 1) * 80 + (size_t)4 * 4 * COUT * 16 + 16;
     static bool attr_set = false;
@@ -291,7 +297,7 @@ hipError_t launch_s2_inst(hipStream_t st, const float* in, const void* wpk, cons
     }
     const int tiles = (Sc + 15) / 16;
     hipLaunchKernelGGL((conv3x3_s2_f16x3_kernel<CIN_REAL, CIN, COUT, MODE>), dim3(N * tiles * tiles, MODE == 0 ? 1 : 4),
-                       dim3(256), lds, st, in, reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, Sc, tiles);
+                       dim3(256), lds, st, in, reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, Sc, tiles, kdiv);
     return hipGetLastError();
 }
 
@@ -299,14 +305,18 @@ hipError_t launch_s2_inst(hipStream_t st, const float* in, const void* wpk, cons
 
 // Forward stride-2 conv + bias + ELU.  S = fine (input) size, even; cin_real = floats per input pixel (20 for the
 // 17-channel encoding, packed with cin_pad = 32), wpk = launch_pack_conv_weights_f16(.., cin_pad, cout, tflip 0).
+// Split first layer (the encoding's channels that all slots of an image share are convolved once per image):
+//   bias == nullptr          raw result, no bias / ELU (the per-image part; cin_real 8, packed with cin_pad 16)
+//   addmap != nullptr, kdiv  out = ELU(conv + bias + addmap[n / kdiv])   (the per-slot part; cin_real 12, cin_pad 16)
 hipError_t launch_conv3x3_s2_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
-                                   float* out, int N, int S, int cin_real, int cout)
+                                   float* out, int N, int S, int cin_real, int cout, const float* addmap, int kdiv)
 {
     IOD_XSKIP(512);
-    if (S % 2 != 0 || S < 2) return hipErrorInvalidValue;
+    if (S % 2 != 0 || S < 2 || (addmap != nullptr) != (kdiv > 0)) return hipErrorInvalidValue;
 #define S2F_CASE(CR, CP, CO) \
-    if (cin_real == CR && cout == CO) return launch_s2_inst<CR, CP, CO, 0>(st, in, wpk, wmeta, bias, nullptr, out, N, S / 2);
+    if (cin_real == CR && cout == CO) return launch_s2_inst<CR, CP, CO, 0>(st, in, wpk, wmeta, bias, addmap, out, N, S / 2, kdiv);
     S2F_CASE(20, 32, 64) S2F_CASE(64, 64, 64) S2F_CASE(20, 32, 32) S2F_CASE(32, 32, 32)
+    S2F_CASE(12, 16, 64) S2F_CASE(8, 16, 64) S2F_CASE(12, 16, 32) S2F_CASE(8, 16, 32)
 #undef S2F_CASE
     return hipErrorInvalidValue;
 }
@@ -337,7 +347,8 @@ namespace {
 template <int CI_REAL, int CI, int NCO, int TH>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_s2_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __restrict__ d, float* __restrict__ part,
-                                   float* __restrict__ part_b, int Sc, int ntiles, int tiles_x, int tiles_y)
+                                   float* __restrict__ part_b, int Sc, int ntiles, int tiles_x, int tiles_y,
+                                   const float* __restrict__ a2, int kdiv)
 {
     constexpr int MT = CI / 32, NTT = NCO / 32, KS = 4 / (MT * NTT);
     static_assert(TH % KS == 0, "tile rows must split evenly over the K-split waves");
@@ -377,7 +388,10 @@ void conv3x3_s2_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __r
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y;
         const int n = t / tiles_y;
-        const float* a_n = a + (size_t)n * Sf * Sf * CI_REAL;
+        // split first layer (a2 != nullptr, CI_REAL == 20): channels 0..11 from the per-slot tensor a[n] (12 floats per pixel),
+        // channels 12..19 from the per-image tensor a2[n / kdiv] (8 floats per pixel)
+        const float* a_n = a + (size_t)n * Sf * Sf * (a2 ? 12 : CI_REAL);
+        const float* a2_n = a2 ? a2 + (size_t)(n / kdiv) * Sf * Sf * 8 : nullptr;
         const float* d_n = d + (size_t)n * Sc * Sc * NCO;
 
         float4 ra[NAU][2], rd[NDU][2];
@@ -392,8 +406,11 @@ void conv3x3_s2_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __r
             const int fx0 = 2 * (tx * 16 + 2 * j) + par, fx1 = fx0 + 2;
             ra[k][0] = ra[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (u < NA_UNITS && fy >= 0 && fy < Sf) {
-                if (fx0 >= 0 && fx0 < Sf) ra[k][0] = *reinterpret_cast<const float4*>(a_n + ((size_t)fy * Sf + fx0) * CI_REAL + c4 * 4);
-                if (fx1 >= 0 && fx1 < Sf) ra[k][1] = *reinterpret_cast<const float4*>(a_n + ((size_t)fy * Sf + fx1) * CI_REAL + c4 * 4);
+                const bool sh = a2_n && c4 >= 3;
+                const float* src = sh ? a2_n + (c4 - 3) * 4 : a_n + c4 * 4;
+                const int pst = a2_n ? (sh ? 8 : 12) : CI_REAL;
+                if (fx0 >= 0 && fx0 < Sf) ra[k][0] = *reinterpret_cast<const float4*>(src + ((size_t)fy * Sf + fx0) * pst);
+                if (fx1 >= 0 && fx1 < Sf) ra[k][1] = *reinterpret_cast<const float4*>(src + ((size_t)fy * Sf + fx1) * pst);
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -531,7 +548,7 @@ void conv3x3_s2_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __r
 
 template <int CI_REAL, int CI, int NCO, int TH>
 hipError_t launch_s2_wgrad_inst(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N, int Sc,
-                                int* nparts, int* cipad, int* nbias_parts)
+                                int* nparts, int* cipad, int* nbias_parts, const float* a2, int kdiv)
 {
     constexpr int MT = CI / 32, NTT = NCO / 32, KS = 4 / (MT * NTT);
     constexpr size_t lds = (size_t)(2 * CI * (2 * TH + 1) * 20 + 2 * NCO * (TH * 8 + 4)) * 4 + 32;
@@ -546,7 +563,7 @@ hipError_t launch_s2_wgrad_inst(hipStream_t st, const float* a, const float* d, 
     const int tiles_x = (Sc + 15) / 16, tiles_y = (Sc + TH - 1) / TH, ntiles = N * tiles_x * tiles_y;
     const int blocks = ntiles < 512 ? ntiles : 512;
     hipLaunchKernelGGL((conv3x3_s2_wgrad_f16x3_kernel<CI_REAL, CI, NCO, TH>), dim3(blocks), dim3(256), lds, st, a, d, part,
-                       part_b, Sc, ntiles, tiles_x, tiles_y);
+                       part_b, Sc, ntiles, tiles_x, tiles_y, a2, kdiv);
     *nparts = blocks * KS;
     *cipad = CI;
     *nbias_parts = blocks;
@@ -557,14 +574,85 @@ hipError_t launch_s2_wgrad_inst(hipStream_t st, const float* a, const float* d, 
 
 // part: nparts x [9][cipad][nco] partial tiles (reduce with launch_wgrad_reduce), part_b: nbias_parts x [nco] bias partials.
 // S = fine (input) size, even.
+// a2 / kdiv: split first layer - 12 per-slot channels from a, 8 per-image channels from a2[n / kdiv] (ci_real 20 only).
 hipError_t launch_conv3x3_s2_wgrad_f16x3(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
-                                         int S, int ci_real, int nco, int* nparts, int* cipad, int* nbias_parts)
+                                         int S, int ci_real, int nco, int* nparts, int* cipad, int* nbias_parts,
+                                         const float* a2, int kdiv)
 {
     IOD_XSKIP(1024);
-    if (S % 2 != 0 || S < 2) return hipErrorInvalidValue;
+    if (S % 2 != 0 || S < 2 || (a2 && (ci_real != 20 || kdiv < 1))) return hipErrorInvalidValue;
 #define S2W_CASE(CR, CP, CO, TH) \
-    if (ci_real == CR && nco == CO) return launch_s2_wgrad_inst<CR, CP, CO, TH>(st, a, d, part, part_b, N, S / 2, nparts, cipad, nbias_parts);
+    if (ci_real == CR && nco == CO) return launch_s2_wgrad_inst<CR, CP, CO, TH>(st, a, d, part, part_b, N, S / 2, nparts, cipad, nbias_parts, a2, kdiv);
     S2W_CASE(64, 64, 64, 2) S2W_CASE(20, 32, 64, 4) S2W_CASE(32, 32, 32, 4) S2W_CASE(20, 32, 32, 4)
 #undef S2W_CASE
     return hipErrorInvalidValue;
+}
+
+// =========================================================================================
+// Split first layer of the refinement network.  The 17-channel encoding (IODINE.get_input_encoding, iodine.py:243-343) has
+// 6 channels that every slot of an image shares (image rgb, LN(pixel likelihood), the two coordinate channels) and 11 that
+// differ; a conv is linear in its input channels, so layer 0 = ELU(bias + conv_11(per slot) + conv_6(per image)): the shared
+// part is convolved once per image, the per-slot tensor shrinks from 20 to 12 floats per pixel and from two 16-channel chunks
+// (one of them 3/4 padding) to one.  Internal channel order: 0..11 per-slot (11 = pad), 12..19 per-image (18, 19 = pad).
+// =========================================================================================
+namespace {
+__device__ __constant__ int c_ref_split_map[20] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, -1, 0, 1, 2, 13, 15, 16, -1, -1};
+
+// w [O][17][9] -> w_slot [O][12][9], w_sh [O][8][9] (pad channels zero)
+__global__ void ref_split_weights_kernel(const float* __restrict__ w, int O, float* __restrict__ w_slot, float* __restrict__ w_sh)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= O * 20 * 9) return;
+    const int t = idx % 9, i = (idx / 9) % 20, o = idx / 180;
+    const int r = c_ref_split_map[i];
+    const float v = r >= 0 ? w[((size_t)o * 17 + r) * 9 + t] : 0.f;
+    if (i < 12) w_slot[((size_t)o * 12 + i) * 9 + t] = v;
+    else w_sh[((size_t)o * 8 + (i - 12)) * 9 + t] = v;
+}
+
+// gw [O][17][9] += g20 [O][20][9] in the internal channel order
+__global__ void ref_unsplit_grad_kernel(const float* __restrict__ g20, int O, float* __restrict__ gw)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= O * 20 * 9) return;
+    const int t = idx % 9, i = (idx / 9) % 20, o = idx / 180;
+    const int r = c_ref_split_map[i];
+    if (r >= 0) gw[((size_t)o * 17 + r) * 9 + t] += g20[idx];
+}
+
+// the 20-channel encoding (17 + 3 zero pad, reference channel order) from the split tensors - debug / test read-back only
+__global__ void enc_join_kernel(const float* __restrict__ enck, const float* __restrict__ encs, float* __restrict__ enc, int K, int P,
+                                size_t total)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % 20);
+    const size_t px = idx / 20, n = px / P, p = px % P;
+    float v = 0.f;
+    if (c < 17) {
+        int i = 0;
+        for (int q = 0; q < 20; ++q) if (c_ref_split_map[q] == c) i = q;
+        v = i < 12 ? enck[px * 12 + i] : encs[((n / K) * P + p) * 8 + (i - 12)];
+    }
+    enc[idx] = v;
+}
+}  // namespace
+
+hipError_t launch_ref_split_weights(hipStream_t st, const float* w, int O, float* w_slot, float* w_sh)
+{
+    hipLaunchKernelGGL(ref_split_weights_kernel, dim3((O * 180 + 255) / 256), dim3(256), 0, st, w, O, w_slot, w_sh);
+    return hipGetLastError();
+}
+
+hipError_t launch_ref_unsplit_grad(hipStream_t st, const float* g20, int O, float* gw)
+{
+    hipLaunchKernelGGL(ref_unsplit_grad_kernel, dim3((O * 180 + 255) / 256), dim3(256), 0, st, g20, O, gw);
+    return hipGetLastError();
+}
+
+hipError_t launch_enc_join(hipStream_t st, const float* enck, const float* encs, float* enc, int N, int K, int P)
+{
+    const size_t total = (size_t)N * P * 20;
+    hipLaunchKernelGGL(enc_join_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, enck, encs, enc, K, P, total);
+    return hipGetLastError();
 }

@@ -162,7 +162,7 @@ def test_hip_graph_replay_is_bit_identical(case):
 
 
 OPTIONS = [('conv_precision', 0), ('conv_variant', 1), ('conv_variant', 5), ('wgrad_ws', 0), ('wgrad_ws', 1), ('out_variant', 0),
-           ('out_dgrad_variant', 0), ('out_bwd_fused', 0), ('fuse_l0', 0), ('zigzag', 0)]
+           ('out_dgrad_variant', 0), ('out_bwd_fused', 0), ('fuse_l0', 0), ('refine_split', 0), ('zigzag', 0)]
 
 
 @pytest.mark.parametrize('opt,val', OPTIONS)
