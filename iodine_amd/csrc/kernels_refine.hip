@@ -227,38 +227,73 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
     });
 
     const float inv_ws = wmeta[1] / cur_scale;
-    // MFMAs are issued as (weights, activations): accumulator rows are channels, lane li = pixel li of the 32-px tile,
-    // registers 4g..4g+3 = channels 8g + 4kh .. +3 -> float4 epilogue traffic
+    // MFMAs are issued as (weights, activations): accumulator rows are channels, lane li = pixel li of a 32-pixel half tile,
+    // registers 4g..4g+3 = channels 8g + 4kh .. +3.  Stored directly, every instruction writes 16 bytes per lane at the pixel
+    // stride (32 partial cache lines); so each wave transposes its half tile through the (now free) staging buffers and
+    // stores WHOLE pixels (forward form): 16 lanes x 16 bytes = one pixel, 4 (C = 64) or 8 (C = 32) pixels per instruction.
+    if constexpr (MODE == 1) {
+        // data gradient: direct float4 stores (the transposed form exposes the ELU' operand's latency: 346 -> 387 us at cfg3)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int Y = ty * 16 + 4 * wv + 2 * mt + (li >> 4);
-        const int X = tx * 16 + (li & 15);
-        if (Y >= Sc || X >= Sc) continue;
+        for (int mt = 0; mt < 2; ++mt) {
+            const int Y = ty * 16 + 4 * wv + 2 * mt + (li >> 4);
+            const int X = tx * 16 + (li & 15);
+            if (Y >= Sc || X >= Sc) continue;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int c0 = nt * 32 + 8 * g4 + 4 * kh;
-                float4 v = make_float4(acc[mt][nt][4 * g4] * inv_ws, acc[mt][nt][4 * g4 + 1] * inv_ws,
-                                       acc[mt][nt][4 * g4 + 2] * inv_ws, acc[mt][nt][4 * g4 + 3] * inv_ws);
-                if (MODE == 0) {
-                    float4* dst = reinterpret_cast<float4*>(out + (size_t)((n * Sc + Y) * Sc + X) * COUT + c0);
-                    if (!bias) { *dst = v; continue; }       // raw form (block-uniform): the per-image part of a split first layer
-                    const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                    if (kdiv) {                              // + the per-image map of the channels all slots of an image share
-                        const float4 mv = *reinterpret_cast<const float4*>(aux + (size_t)(((n / kdiv) * Sc + Y) * Sc + X) * COUT + c0);
-                        v.x += mv.x; v.y += mv.y; v.z += mv.z; v.w += mv.w;
-                    }
-                    *dst = make_float4(elu1_fast_r(v.x), elu1_fast_r(v.y), elu1_fast_r(v.z), elu1_fast_r(v.w));
-                } else {
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int c0 = nt * 32 + 8 * g4 + 4 * kh;
+                    float4 v = make_float4(acc[mt][nt][4 * g4] * inv_ws, acc[mt][nt][4 * g4 + 1] * inv_ws,
+                                           acc[mt][nt][4 * g4 + 2] * inv_ws, acc[mt][nt][4 * g4 + 3] * inv_ws);
                     const size_t o = (size_t)((n * Sf + 2 * Y + (SBT >> 1)) * Sf + 2 * X + (SBT & 1)) * COUT + c0;
                     const float4 a4 = *reinterpret_cast<const float4*>(aux + o);
                     v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
                     v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
                     *reinterpret_cast<float4*>(out + o) = v;
                 }
+        }
+        return;
+    }
+    __syncthreads();                                     // every wave is done reading the last stage's LDS
+    constexpr int EPD = COUT + 4;                        // dwords per transposed pixel (conflict-free float4 writes)
+    constexpr int SEGS = COUT / 4, PPI = 64 / SEGS, NEP = 32 / PPI;
+    static_assert(4 * 32 * EPD * 4 <= IN_BYTES + 4 * TAP_U4 * 16, "transposition regions fit the staging buffers");
+    float* ep = reinterpret_cast<float*>(smem_b) + wv * 32 * EPD;
+    const int seg = lane % SEGS, pl = lane / SEGS;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<f32x4*>(ep + li * EPD + nt * 32 + 8 * g4 + 4 * kh) =
+                    f32x4{acc[mt][nt][4 * g4] * inv_ws, acc[mt][nt][4 * g4 + 1] * inv_ws, acc[mt][nt][4 * g4 + 2] * inv_ws,
+                          acc[mt][nt][4 * g4 + 3] * inv_ws};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < NEP; ++j) {
+            const int pq = j * PPI + pl;
+            const int Y = ty * 16 + 4 * wv + 2 * mt + (pq >> 4);
+            const int X = tx * 16 + (pq & 15);
+            if (Y >= Sc || X >= Sc) continue;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(ep + pq * EPD + seg * 4);
+            float4 v = make_float4(t.x, t.y, t.z, t.w);
+            const int c0 = seg * 4;
+            float4* dst = reinterpret_cast<float4*>(out + (size_t)((n * Sc + Y) * Sc + X) * COUT + c0);
+            if (!bias) { *dst = v; continue; }           // raw form (block-uniform): the per-image part of a split first layer
+            const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (kdiv) {                                  // + the per-image map of the channels all slots of an image share
+                const float4 mv = *reinterpret_cast<const float4*>(aux + (size_t)(((n / kdiv) * Sc + Y) * Sc + X) * COUT + c0);
+                v.x += mv.x; v.y += mv.y; v.z += mv.z; v.w += mv.w;
             }
+            *dst = make_float4(elu1_fast_r(v.x), elu1_fast_r(v.y), elu1_fast_r(v.z), elu1_fast_r(v.w));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
