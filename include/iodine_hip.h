@@ -177,6 +177,9 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * "out_dgrad_variant" (output conv data gradient: 1 = split-fp16 streaming kernel -- default, 0 = generic fp32 tile kernel),
  * "out_bwd_fused" (1 -- default: in training the output conv's data gradient and weight / bias gradient come from ONE pass
  * over the saved activation; 0 = two kernels, as iodine_reconstruct's data gradient + the GEMM-form weight gradient),
+ * "refine_split" (1 -- default on the split-fp16 path: the first refinement layer is computed as a per-slot conv over the 11
+ * encoding channels that differ between the slots of an image plus a per-image conv over the 6 they share; 0 = one conv
+ * over the 20-float encoding per slot; a change takes effect with the next forward),
  * "zigzag" (1 -- default: odd decoder layers walk their tiles backwards so that a launch starts on what the previous one
  * wrote last; 0 = every launch in ascending order; results identical),
  * "wgrad_ws" (split-fp16 64->64 / 32->32 weight gradient: 2 = warp-specialised, natural-order staging + transposing LDS
