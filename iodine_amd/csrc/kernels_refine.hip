@@ -217,6 +217,23 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
     prefetch_in(integral_constant<int, 0>{}, rin[0]);
     prefetch_w(integral_constant<int, 0>{});
     if constexpr (NSTAGE > 1) prefetch_in(integral_constant<int, 1>{}, rin[1]);
+    // data gradient: the ELU' operand of the whole tile in the whole-pixel layout of the epilogue (lane = 16-byte segment seg of
+    // pixel pl of an instruction), requested behind the first two stages' inputs so that it is there long before it is used
+    constexpr int E_SEGS = COUT / 4, E_PPI = 64 / E_SEGS, E_NEP = 32 / E_PPI;
+    float4 axv[MODE == 1 ? 2 : 1][MODE == 1 ? E_NEP : 1];
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < E_NEP; ++j) {
+                const int pq = j * E_PPI + lane / E_SEGS;
+                const int Y = ty * 16 + 4 * wv + 2 * mt + (pq >> 4), X = tx * 16 + (pq & 15);
+                axv[mt][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (Y < Sc && X < Sc)
+                    axv[mt][j] = *reinterpret_cast<const float4*>(
+                        aux + (size_t)((n * Sf + 2 * Y + (SBT >> 1)) * Sf + 2 * X + (SBT & 1)) * COUT + (lane % E_SEGS) * 4);
+            }
+    }
     static_for<NSTAGE>([&](auto Ic) {
         constexpr int I = decltype(Ic)::value;
         const float sc = commit(Ic, rin[I & 1]);
@@ -230,30 +247,9 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
     // MFMAs are issued as (weights, activations): accumulator rows are channels, lane li = pixel li of a 32-pixel half tile,
     // registers 4g..4g+3 = channels 8g + 4kh .. +3.  Stored directly, every instruction writes 16 bytes per lane at the pixel
     // stride (32 partial cache lines); so each wave transposes its half tile through the (now free) staging buffers and
-    // stores WHOLE pixels (forward form): 16 lanes x 16 bytes = one pixel, 4 (C = 64) or 8 (C = 32) pixels per instruction.
-    if constexpr (MODE == 1) {
-        // data gradient: direct float4 stores (the transposed form exposes the ELU' operand's latency: 346 -> 387 us at cfg3)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int Y = ty * 16 + 4 * wv + 2 * mt + (li >> 4);
-            const int X = tx * 16 + (li & 15);
-            if (Y >= Sc || X >= Sc) continue;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int c0 = nt * 32 + 8 * g4 + 4 * kh;
-                    float4 v = make_float4(acc[mt][nt][4 * g4] * inv_ws, acc[mt][nt][4 * g4 + 1] * inv_ws,
-                                           acc[mt][nt][4 * g4 + 2] * inv_ws, acc[mt][nt][4 * g4 + 3] * inv_ws);
-                    const size_t o = (size_t)((n * Sf + 2 * Y + (SBT >> 1)) * Sf + 2 * X + (SBT & 1)) * COUT + c0;
-                    const float4 a4 = *reinterpret_cast<const float4*>(aux + o);
-                    v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
-                    v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
-                    *reinterpret_cast<float4*>(out + o) = v;
-                }
-        }
-        return;
-    }
+    // stores / multiplies WHOLE pixels: 16 lanes x 16 bytes = one pixel, 4 (C = 64) or 8 (C = 32) pixels per instruction
+    // (data gradient: the ELU' operand was requested in that layout at the start - fetched only now it arrives too late:
+    // 346 -> 387 us at cfg3).
     __syncthreads();                                     // every wave is done reading the last stage's LDS
     constexpr int EPD = COUT + 4;                        // dwords per transposed pixel (conflict-free float4 writes)
     constexpr int SEGS = COUT / 4, PPI = 64 / SEGS, NEP = 32 / PPI;
@@ -281,6 +277,13 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
             const f32x4 t = *reinterpret_cast<const f32x4*>(ep + pq * EPD + seg * 4);
             float4 v = make_float4(t.x, t.y, t.z, t.w);
             const int c0 = seg * 4;
+            if constexpr (MODE == 1) {
+                const float4 a4 = axv[mt][j];
+                v.x *= elu1_grad_from_out(a4.x); v.y *= elu1_grad_from_out(a4.y);
+                v.z *= elu1_grad_from_out(a4.z); v.w *= elu1_grad_from_out(a4.w);
+                *reinterpret_cast<float4*>(out + (size_t)((n * Sf + 2 * Y + (SBT >> 1)) * Sf + 2 * X + (SBT & 1)) * COUT + c0) = v;
+                continue;
+            }
             float4* dst = reinterpret_cast<float4*>(out + (size_t)((n * Sc + Y) * Sc + X) * COUT + c0);
             if (!bias) { *dst = v; continue; }           // raw form (block-uniform): the per-image part of a split first layer
             const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
@@ -299,8 +302,11 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
 
 // MODE 0: in = fine [N][2Sc][2Sc][CIN_REAL] -> out = coarse [N][Sc][Sc][COUT], bias + ELU
 // MODE 1: in = coarse gradient [N][Sc][Sc][CIN] -> out = fine [N][2Sc][2Sc][COUT] times ELU'(aux); grid.y = parity class
+#ifndef S2_FWD_WAVES
+#define S2_FWD_WAVES 2
+#endif
 template <int CIN_REAL, int CIN, int COUT, int MODE>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, MODE == 0 ? S2_FWD_WAVES : 2)
 void conv3x3_s2_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
                              const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
                              int Sc, int tiles, int kdiv)
