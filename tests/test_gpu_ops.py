@@ -111,8 +111,8 @@ def test_conv_tile_f16x3_forward_and_dgrad(C_, S, N, mode):
 @pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 2), (64, 128, 2), (64, 16, 300), (32, 64, 9), (32, 32, 70)])
 def test_conv_weight_stationary_f16x3(C_, S, N):
     """the weight-stationary persistent kernel (op mode 10: weights in registers, per-cell max side buffer, whole-pixel
-    epilogue through LDS): forward + bias + ELU, data gradient x ELU', and the EPI_L0ROWS form that reduces the data gradient
-    to per-row left / interior / right sums"""
+    epilogue through LDS): forward + bias + ELU, data gradient x ELU', and the EPI_L0ROWS / EPI_L0ROWSX forms that reduce the data
+    gradient to per-row left / interior / right (/ x-coordinate-weighted) sums"""
     x = _rand(N, C_, S, S, seed=21)
     w = _rand(C_, C_, 3, 3, seed=22, scale=3.0 / (C_ * 9) ** 0.5)
     b = _rand(C_, seed=23, scale=0.5)
@@ -135,6 +135,12 @@ def test_conv_weight_stationary_f16x3(C_, S, N):
     want[:, :, -1, 2] = r[:, :, -1, 15]; want[:, :, -1, 1] -= r[:, :, -1, 15]
     for half in (slice(0, N // 2), slice(N // 2, N)):
         assert rel_err(rows[half], want[half].float()) < 5e-6, rel_err(rows[half], want[half].float())
+    # EPI_L0ROWSX (training): the same three sums plus sum_x linspace(-1, 1, S)[x] * value over all columns of the tile
+    rows4 = _conv_op(10, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 5, 1, (N, S, tiles, 4, C_))
+    lin = torch.linspace(-1, 1, S).double().view(1, 1, tiles, 16, 1)
+    want4 = torch.cat([want, (r * lin).sum(3, keepdim=True)], 3)
+    for half in (slice(0, N // 2), slice(N // 2, N)):
+        assert rel_err(rows4[half], want4[half].float()) < 5e-6, rel_err(rows4[half], want4[half].float())
     assert torch.equal(gotd, _conv_op(10, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 1, 1, refd.shape))   # deterministic
 
 
