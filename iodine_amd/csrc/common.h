@@ -166,8 +166,9 @@ inline int l0_dgroups(int N) { const int g = (N + 31) / 32; return g < 8 ? 8 : g
 constexpr int MCOPY_MAX = 24;
 struct MultiCopy { const float* src[MCOPY_MAX]; float* dst[MCOPY_MAX]; int n[MCOPY_MAX]; int count; };
 hipError_t launch_multi_copy(hipStream_t st, const MultiCopy& mc);
-hipError_t launch_l0_reduce_cls_tiles(hipStream_t st, const float* rows_p, float* Rc, int N, int S, int C);
-hipError_t launch_l0_reduce_cls_tiles_x(hipStream_t st, const float* rows_p, float* Rc, float* rown, int N, int S, int C);
+size_t l0_rows_scratch_floats(int N, int C);
+hipError_t launch_l0_reduce_cls_tiles(hipStream_t st, const float* rows_p, float* Rc, int N, int S, int C, float* scratch);
+hipError_t launch_l0_reduce_cls_tiles_x(hipStream_t st, const float* rows_p, float* Rc, float* rown, int N, int S, int C, float* scratch);
 hipError_t launch_l0_rowsum_acc(hipStream_t st, const float* rown, int N, int S, int C, float alpha, int first, float* Rsum);
 hipError_t launch_l0_coord_grads_rows(hipStream_t st, const float* Rsum, const float* lin, int S, int C, int L, float alpha,
                                       float* gw, float* gb);

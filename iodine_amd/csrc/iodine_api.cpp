@@ -51,6 +51,7 @@ struct Buffers {               // workspace carve-up for one batch size / mode
     // training only
     float *wg_part = nullptr, *wg_part_b = nullptr, *wg_fold = nullptr, *Dsum = nullptr, *Dpart = nullptr, *RT = nullptr, *tmp_lz = nullptr;
     float *rown = nullptr, *Rsum = nullptr;     // training row-sum form of the broadcast layer's backward (EPI_L0ROWSX)
+    float* l0scr = nullptr;                     // partial class sums of the row-sum reductions (l0_rows_scratch_floats)
     float *ddm = nullptr, *ddv = nullptr, *dc1 = nullptr, *dgates = nullptr, *dxin = nullptr, *ds = nullptr,
           *dpooled = nullptr;
     float* carry_h[2] = {nullptr, nullptr};
@@ -281,6 +282,7 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
     b.scal = a.take<float>((size_t)(T + 1) * 3 + 4);
     b.rows = a.take<float>((size_t)N * h->S * 3 * Cd);
     b.rows_p = a.take<float>((size_t)N * h->S * (h->S / 16 > 0 ? h->S / 16 : 1) * (mode == 1 ? 4 : 3) * Cd);   // per-tile row sums (EPI_L0ROWS / EPI_L0ROWSX)
+    b.l0scr = a.take<float>(l0_rows_scratch_floats(N, Cd));
     b.Rc = a.take<float>((size_t)N * 9 * Cd);
     b.pm = a.take<float>((size_t)N * L);
     b.plv = a.take<float>((size_t)N * L);
@@ -528,11 +530,11 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
     }
     *dpre0 = b.dpre[cur];
     if (fused_l0 && train_alpha == 0.f) {
-        PROF(h, st, "l0_reduce", launch_l0_reduce_cls_tiles(st, b.rows_p, b.Rc, N, h->S, Cd));
+        PROF(h, st, "l0_reduce", launch_l0_reduce_cls_tiles(st, b.rows_p, b.Rc, N, h->S, Cd, b.l0scr));
         return IODINE_OK;
     }
     if (fused_l0) {
-        PROF(h, st, "l0_reduce", launch_l0_reduce_cls_tiles_x(st, b.rows_p, b.Rc, b.rown, N, h->S, Cd));
+        PROF(h, st, "l0_reduce", launch_l0_reduce_cls_tiles_x(st, b.rows_p, b.Rc, b.rown, N, h->S, Cd, b.l0scr));
         HIPCHK(h, launch_l0_rowsum_acc(st, b.rown, N, h->S, Cd, train_alpha, it == 0, b.Rsum));
     } else
     // row / class sums of dpre0 for dz; in training the same read also feeds the slot-summed gradient map, which is

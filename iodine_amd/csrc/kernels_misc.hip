@@ -263,81 +263,80 @@ __global__ void l0_reduce_cls_kernel(const float* __restrict__ rows, float* __re
     }
 }
 
-// The same from per-tile row sums rows_p[n][y][tile x][3][C] (written by the EPI_L0ROWS epilogue of the layer-1 data
-// gradient, which then never stores d(pre-activation 0)): sum over the tile columns first, then over the rows by class.
-__global__ void l0_reduce_cls_tiles_kernel(const float* __restrict__ rows_p, float* __restrict__ Rc, int S, int C, int tiles)
+// The same from per-tile row sums rows_p[n][y][tile x][NQ][C] (written by the EPI_L0ROWS / EPI_L0ROWSX epilogue of the layer-1
+// data gradient, which then never stores d(pre-activation 0)): sum over the tile columns first, then over the rows by class.
+//   NQ = 3 (inference): left / interior / right column sums.
+//   NQ = 4 (training): + the x-coordinate-weighted sum; the per-row sums over the tile columns also go to rown[n][y][4][C] -
+//     their sum over the slot-images (l0_rowsum_acc_kernel) is all the coordinate-channel and bias gradients of the broadcast
+//     layer need, so d(pre-activation 0) is never stored in training either.
+// Grid (slot-image, row slice): one block per slot-image left 224 blocks of the 256 CUs reading 176 - 235 MB at 2.4 TB/s
+// (72 - 83 us); with L0R_SLICES row slices per slot-image and float4 columns the interior-row sums come as partials that a second, tiny
+// kernel adds in fixed order.
+constexpr int L0R_SLICES = 16;
+template <int NQ>
+__global__ __launch_bounds__(256)
+void l0_rows_reduce_kernel(const float4* __restrict__ rows_p, float4* __restrict__ part, float4* __restrict__ edge,
+                           float4* __restrict__ rown, int S, int C, int tiles)
 {
-    __shared__ float s_mid[4][192];
-    const int n = blockIdx.x, W = 3 * C;
-    const int t = threadIdx.x % W, slice = threadIdx.x / W;
-    const float* src = rows_p + (size_t)n * S * tiles * W + t;
+    __shared__ float4 s_mid[4][64];
+    const int n = blockIdx.x, sl = blockIdx.y, W4 = NQ * C / 4, C4 = C / 4;
+    const int t = threadIdx.x % W4, sub = threadIdx.x / W4;      // t = float4 column: q*C/4 + co/4; four row sub-slices
+    const float4* src = rows_p + (size_t)n * S * tiles * W4 + t;
+    float4* dst = rown ? rown + (size_t)n * S * W4 + t : nullptr;
+    auto add4 = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
     auto row_sum = [&](int y) {
-        const float* p = src + (size_t)y * tiles * W;
-        float a = 0.f, b = 0.f;
+        const float4* p = src + (size_t)y * tiles * W4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
         int tx = 0;
-        for (; tx + 1 < tiles; tx += 2) { a += p[(size_t)tx * W]; b += p[(size_t)(tx + 1) * W]; }
-        if (tx < tiles) a += p[(size_t)tx * W];
-        return a + b;
+        for (; tx + 1 < tiles; tx += 2) { add4(a, p[(size_t)tx * W4]); add4(b, p[(size_t)(tx + 1) * W4]); }
+        if (tx < tiles) add4(a, p[(size_t)tx * W4]);
+        add4(a, b);
+        return a;
     };
-    const int per = (S - 2 + 3) / 4, y0 = 1 + slice * per, y1 = min(S - 1, y0 + per);
-    float a0 = 0.f, a1 = 0.f;
-    int y = y0;
-    for (; y + 1 < y1; y += 2) { a0 += row_sum(y); a1 += row_sum(y + 1); }
-    if (y < y1) a0 += row_sum(y);
-    s_mid[slice][t] = a0 + a1;
+    const int per = (S - 2 + L0R_SLICES - 1) / L0R_SLICES;
+    const int y0 = 1 + sl * per, y1 = min(S - 1, y0 + per);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    int y = y0 + sub;
+    for (; y + 4 < y1; y += 8) {
+        const float4 r0 = row_sum(y), r1 = row_sum(y + 4);
+        if (dst) { dst[(size_t)y * W4] = r0; dst[(size_t)(y + 4) * W4] = r1; }
+        add4(a0, r0); add4(a1, r1);
+    }
+    if (y < y1) { const float4 r0 = row_sum(y); if (dst) dst[(size_t)y * W4] = r0; add4(a0, r0); }
+    add4(a0, a1);
+    s_mid[sub][t] = a0;
     __syncthreads();
-    if (slice == 0) {
-        float* o = Rc + (size_t)n * 9 * C;
-        const int cc = t / C, co = t % C;
-        o[(0 * 3 + cc) * C + co] = row_sum(0);
-        o[(1 * 3 + cc) * C + co] = (s_mid[0][t] + s_mid[1][t]) + (s_mid[2][t] + s_mid[3][t]);
-        o[(2 * 3 + cc) * C + co] = row_sum(S - 1);
+    if (sub == 0 && t < 3 * C4) {
+        float4 m0 = s_mid[0][t], m2 = s_mid[2][t];
+        add4(m0, s_mid[1][t]); add4(m2, s_mid[3][t]); add4(m0, m2);
+        part[((size_t)n * L0R_SLICES + sl) * 3 * C4 + t] = m0;
+    }
+    // first / last image row: their own classes
+    if (sl == 0 && sub == 1) {
+        const float4 top = row_sum(0);
+        if (dst) dst[0] = top;
+        if (t < 3 * C4) edge[((size_t)n * 2 + 0) * 3 * C4 + t] = top;
+    }
+    if (sl == L0R_SLICES - 1 && sub == 2) {
+        const float4 bot = row_sum(S - 1);
+        if (dst) dst[(size_t)(S - 1) * W4] = bot;
+        if (t < 3 * C4) edge[((size_t)n * 2 + 1) * 3 * C4 + t] = bot;
     }
 }
 
-// Training form: rows_p[n][y][tile x][4][C] from the EPI_L0ROWSX epilogue (fourth value = x-coordinate-weighted sum).  Same
-// class sums Rc[n][9][C] (same order of additions as above), and the per-row sums over the tile columns go to
-// rown[n][y][4][C]: their sum over the slot-images (l0_rowsum_acc_kernel) is all the coordinate-channel and bias gradients
-// of the broadcast layer need, so d(pre-activation 0) is never stored in training either.
-__global__ __launch_bounds__(1024)
-void l0_reduce_cls_tiles_x_kernel(const float* __restrict__ rows_p, float* __restrict__ Rc, float* __restrict__ rown, int S, int C,
-                                  int tiles)
+// Rc[n][row class][column class][C]: top row, interior rows (the slices' partials in fixed order), bottom row
+__global__ void l0_rows_combine_kernel(const float* __restrict__ part, const float* __restrict__ edge, float* __restrict__ Rc, int C)
 {
-    __shared__ float s_mid[4][256];
-    const int n = blockIdx.x, W = 4 * C;
-    const int t = threadIdx.x % W, slice = threadIdx.x / W;      // t = q*C + co
-    const float* src = rows_p + (size_t)n * S * tiles * W + t;
-    float* dst = rown + (size_t)n * S * W + t;
-    auto row_sum = [&](int y) {
-        const float* p = src + (size_t)y * tiles * W;
-        float a = 0.f, b = 0.f;
-        int tx = 0;
-        for (; tx + 1 < tiles; tx += 2) { a += p[(size_t)tx * W]; b += p[(size_t)(tx + 1) * W]; }
-        if (tx < tiles) a += p[(size_t)tx * W];
-        return a + b;
-    };
-    const int per = (S - 2 + 3) / 4, y0 = 1 + slice * per, y1 = min(S - 1, y0 + per);
-    float a0 = 0.f, a1 = 0.f;
-    int y = y0;
-    for (; y + 1 < y1; y += 2) {
-        const float r0 = row_sum(y), r1 = row_sum(y + 1);
-        dst[(size_t)y * W] = r0; dst[(size_t)(y + 1) * W] = r1;
-        a0 += r0; a1 += r1;
-    }
-    if (y < y1) { const float r0 = row_sum(y); dst[(size_t)y * W] = r0; a0 += r0; }
-    s_mid[slice][t] = a0 + a1;
-    __syncthreads();
-    if (slice == 0) {
-        const float top = row_sum(0), bot = row_sum(S - 1);
-        dst[0] = top; dst[(size_t)(S - 1) * W] = bot;
-        if (t < 3 * C) {
-            float* o = Rc + (size_t)n * 9 * C;
-            const int cc = t / C, co = t % C;
-            o[(0 * 3 + cc) * C + co] = top;
-            o[(1 * 3 + cc) * C + co] = (s_mid[0][t] + s_mid[1][t]) + (s_mid[2][t] + s_mid[3][t]);
-            o[(2 * 3 + cc) * C + co] = bot;
-        }
-    }
+    const int n = blockIdx.x, t = threadIdx.x;                   // t = cc*C + co
+    if (t >= 3 * C) return;
+    const float* p = part + (size_t)n * L0R_SLICES * 3 * C + t;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int s = 0; s < L0R_SLICES; s += 2) { a += p[(size_t)s * 3 * C]; b += p[(size_t)(s + 1) * 3 * C]; }
+    float* o = Rc + (size_t)n * 9 * C;
+    o[0 * 3 * C + t] = edge[((size_t)n * 2 + 0) * 3 * C + t];
+    o[1 * 3 * C + t] = a + b;
+    o[2 * 3 * C + t] = edge[((size_t)n * 2 + 1) * 3 * C + t];
 }
 
 // Rsum[i] = (first ? 0 : Rsum[i]) + alpha * sum_n rown[n][i], i < len: fixed order over the slot-images (four interleaved partial
@@ -357,11 +356,28 @@ __global__ void l0_rowsum_acc_kernel(const float* __restrict__ rown, int N, int 
     Rsum[i] = first ? s : Rsum[i] + s;
 }
 
-hipError_t launch_l0_reduce_cls_tiles_x(hipStream_t st, const float* rows_p, float* Rc, float* rown, int N, int S, int C)
+// scratch: l0_rows_scratch_floats(N, C) floats
+size_t l0_rows_scratch_floats(int N, int C) { return (size_t)N * (L0R_SLICES + 2) * 3 * C; }
+
+hipError_t launch_l0_reduce_cls_tiles(hipStream_t st, const float* rows_p, float* Rc, int N, int S, int C, float* scratch)
 {
     IOD_XSKIP(32);
-    if (C > 64 || S % 16 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(l0_reduce_cls_tiles_x_kernel, dim3(N), dim3(4 * 4 * C), 0, st, rows_p, Rc, rown, S, C, S / 16);
+    if (C > 64 || S % 16 != 0 || S < 4 || !scratch) return hipErrorInvalidValue;
+    float *part = scratch, *edge = scratch + (size_t)N * L0R_SLICES * 3 * C;
+    hipLaunchKernelGGL(l0_rows_reduce_kernel<3>, dim3(N, L0R_SLICES), dim3(3 * C), 0, st, (const float4*)rows_p, (float4*)part, (float4*)edge,
+                       (float4*)nullptr, S, C, S / 16);
+    hipLaunchKernelGGL(l0_rows_combine_kernel, dim3(N), dim3(3 * C), 0, st, part, edge, Rc, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_l0_reduce_cls_tiles_x(hipStream_t st, const float* rows_p, float* Rc, float* rown, int N, int S, int C, float* scratch)
+{
+    IOD_XSKIP(32);
+    if (C > 64 || S % 16 != 0 || S < 4 || !scratch) return hipErrorInvalidValue;
+    float *part = scratch, *edge = scratch + (size_t)N * L0R_SLICES * 3 * C;
+    hipLaunchKernelGGL(l0_rows_reduce_kernel<4>, dim3(N, L0R_SLICES), dim3(4 * C), 0, st, (const float4*)rows_p, (float4*)part, (float4*)edge,
+                       (float4*)rown, S, C, S / 16);
+    hipLaunchKernelGGL(l0_rows_combine_kernel, dim3(N), dim3(3 * C), 0, st, part, edge, Rc, C);
     return hipGetLastError();
 }
 
@@ -369,14 +385,6 @@ hipError_t launch_l0_rowsum_acc(hipStream_t st, const float* rown, int N, int S,
 {
     const int len = S * 4 * C;
     hipLaunchKernelGGL(l0_rowsum_acc_kernel, dim3((len + 255) / 256), dim3(256), 0, st, rown, N, len, alpha, first, Rsum);
-    return hipGetLastError();
-}
-
-hipError_t launch_l0_reduce_cls_tiles(hipStream_t st, const float* rows_p, float* Rc, int N, int S, int C)
-{
-    IOD_XSKIP(32);
-    if (C > 64 || S % 16 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(l0_reduce_cls_tiles_kernel, dim3(N), dim3(4 * 3 * C), 0, st, rows_p, Rc, S, C, S / 16);
     return hipGetLastError();
 }
 
