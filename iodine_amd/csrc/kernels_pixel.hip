@@ -78,10 +78,32 @@ IOD_DEVINL void pixel_terms(const float4 xv, const float4* __restrict__ dec, siz
     for (int k = 0; k < K; ++k) { t.pk[k] = expf(lsum[k]); t.mix += t.m[k] * t.pk[k]; }
 }
 
+// sum of a double over the wave (valid in every lane).  Lane swaps / DPP in the VALU on the two 32-bit halves: __shfl_down on a
+// double is two ds_bpermute per step, and the pass-1 kernel reduces 6K + 3 statistics per wave for only two pixels per thread.
 IOD_DEVINL double wave_sum_d(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    auto halves = [](double x, unsigned& lo, unsigned& hi) { const unsigned long long u = __double_as_longlong(x); lo = (unsigned)u; hi = (unsigned)(u >> 32); };
+    auto join = [](unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
+    unsigned lo, hi;
+    {
+        halves(v, lo, hi);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = join(a[0], b[0]) + join(a[1], b[1]);
+    }
+    {
+        halves(v, lo, hi);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = join(a[0], b[0]) + join(a[1], b[1]);
+    }
+#define IOD_ROW_ROR_ADD(ctrl)                                                                                  \
+    {                                                                                                          \
+        halves(v, lo, hi);                                                                                     \
+        v += join(__builtin_amdgcn_update_dpp(0u, lo, ctrl, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0u, hi, ctrl, 0xf, 0xf, false)); \
+    }
+    IOD_ROW_ROR_ADD(0x128) IOD_ROW_ROR_ADD(0x124) IOD_ROW_ROR_ADD(0x122) IOD_ROW_ROR_ADD(0x121)       // row_ror:8, 4, 2, 1
+#undef IOD_ROW_ROR_ADD
     return v;
 }
 
