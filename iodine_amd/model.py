@@ -111,6 +111,31 @@ class _TrainStep(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+_WRAPPER_OPTIONS = ('batch_cap',)      # max images per library call (IODINE.max_batch); the rest go to iodine_set_option
+
+
+class _ChunkedTrainStep(torch.autograd.Function):
+    """The same for a batch larger than one device call takes (``IODINE.max_batch``): the images are independent and the loss is
+    a batch mean, so the batch runs as chunks, each chunk's forward AND backward at once (the library keeps one saved forward),
+    the parameter gradients accumulated with the chunk's share of the batch; ``loss.backward()`` then only scales them."""
+
+    @staticmethod
+    def forward(ctx, module, x, eps, *params):
+        loss, elbo_iter, flat = module._train_chunked(x, eps)
+        ctx.module, ctx.flat = module, flat
+        ctx.mark_non_differentiable(elbo_iter)
+        return loss, elbo_iter
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_elbo):
+        flat = ctx.flat * grad_loss.to(ctx.flat.dtype)
+        views, off = [], 0
+        for p in ctx.module._ordered_params():
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return (None, None, None, *views)
+
+
 class IODINE(nn.Module):
     def __init__(self, ARCH):
         super().__init__()
@@ -198,6 +223,8 @@ class IODINE(nn.Module):
                 _lib.check(L.iodine_create(C.byref(self._cfg), C.byref(h)), None, 'iodine_create')
             self._handle, self._handle_device = h, device
             for k, v in self._options.items():
+                if k in _WRAPPER_OPTIONS:
+                    continue
                 _lib.check(L.iodine_set_option(h, k.encode(), v), h)
             names = []
             for i in range(L.iodine_num_params(h)):
@@ -298,6 +325,8 @@ class IODINE(nn.Module):
     def set_option(self, key: str, value: float):
         """Debug/test options of the library (e.g. ``stop_after_iters``); applied to the live handle."""
         self._options[key] = float(value)
+        if key in _WRAPPER_OPTIONS:                 # handled by this wrapper, unknown to the library
+            return
         if self._handle is not None:
             _lib.check(_lib.lib().iodine_set_option(self._handle, key.encode(), float(value)), self._handle)
         if key in ('conv_precision', 'conv_variant'):
@@ -312,6 +341,46 @@ class IODINE(nn.Module):
         return tot.value, cnt.value
 
     # ---- inference: iodine.py:59-112 ------------------------------------------------------------
+    def max_batch(self, training: bool = False) -> int:
+        """Images one library call takes: the kernels index an activation tensor [B*K][pixels][channels] with 32-bit element
+        offsets (iodine_api.cpp check_ready / iodine_train_forward).  Larger batches are run in chunks of at most this many
+        images by the methods below - images are independent.  The ``batch_cap`` option lowers it (tests)."""
+        P, K, T = self.img_size * self.img_size, self.K, self.n_iters
+        cd, cr = int(self._cfg.dec_conv_chan), int(self._cfg.ref_conv_chan)
+        lim = ((1 << 31) - 1) // (K * P * max(cd, cr, 20))
+        if training:
+            lim = min(lim, ((1 << 31) - 1) // (K * T * P * 20), ((1 << 31) - 1) // (K * T * max(P // 4, 1) * cr))
+        cap = int(self._options.get('batch_cap', 0))
+        return max(1, min(lim, cap) if cap > 0 else lim)
+
+    @staticmethod
+    def _chunks(B, cap):
+        """Balanced split of B images into ceil(B / cap) runs: [(start, stop), ...]."""
+        n = -(-B // cap)
+        base, extra = divmod(B, n)
+        out, s = [], 0
+        for i in range(n):
+            e = s + base + (1 if i < extra else 0)
+            out.append((s, e))
+            s = e
+        return out
+
+    def _merge_chunk_state(self, parts, sizes, x):
+        """Per-call state and logger entries of a chunked call, as one call over the whole batch would have left them: tensors
+        over the batch concatenated, batch means (ELBO terms) weighted by the chunks' sizes, image-0 entries from chunk 0."""
+        B = float(sum(sizes))
+        cat = lambda key: torch.cat([p[key] for p in parts], 0)
+        self.z, self.mean, self.mask, self.mask_logits = cat('z'), cat('mean'), cat('mask'), cat('mask_logits')
+        self.elbo_terms = sum(p['elbo_terms'] * (n / B) for p, n in zip(parts, sizes))
+        logger.update(**parts[0]['logger0'])
+        if self.elbo_terms.shape[0] > 0:
+            logger.update(kl=self.elbo_terms[-1, 1], likelihood=self.elbo_terms[-1, 2])
+
+    def _chunk_state(self):
+        keep = ('image', 'pred') + tuple(f'mask_{i}' for i in range(self.K)) + tuple(f'pred_{i}' for i in range(self.K))
+        return dict(z=self.z, mean=self.mean, mask=self.mask, mask_logits=self.mask_logits, elbo_terms=self.elbo_terms,
+                    logger0={k: logger[k] for k in keep if k in logger})
+
     def _fetch_last_elbo(self, h, x, terms, count=None):
         """State the reference leaves on ``self`` after an ``elbo()`` call (iodine.py:171-187) and its logger entries
         (iodine.py:225-239): z, mean, mask, mask_logits of the whole batch and pred/image of image 0."""
@@ -332,6 +401,16 @@ class IODINE(nn.Module):
     def _reconstruct(self, x, eps, want_images=True):
         x = self._check_x(x)
         dev, B = x.device, x.shape[0]
+        cap = self.max_batch()
+        if B > cap:                                   # chunks of independent images; eps (T+1, B, K, L) is cut along B
+            outs, parts, sizes, pms, plvs = [], [], [], [], []
+            for s, e in self._chunks(B, cap):
+                outs.append(self._reconstruct(x[s:e], None if eps is None else eps[:, s:e], want_images))
+                parts.append(self._chunk_state()); sizes.append(e - s)
+                pms.append(self.posterior.mean); plvs.append(self.posterior.logvar)
+            self.posterior.mean, self.posterior.logvar = torch.cat(pms, 0), torch.cat(plvs, 0)
+            self._merge_chunk_state(parts, sizes, x)
+            return tuple(None if outs[0][j] is None else torch.cat([o[j] for o in outs], 0) for j in range(4))
         h = self._sync_params(dev)
         self._ensure_workspace(h, B, 0, dev)
         eps = self._eps(eps, B, dev)
@@ -368,6 +447,10 @@ class IODINE(nn.Module):
         """iodine.py:59-71."""
         z = z.detach().to(torch.float32).contiguous()
         dev, B = z.device, z.shape[0]
+        cap = self.max_batch()
+        if B > cap:
+            outs = [self.decode(z[s:e]) for s, e in self._chunks(B, cap)]
+            return tuple(torch.cat([o[j] for o in outs], 0) for j in range(3))
         h = self._sync_params(dev)
         self._ensure_workspace(h, B, 0, dev)
         K, S = self.K, self.img_size
@@ -387,6 +470,19 @@ class IODINE(nn.Module):
         the gradients the reference takes from it are what reconstruct / forward compute in closed form)."""
         x = self._check_x(x)
         dev, B = x.device, x.shape[0]
+        cap = self.max_batch()
+        if B > cap:
+            pm0, plv0 = self.posterior.mean, self.posterior.logvar
+            whole = pm0 is not None and plv0 is not None and tuple(pm0.shape) == (B, self.K, self.dim_latent) and pm0.device == dev
+            parts, sizes = [], []
+            for s, e in self._chunks(B, cap):
+                # the chunk's slice of the current posterior (or the initial posterior, as for a whole batch)
+                self.posterior.mean, self.posterior.logvar = (pm0[s:e], plv0[s:e]) if whole else (None, None)
+                self.elbo(x[s:e], None if eps is None else eps[s:e])
+                parts.append(self._chunk_state()); sizes.append(e - s)
+            self.posterior.mean, self.posterior.logvar = pm0, plv0
+            self._merge_chunk_state(parts, sizes, x)
+            return self.elbo_terms[0, 0]
         h = self._sync_params(dev)
         self._ensure_workspace(h, B, 0, dev)
         shape = (B, self.K, self.dim_latent)
@@ -408,6 +504,10 @@ class IODINE(nn.Module):
     def forward(self, x, eps=None):
         """-sum_i (i+1)/(T+1) ELBO_i, differentiable wrt every parameter."""
         x = self._check_x(x)
+        if x.shape[0] > self.max_batch(training=True):
+            loss, elbo_iter = _ChunkedTrainStep.apply(self, x, eps, *self._ordered_params())
+            self.elbo_terms = elbo_iter
+            return loss
         eps = self._eps(eps, x.shape[0], x.device)
         loss, elbo_iter = _TrainStep.apply(self, x, eps, *self._ordered_params())
         self.elbo_terms = elbo_iter
@@ -430,6 +530,34 @@ class IODINE(nn.Module):
                                                                              _lib.ptr(loss), _lib.ptr(elbo_iter)),
                                              h, 'iodine_train_forward'))
         return loss, elbo_iter
+
+    def _train_chunked(self, x, eps):
+        """Forward + backward of every chunk (see _ChunkedTrainStep): returns the batch loss, the (T+1, 3) ELBO terms of the whole
+        batch and d loss / d parameters as one flat buffer in named_parameters() order."""
+        dev, B = x.device, x.shape[0]
+        flat = torch.empty(sum(p.numel() for p in self._ordered_params()), device=dev, dtype=torch.float32)
+        loss, terms, parts, sizes = None, None, [], []
+        for c, (s, e) in enumerate(self._chunks(B, self.max_batch(training=True))):
+            xc = x[s:e].contiguous()
+            ec = self._eps(None if eps is None else eps[:, s:e], e - s, dev)
+            lc, tc = self._train_forward(xc, ec)
+            h = self._handle
+            w = torch.full((), (e - s) / float(B), device=dev, dtype=torch.float32)
+            self._launch(dev, lambda: _lib.check(_lib.lib().iodine_train_backward_flat(h, self._stream(), _lib.ptr(w), _lib.ptr(flat),
+                                                                                       1 if c else 0), h, 'iodine_train_backward'))
+            with torch.no_grad():
+                self._fetch_last_elbo(h, xc, tc[-1])
+                self.elbo_terms = tc
+                parts.append(self._chunk_state()); sizes.append(e - s)
+                if c == 0:
+                    stats = torch.empty((2,), device=dev, dtype=torch.float32)
+                    self._launch(dev, lambda: _lib.check(_lib.lib().iodine_logger_scalars(h, self._stream(), _lib.ptr(stats)), h))
+                    logger.update(init_mean=stats[0], init_logvar=stats[1])
+            self._call_serial += 1                  # this chunk's saved forward is consumed
+            loss = lc * w if loss is None else loss + lc * w
+        with torch.no_grad():
+            self._merge_chunk_state(parts, sizes, x)
+        return loss, self.elbo_terms, flat
 
     def _train_backward(self, grad_loss, serial):
         if serial != self._call_serial:

@@ -70,6 +70,21 @@ def test_module_surface_matches_reference_names():
         m.reconstruct(torch.zeros(1, 3, arch.img_size, arch.img_size))
 
 
+def test_max_batch_and_chunking_plan():
+    """IODINE.max_batch mirrors the library's 32-bit offset limits (iodine_api.cpp check_ready / iodine_train_forward); larger
+    batches are cut into balanced runs of independent images."""
+    from iodine_amd import IODINE
+    from iodine_amd.model import clevr6_arch
+    m = IODINE(clevr6_arch())                                   # cfg3: K = 7, T = 5, 128 x 128, 64 channels
+    assert m.max_batch() == (2 ** 31 - 1) // (7 * 128 * 128 * 64) == 292
+    assert m.max_batch(training=True) == (2 ** 31 - 1) // (7 * 5 * 128 * 128 * 20) == 187
+    m.set_option('batch_cap', 32)
+    assert m.max_batch() == m.max_batch(training=True) == 32
+    assert m._chunks(256, 32) == [(32 * i, 32 * i + 32) for i in range(8)]
+    assert m._chunks(70, 32) == [(0, 24), (24, 47), (47, 70)]
+    assert m._chunks(5, 32) == [(0, 5)]
+
+
 def test_synth_is_deterministic_and_shard_invariant():
     e1 = synth.make_eps(2, 4, 3, 8, seed=1)
     e2 = synth.make_eps(2, 4, 3, 8, seed=1)

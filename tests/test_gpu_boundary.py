@@ -296,3 +296,60 @@ def test_odd_batches_and_eleven_slots_at_64px(B, K, T):
     bad = [(n, rel_l2(p.grad.cpu().numpy(), grads[n].numpy())) for n, p in m.named_parameters()
            if not rel_l2(p.grad.cpu().numpy(), grads[n].numpy()) < 1e-3]
     assert not bad, bad
+
+
+def test_batches_beyond_one_library_call_run_in_chunks():
+    """IODINE.max_batch: the kernels use 32-bit element offsets, so one library call takes a bounded number of images (145 at
+    cfg3); the wrapper runs larger batches as chunks of independent images.  With ``batch_cap`` = 2 a batch of 5 goes through
+    the chunked paths of reconstruct / elbo / decode / forward + backward and must agree with the single call: per-image
+    outputs bit for bit, batch means and gradients to summation order."""
+    g = load_golden('cfg1_dsprites_k4_t3_b4')
+    arch, params, _, _, _ = golden_setup(g)
+    B, K, T, L = 5, arch.slots, arch.iters, arch.dim_latent
+    imgs, _ = synth.make_images(B, arch.img_size, seed=77, kind='blobs')
+    x = torch.from_numpy(imgs).to(DEV)
+    eps = torch.from_numpy(synth.make_eps(T, B, K, L, seed=78)).to(DEV)
+    m = make_hip_model(arch, params)
+    assert m.max_batch() > 1000 and m.max_batch(training=True) <= m.max_batch()
+
+    def run_all():
+        out = {}
+        out['recon'] = m.reconstruct(x, eps)
+        out['state'] = (m.z, m.mean, m.mask, m.mask_logits, m.posterior.mean, m.posterior.logvar)
+        out['recon_terms'] = m.elbo_terms.clone()
+        out['log_recon'] = {k: logger[k].clone() for k in ('image', 'pred', 'mask_0', f'pred_{K - 1}')}
+        out['elbo'] = m.elbo(x, eps[0]).clone()                       # from the posterior reconstruct left behind
+        out['decode'] = m.decode(out['state'][0])
+        m.zero_grad(set_to_none=True)
+        loss = m(x, eps)
+        out['train_terms'] = m.elbo_terms.clone()
+        out['train_z'] = m.z
+        (2.0 * loss).backward()
+        out['loss'] = loss.detach().clone()
+        out['grads'] = {n: p.grad.clone() for n, p in m.named_parameters()}
+        out['log_train'] = {k: logger[k].clone() for k in ('image', 'pred', 'kl', 'likelihood', 'init_mean', 'init_logvar')}
+        return out
+
+    whole = run_all()
+    m.set_option('batch_cap', 2)
+    assert m.max_batch() == 2 and IODINE_chunks(m, B) == [(0, 2), (2, 4), (4, 5)]
+    parts = run_all()
+    m.set_option('batch_cap', 0)
+    for a, b in zip(whole['recon'] + whole['state'] + whole['decode'], parts['recon'] + parts['state'] + parts['decode']):
+        assert torch.equal(a, b)
+    assert torch.equal(whole['train_z'], parts['train_z'])
+    for k in whole['log_recon']:
+        assert torch.equal(whole['log_recon'][k], parts['log_recon'][k]), k
+    for k in ('image', 'pred', 'init_mean', 'init_logvar'):
+        assert torch.equal(whole['log_train'][k], parts['log_train'][k]), k
+    for k in ('kl', 'likelihood'):
+        assert rel_err(parts['log_train'][k].cpu(), whole['log_train'][k].cpu()) < 1e-5, k
+    for k in ('recon_terms', 'train_terms', 'elbo', 'loss'):
+        assert rel_err(parts[k].cpu(), whole[k].cpu()) < 1e-5, k
+    for n in whole['grads']:
+        a, b = parts['grads'][n].double().cpu(), whole['grads'][n].double().cpu()
+        assert float((a - b).norm()) <= 2e-5 * float(b.norm()) + 1e-12, (n, float((a - b).norm()), float(b.norm()))
+
+
+def IODINE_chunks(m, B):
+    return m._chunks(B, m.max_batch())
