@@ -71,5 +71,8 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises((RuntimeError, ValueError)):                          # CPU tensors: no fallback path
         m.reconstruct(torch.rand(1, 3, 16, 16))
     big = IODINE(arch_namespace(64, 5, 7, 128, (64, 4, 256), (64, 4))).to(DEV)
-    with pytest.raises(RuntimeError, match='batch too large'):               # 32-bit element offsets: fail, do not wrap
+    # 32-bit element offsets: the LIBRARY fails, it does not wrap (the wrapper cuts such a batch into chunks, IODINE.max_batch)
+    assert big.max_batch() == 292 and big._chunks(300, big.max_batch()) == [(0, 150), (150, 300)]
+    big.max_batch = lambda training=False: 10 ** 9
+    with pytest.raises(RuntimeError, match='batch too large'):
         big.reconstruct(torch.empty(300, 3, 128, 128, device=DEV))
