@@ -389,13 +389,15 @@ hipError_t launch_colsum_tall(hipStream_t st, const float* src, int rows, int co
 // generic small SGEMM (row-major): C[M][N] = alpha * op(A)[M][K] * op(B)[K][N] + beta * C, 16x16 LDS tiles.
 // Used for the head backward (N = B*K rows; at most a few hundred MFLOP per call).
 // =========================================================================================
+template <int BK>
 __global__ __launch_bounds__(256)
 void sgemm_kernel(int ta, int tb, int M, int N, int K, float alpha, const float* __restrict__ A, int lda,
                   const float* __restrict__ B, int ldb, float beta, float* __restrict__ Cm, int ldc)
 {
-    // These GEMMs are latency-bound (operands are L2-resident, a few hundred blocks): K advances 64 at a time so that every
-    // thread has 8 independent loads in flight per barrier pair instead of 2; the k order of the fma chain is unchanged.
-    constexpr int BK = 64;
+    // These GEMMs are latency-bound (operands are L2-resident, a few hundred blocks): K advances BK = 64 at a time so that every
+    // thread has 8 independent loads in flight per barrier pair instead of 2, and 256 at a time (32 loads, four float4 per
+    // operand) for the long reductions (K >= 512: 16 -> 4 exposed round trips at K = 1024); the k order of the fma chain is
+    // unchanged, so every BK gives the same bits.
     __shared__ float sA[16][BK + 1], sB[BK][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
@@ -407,20 +409,34 @@ void sgemm_kernel(int ta, int tb, int M, int N, int K, float alpha, const float*
                         (((size_t)A | (size_t)B) & 15) == 0;
     for (int k0 = 0; k0 < K; k0 += BK) {
         if (vec_ok) {
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb4 = va;
-            if (!ta) {                                       // A [M][K]: 16 rows x 64 k, float4 along k
-                const int r = t >> 4, kq = (t & 15) * 4, gr = blockIdx.y * 16 + r;
-                if (gr < M && k0 + kq < K) va = *reinterpret_cast<const float4*>(A + (size_t)gr * lda + k0 + kq);
-                sA[r][kq] = va.x; sA[r][kq + 1] = va.y; sA[r][kq + 2] = va.z; sA[r][kq + 3] = va.w;
-            } else {                                         // A [K][M]: 64 k x 16 rows, float4 along m
-                const int kk = t >> 2, mq = (t & 3) * 4, gm = blockIdx.y * 16 + mq;
-                if (k0 + kk < K && gm < M) va = *reinterpret_cast<const float4*>(A + (size_t)(k0 + kk) * lda + gm);
-                sA[mq][kk] = va.x; sA[mq + 1][kk] = va.y; sA[mq + 2][kk] = va.z; sA[mq + 3][kk] = va.w;
+            constexpr int NV = BK / 64;                      // float4 loads per thread and operand
+            float4 va[NV], vb4[NV];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                va[q] = vb4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!ta) {                                   // A [M][K]: 16 rows x 64 k per pass, float4 along k
+                    const int r = t >> 4, kq = q * 64 + (t & 15) * 4, gr = blockIdx.y * 16 + r;
+                    if (gr < M && k0 + kq < K) va[q] = *reinterpret_cast<const float4*>(A + (size_t)gr * lda + k0 + kq);
+                } else {                                     // A [K][M]: 64 k x 16 rows per pass, float4 along m
+                    const int kk = q * 64 + (t >> 2), gm = blockIdx.y * 16 + (t & 3) * 4;
+                    if (k0 + kk < K && gm < M) va[q] = *reinterpret_cast<const float4*>(A + (size_t)(k0 + kk) * lda + gm);
+                }
+                {                                            // B [K][N]: 64 k x 16 columns per pass, float4 along n
+                    const int kk = q * 64 + (t >> 2), gn = blockIdx.x * 16 + (t & 3) * 4;
+                    if (k0 + kk < K && gn < N) vb4[q] = *reinterpret_cast<const float4*>(B + (size_t)(k0 + kk) * ldb + gn);
+                }
             }
-            {                                                // B [K][N]: 64 k x 16 columns, float4 along n
-                const int kk = t >> 2, nq = (t & 3) * 4, gn = blockIdx.x * 16 + nq;
-                if (k0 + kk < K && gn < N) vb4 = *reinterpret_cast<const float4*>(B + (size_t)(k0 + kk) * ldb + gn);
-                sB[kk][nq] = vb4.x; sB[kk][nq + 1] = vb4.y; sB[kk][nq + 2] = vb4.z; sB[kk][nq + 3] = vb4.w;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                if (!ta) {
+                    const int r = t >> 4, kq = q * 64 + (t & 15) * 4;
+                    sA[r][kq] = va[q].x; sA[r][kq + 1] = va[q].y; sA[r][kq + 2] = va[q].z; sA[r][kq + 3] = va[q].w;
+                } else {
+                    const int kk = q * 64 + (t >> 2), mq = (t & 3) * 4;
+                    sA[mq][kk] = va[q].x; sA[mq + 1][kk] = va[q].y; sA[mq + 2][kk] = va[q].z; sA[mq + 3][kk] = va[q].w;
+                }
+                const int kk = q * 64 + (t >> 2), nq = (t & 3) * 4;
+                sB[kk][nq] = vb4[q].x; sB[kk][nq + 1] = vb4[q].y; sB[kk][nq + 2] = vb4[q].z; sB[kk][nq + 3] = vb4[q].w;
             }
         } else {
             float ra[BK / 16], rb[BK / 16];
@@ -448,8 +464,14 @@ hipError_t launch_sgemm(hipStream_t st, int ta, int tb, int M, int N, int K, flo
                         const float* B, int ldb, float beta, float* C, int ldc)
 {
     IOD_XSKIP(2);
-    hipLaunchKernelGGL(sgemm_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, st, ta, tb, M, N, K, alpha, A, lda,
-                       B, ldb, beta, C, ldc);
+    // (the long-K form only where the grid leaves the chip mostly empty: with >= 1024 blocks its 34 KB of LDS costs occupancy -
+    // 99 -> 111 us for the 1024 x 512 x 1120 weight gradient)
+    if (K >= 512 && ((N + 15) / 16) * ((M + 15) / 16) <= 512)
+        hipLaunchKernelGGL(sgemm_kernel<256>, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, st, ta, tb, M, N, K, alpha, A, lda,
+                           B, ldb, beta, C, ldc);
+    else
+        hipLaunchKernelGGL(sgemm_kernel<64>, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, st, ta, tb, M, N, K, alpha, A, lda,
+                           B, ldb, beta, C, ldc);
     return hipGetLastError();
 }
 
