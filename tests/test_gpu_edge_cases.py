@@ -1,7 +1,7 @@
 """Edge cases of the hot path against the CPU oracle on the same seeded inputs (reference semantics:
 lib/modeling/iodine.py): one slot, the maximum slot count the pixel kernels are instantiated for, a single refinement
 iteration, batch of one, layer-norms switched off (ARCH.LAYERNORM, iodine.py:376-395), another likelihood sigma
-(ARCH.SIGMA, iodine.py:661-666), odd layer counts, and unsupported configurations failing loudly."""
+(ARCH.SIGMA, iodine.py:661-666), odd layer counts, an image size off the fast path, and unsupported configurations failing loudly."""
 import dataclasses
 
 import numpy as np
@@ -33,6 +33,9 @@ CASES = {
     'sigma_0p3': (dataclasses.replace(O.tiny_arch(slots=4, iters=2), sigma=0.3), 2),
     'deeper_stacks_32px': (O.tiny_arch(slots=2, iters=2, img_size=32, ref_layers=3, dec_layers=3), 2),
     'dsprites_k2_t1': (O.dsprites_arch(slots=2, iters=1), 1),
+    # image size that is not a power of two: the weight-stationary conv and the row-sum forms do not apply, the LDS-tiled conv
+    # and the stored-gradient reductions take over (conv_ws_ok() false); the fused output conv backward runs without side buffer
+    'not_a_power_of_two_48px': (O.tiny_arch(slots=3, iters=2, img_size=48), 2),
 }
 
 
