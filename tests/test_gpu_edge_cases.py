@@ -35,6 +35,7 @@ CASES = {
     'dsprites_k2_t1': (O.dsprites_arch(slots=2, iters=1), 1),
     # image size that is not a power of two: the weight-stationary conv and the row-sum forms do not apply, the LDS-tiled conv
     # and the stored-gradient reductions take over (conv_ws_ok() false); the fused output conv backward runs without side buffer
+    'large_image_256px': (O.tiny_arch(slots=2, iters=1, img_size=256), 1),
     'not_a_power_of_two_48px': (O.tiny_arch(slots=3, iters=2, img_size=48), 2),
 }
 
