@@ -18,14 +18,28 @@ one RCCL all-reduce of the flat gradient buffer per training step, no data-path 
 ``--gpus N`` with N>1 and no launcher environment starts its own N ranks (``torch.distributed.run``, one process per GPU);
 under the driver's ``python -m torch.distributed.run ... bench.py --gpus N`` the ranks are used as given.
 
-Extra objects on the JSON line: ``roofline`` for the dominant kernel (split-fp16 MFMA 3x3 conv C->C; duration from HIP events
-recorded on the launch stream inside the timed region; ``traffic`` from the tracked PMC file profiles/r02_pmc.json while its
-source digest still matches the tree), ``cpu_baseline`` (the CPU oracle timed on this box's host cores on a bounded sample,
-rank 0 at N=1 only) with ELBO and gradient parity of this very run against it, ``exact_fp32`` (the same step on the exact
-fp32-MFMA path, 2 steps), and ``rccl`` for N>1.
+The timed region is EXACTLY ``--steps`` steps (``value``, ``ms_per_step``).  When that region is shorter than 6 s the same step
+keeps running afterwards until 6 s of continuous GPU work have passed (``sustained``: steps_run, ms_per_step - a second,
+longer measurement of the same loop, and long enough for an external utilisation sampler to see the GPU busy).
+
+Extra objects on the JSON line:
+  * ``roofline``: the dominant kernel (split-fp16 MFMA 3x3 conv C->C, forward / data-gradient / weight-gradient launches);
+    duration from HIP events recorded on the launch stream inside the timed region; ``traffic`` from the tracked PMC file
+    profiles/r*_pmc.json while its source digest still matches the tree;
+  * ``roofline_hbm``: the other regime (SURVEY 8d "report both") - of the HBM-bound helper kernels the one that loses the most
+    time against the 8 TB/s roof (time x (1 - frac)), with the whole candidate table; algorithmic bytes per launch from the
+    shapes (DESIGN 4.2), durations from HIP events of an extra pass that brackets every launch;
+  * ``inference_step``: the reconstruct step on the same workload with its own ``roofline`` (forward + data-gradient launches);
+  * ``configs``: BASELINE configs[1] (dSprites 64x64, K=6, T=5, B=32) and the per-GPU shard of configs[4] (K=11, T=7, B=8),
+    5 steps each of both step types - side measurements, not part of ``value``;
+  * ``cpu_baseline``: the CPU oracle timed on this box's host cores on a bounded sample (rank 0 at N=1 only), with ELBO and
+    gradient parity of this very run against it; ``exact_fp32``: the same step on the exact fp32-MFMA path;
+  * ``rccl`` for N>1: world size, all-reduce time, and whether the replicas held identical parameters before the first and
+    after the last step.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -36,11 +50,13 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (the 5 PF headline is 2:1 sparse)
+PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+SUSTAIN_S = 6.0                    # minimum length of the continuous step loop (timed region + its continuation)
 SPLIT_PASSES = 3                   # fp32 product = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, three f16 MFMAs, fp32 accumulate
 PUBLISHED_TRAIN_ITERS_PER_S = 94.0  # 1.7 s / 32-image T=5 training step on 4 unknown GPUs (log.md:3)
 DOMINANT = ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad')
 CATS = DOMINANT + ('dec_out', 'dec_out_dgrad', 'dec_out_wgrad', 'dec_out_bwd', 'dec_l0', 'l0_reduce', 'l0_slot_sum', 'pixel_pass1',
-                   'pixel_pass2', 'refine_conv', 'refine_head', 'refine_wgrad', 'refine_dgrad', 'refine_bias_grad', 'head_bwd')
+                   'pixel_pass2', 'refine_conv', 'refine_l0', 'refine_head', 'refine_wgrad', 'refine_dgrad', 'refine_bias_grad', 'head_bwd')
 
 
 def parse():
@@ -61,18 +77,20 @@ def parse():
     ap.add_argument('--no-adam', action='store_true', help='time forward + backward only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-exact-fp32', action='store_true')
+    ap.add_argument('--no-extra-configs', action='store_true', help='skip the cfg2 / cfg5-shard side measurements')
+    ap.add_argument('--no-sustain', action='store_true', help='do not continue a short timed region to 6 s of GPU work')
     ap.add_argument('--cpu-batch', type=int, default=None)
     return ap.parse_args()
 
 
-def build_model(args, device):
+def build_model(config, slots, iters, device):
     import torch
     from iodine_amd import IODINE, synth
     from iodine_amd.model import clevr6_arch, dsprites_arch
-    if args.config == 'clevr6':
-        arch = clevr6_arch(slots=args.slots or 7, iters=args.iters or 5)
+    if config == 'clevr6':
+        arch = clevr6_arch(slots=slots or 7, iters=iters or 5)
     else:
-        arch = dsprites_arch(slots=args.slots or 6, iters=args.iters or 5)
+        arch = dsprites_arch(slots=slots or 6, iters=iters or 5)
     model = IODINE(arch)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     params = synth.make_params(shapes, seed=0)              # torch-default-init bounds, deterministic bytes
@@ -81,9 +99,10 @@ def build_model(args, device):
 
 
 def cpu_baseline(args, arch, params, mode):
-    """Time the CPU oracle (PyTorch-CPU restatement of the reference) on a bounded sample of the same workload: all host
-    cores (<= 64 threads) at batch 4 (CLEVR) / 8 (dSprites), plus one repetition at 8 threads for comparability with the
-    survey container.  Returns the JSON object and what the parity check needs."""
+    """Time the CPU oracle (PyTorch-CPU restatement of the reference) on a bounded sample of the same workload: all host cores
+    (<= 64 threads), ONE step at batch 4 (CLEVR) / 8 (dSprites) after a batch-1 warm-up (about 15 s of CPU work in all), plus
+    one batch-1 step at 8 threads for comparability with the survey container.  Returns the JSON
+    object and what the parity check needs."""
     import torch
     from iodine_amd import synth
     from oracle import iodine_oracle as O
@@ -96,58 +115,101 @@ def cpu_baseline(args, arch, params, mode):
     p = {k: torch.from_numpy(v) for k, v in params.items()}
     x = torch.from_numpy(synth.make_images(Bc, oa.img_size, seed=0))
     eps = torch.from_numpy(synth.make_eps(oa.iters, Bc, oa.slots, oa.dim_latent, seed=1))
-    fn = (lambda: O.reconstruct(x, eps, p, oa)) if mode == 'infer' else (lambda: O.train_step_grads(x, eps, p, oa))
+
+    def fn(n):
+        xe = (x[:n], eps[:, :n].contiguous())
+        return O.reconstruct(*xe, p, oa) if mode == 'infer' else O.train_step_grads(*xe, p, oa)
+
     torch.set_num_threads(threads)
-    fn()                                                    # warm-up
-    reps, t0 = 0, time.perf_counter()
-    while reps < 2 or (time.perf_counter() - t0 < 10.0 and reps < 8):
-        out = fn()
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
+    fn(1)                                                   # warm-up (thread pool, oneDNN primitive cache)
+    t0 = time.perf_counter()
+    out = fn(Bc)
+    dt = time.perf_counter() - t0
     dt8 = None
     if threads > 8:
         torch.set_num_threads(8)
         t1 = time.perf_counter()
-        fn()
+        fn(1)
         dt8 = time.perf_counter() - t1
         torch.set_num_threads(threads)
     ref_elbos = (out['elbos'] if mode == 'infer' else out[0]['elbos']).detach().double().numpy()
     ref_grads = None if mode == 'infer' else out[1]
     cb = dict(value=round(Bc * oa.iters / dt, 4), unit='image-refinement-iters/s', cores=threads, kind='port',
-              sample=f'{mode} step, batch {Bc} of the same workload (weights, images, eps), {reps} reps after 1 warm-up, '
+              sample=f'{mode} step, batch {Bc} of the same workload (weights, images, eps), 1 step after a batch-1 warm-up, '
                      f'{dt * 1e3:.0f} ms/step; oracle/iodine_oracle.py (PyTorch-CPU fp32, the ATen arithmetic the reference runs)',
               ms_per_step=round(dt * 1e3, 1))
     if dt8 is not None:
-        cb['threads8'] = dict(value=round(Bc * oa.iters / dt8, 4), ms_per_step=round(dt8 * 1e3, 1), cores=8,
-                              sample='same sample, 1 repetition at torch.set_num_threads(8)')
+        cb['threads8'] = dict(value=round(oa.iters / dt8, 4), ms_per_step=round(dt8 * 1e3, 1), cores=8,
+                              sample='batch 1 of the same sample, 1 step at torch.set_num_threads(8)')
     return cb, (x, eps, ref_elbos, ref_grads)
 
 
-PMC_PIPE = None      # matrix-pipe utilisation and shader clock of the same PMC passes (the chip clocks to its power budget)
+def pmc_file():
+    """The newest tracked PMC record (profiles/rNN_pmc.json)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc.json')))
+    return files[-1] if files else None
 
 
-def pmc_traffic(args, B, K):
-    """HBM bytes per launch of the dominant kernels from the tracked PMC file (tools/pmc_to_json.py writes it from rocprofv3
-    --pmc passes: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  Quoted only while the file describes THIS tree (source
-    digest) and THIS shape; otherwise null."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc.json')
-    if not os.path.exists(path):
-        return None, 'profiles/r02_pmc.json missing'
+def pmc_record(args, B, K):
+    """HBM bytes per launch (every profiled category) and matrix-pipe utilisation / shader clock of the dominant kernels from the
+    tracked PMC file (tools/pmc_to_json.py writes it from rocprofv3 --pmc passes: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).
+    Quoted only while the file describes THIS tree (source digest) and THIS shape; otherwise (None, None, reason)."""
+    path = pmc_file()
+    if not path:
+        return None, None, 'no profiles/rNN_pmc.json'
+    name = os.path.relpath(path, ROOT)
     try:
         from iodine_amd.build import source_digest
         rec = json.load(open(path))
         if rec.get('csrc_sha256') != source_digest():
-            return None, 'profiles/r02_pmc.json was measured on other kernel sources (digest mismatch)'
+            return None, None, f'{name} was measured on other kernel sources (digest mismatch)'
         shape = rec.get('shape', {})
         if (shape.get('config'), shape.get('batch'), shape.get('slots')) != (args.config, B, K) or args.conv_precision != 1:
-            return None, 'profiles/r02_pmc.json was measured on another shape'
-        per = {k: v['hbm_bytes_per_launch'] for k, v in rec['kernels'].items()}
-        global PMC_PIPE
-        PMC_PIPE = {k: {f: v[f] for f in ('mfma_util', 'clock_ghz', 'mfma_rate_of_2p4ghz_peak') if f in v}
-                    for k, v in rec['kernels'].items()}
-        return per, f"profiles/r02_pmc.json ({rec.get('commit', '?')[:10]})"
+            return None, None, f'{name} was measured on another shape'
+        per = {k: v['hbm_bytes_per_launch'] for k, v in rec['kernels'].items() if 'hbm_bytes_per_launch' in v}
+        pipe = {k: {f: v[f] for f in ('mfma_util', 'clock_ghz', 'mfma_rate_of_2p4ghz_peak') if f in v}
+                for k, v in rec['kernels'].items() if 'mfma_util' in v}
+        return per, pipe, f"{name} ({rec.get('commit', '?')[:10]})"
     except Exception as e:                                  # a malformed file must not break the bench line
-        return None, f'profiles/r02_pmc.json unreadable: {e}'
+        return None, None, f'{name} unreadable: {e}'
+
+
+def hbm_algorithmic_bytes(arch, B, mode):
+    """Algorithmic HBM bytes PER LAUNCH (mean over the launches of one category) of the HBM-bound helper kernels:
+    every input tensor read once, every output written once, fp32; weights and KB-sized side buffers not counted."""
+    K, T, S = arch.SLOTS, arch.ITERS, arch.IMG_SIZE
+    Cd, Cr, Dr = arch.DEC.CONV_CHAN, arch.REF.CONV_CHAN, arch.REF.CONV_LAYERS
+    N, P = B * K, S * S
+    act = 4.0 * N * P * Cd                                   # one decoder activation / gradient tensor
+    out4 = 16.0 * N * P                                      # decoder output {rgb, mask logit} resp. its gradient
+    x4 = 16.0 * B * P
+    enc = 48.0 * N * P + 32.0 * B * P                        # split refinement input: 12 floats per slot-pixel + 8 per image-pixel
+    b = {
+        'dec_l0': act,                                       # broadcast layer: write only (4 MB class map read)
+        'dec_out': act + out4,
+        'dec_out_bwd': 2 * act + out4,                       # read activation + output gradient, write data gradient
+        'dec_out_dgrad': 2 * act + out4,
+        'dec_out_wgrad': act + out4,
+        'pixel_pass1': 2 * out4 + x4,
+        'pixel_pass2': out4 + x4 + enc,
+        'l0_reduce': 4.0 * N * S * (S // 16) * (4 if mode == 'train' else 3) * Cd,
+    }
+    # refinement stack, stride 2: layer l reads [N][s][s][C_in], writes [N][s/2][s/2][Cr]
+    per_layer, s = [], S
+    for l in range(Dr):
+        per_layer.append((enc if l == 0 else 4.0 * N * s * s * Cr, 4.0 * N * (s // 2) * (s // 2) * Cr))
+        s //= 2
+    # first layer: per-image part (reads 8 floats per image-pixel, writes a map) + per-slot part (reads 12 floats per
+    # slot-pixel and the map, writes the activation): two launches
+    b['refine_l0'] = (per_layer[0][0] + per_layer[0][1] + 2 * 4.0 * B * (S // 2) * (S // 2) * Cr) / 2.0
+    if Dr > 1:
+        b['refine_conv'] = sum(i + o for i, o in per_layer[1:]) / (Dr - 1)
+    if mode == 'train':                                      # one batch of T * N slot-images per layer
+        b['refine_wgrad'] = T * sum(i + o for i, o in per_layer) / Dr
+        if Dr > 1:
+            b['refine_dgrad'] = T * sum(2 * i + o for i, o in per_layer[1:]) / (Dr - 1)   # read d(out) + saved act, write d(in)
+    return b
 
 
 def main():
@@ -182,27 +244,32 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
-    model, arch, params = build_model(args, device)
+    model, arch, params = build_model(args.config, args.slots, args.iters, device)
     B, T, K, S = args.batch, arch.ITERS, arch.SLOTS, arch.IMG_SIZE
     x = torch.from_numpy(synth.make_images(B, S, seed=0, first_index=rank * B)).to(device)
     model.manual_seed(1234 + rank)                # every rank draws its own noise (library Philox, inside the step)
+    # replicas start from rank 0's parameters (DataParallel re-broadcasts them on every forward, lib/modeling/build.py:11-12)
+    # and are CHECKED to be bitwise identical before the first step and after the last one
+    parallel.broadcast_parameters(model, 0)
+    replicas_before = parallel.replicas_identical(model.parameters())
 
-    opt = None
-    if args.mode == 'infer':
-        def step():
-            return model.reconstruct(x)
-    else:
+    def make_step(m, xb, mode, adam=True):
+        if mode == 'infer':
+            return (lambda: m.reconstruct(xb)), None
         from iodine_amd.optim import make_optimizer
-        opt = None if args.no_adam else make_optimizer(model, base_lr=3e-4, weight_decay=0.0)   # configs/clevr6_prop.yaml:19-20
+        opt = make_optimizer(m, base_lr=3e-4, weight_decay=0.0) if adam else None   # configs/clevr6_prop.yaml:19-20
 
         def step():
-            loss = model(x)
-            model.zero_grad(set_to_none=True)                             # train.py:62 (the flat gradient buffer is replaced)
+            loss = m(xb)
+            m.zero_grad(set_to_none=True)                                 # train.py:62 (the flat gradient buffer is replaced)
             loss.backward()
-            parallel.allreduce_gradients(model.parameters(), world)       # one RCCL all-reduce of the flat grads
+            parallel.allreduce_gradients(m.parameters(), world)           # one RCCL all-reduce of the flat grads
             if opt is not None:
                 opt.step()
             return loss
+        return step, opt
+
+    step, opt = make_step(model, x, args.mode, not args.no_adam)
 
     def barrier():
         torch.cuda.synchronize()
@@ -217,93 +284,148 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def timed(fn, n):
+        """n calls of fn bracketed by barrier + synchronize on both sides; seconds, max over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    def read_prof(m=None):
+        out = {}
+        for cat in CATS:
+            tot, cnt = (m or model).profile_read(cat)
+            if cnt:
+                out[cat] = dict(ms_total=round(tot, 3), launches=cnt, ms_avg=round(tot / cnt, 4))
+        return out
+
     model.set_option('conv_precision', args.conv_precision)
     model.set_option('graph', args.graph)
     for _ in range(args.warmup):
         step()
     model.set_option('profile', 0 if args.graph else 1)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
-    model.set_option('profile', 0)
+    dt = timed(step, args.steps)                                          # ---- THE timed region: exactly --steps steps ----
     ms_per_step = dt / args.steps * 1e3
     value = world * B * T / (dt / args.steps)
-
-    def read_prof():
-        out = {}
-        for cat in CATS:
-            tot, cnt = model.profile_read(cat)
-            if cnt:
-                out[cat] = dict(ms_total=round(tot, 3), launches=cnt, ms_avg=round(tot / cnt, 4))
-        return out
-
     prof = read_prof()                                   # timed region: conv_tile_* only (graph mode: nothing)
     timed_events = bool(prof)
+    model.set_option('profile', 0)
 
-    # secondary measurement (not `value`): the other step type on the same workload
-    other = None
-    if args.mode == 'train':
-        def istep():
-            return model.reconstruct(x)
-        istep()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            istep()
-        barrier()
-        dti = max_over_ranks((time.perf_counter() - t1) / args.steps)
-        other = dict(step='infer (reconstruct: T iterations + final decode)', ms_per_step=round(dti * 1e3, 3),
-                     image_refinement_iters_per_s=round(world * B * T / dti, 2))
+    # the same loop continued: at least SUSTAIN_S seconds of back-to-back steps in all (its own, longer measurement)
+    sustained = None
+    if not args.no_sustain and dt < SUSTAIN_S:
+        n_more = int(math.ceil((SUSTAIN_S - dt) / (dt / args.steps)))
+        dts = timed(step, n_more)
+        sustained = dict(steps_run=args.steps + n_more, seconds=round(dt + dts, 3), continuation_steps=n_more,
+                         continuation_ms_per_step=round(dts / n_more * 1e3, 3),
+                         note=f'value / ms_per_step are the first {args.steps} steps (the requested timed region); the loop then '
+                              f'continued for {n_more} more steps so that the GPU is busy for >= {SUSTAIN_S:.0f} s in one stretch')
 
     # ---- roofline of the dominant kernel: the decoder 3x3 conv C->C (fwd + dgrad + wgrad launches) ----
     # Inside the timed region only the dominant launches were bracketed with events (profile level 1: every category
-    # costs ~1 ms per step in event records); the per-category table comes from two extra, untimed steps at level 2.
+    # costs ~1 ms per step in event records); the per-category table comes from extra, untimed steps at level 2.
     C_ = arch.DEC.CONV_CHAN
     flops_per_launch = 2.0 * C_ * C_ * 9 * S * S * B * K
-    model.set_option('graph', 0)
-    model.set_option('profile', 2)
-    for _ in range(2):
-        step()
-    barrier()
-    model.set_option('profile', 0)
-    prof_all = read_prof()
-    for cat, v in prof_all.items():
-        prof.setdefault(cat, dict(v, note='untimed pass'))
-    dom_ms = sum(prof[c]['ms_total'] for c in DOMINANT if c in prof)
-    dom_n = sum(prof[c]['launches'] for c in DOMINANT if c in prof)
-    achieved = flops_per_launch / (dom_ms / dom_n * 1e-3) / 1e12 if dom_n else 0.0
-    if args.conv_precision == 1:
-        # the kernel executes SPLIT_PASSES f16 MFMAs per algorithmic (fp32-class) multiply-add: the peak for ALGORITHMIC
-        # FLOPs is the dense f16 MFMA peak divided by the number of passes
-        peak = PEAK_F16_MFMA_TFLOPS / SPLIT_PASSES
-        kname = (f'conv3x3_ws_f16x3_kernel<{C_},EPI> + conv3x3_wgrad_f16x3_ws_kernel<{C_},{C_}> (decoder 3x3 conv {C_}->{C_}: '
-                 f'fwd, dgrad, wgrad launches; fp32 in/out, operands split into f16 hi+lo, 3 f16 MFMAs, fp32 accumulate)')
-    else:
-        peak = PEAK_F32_MFMA_TFLOPS
-        kname = (f'conv3x3_tile_kernel<{C_},{C_}> + conv3x3_wgrad_tile_kernel<{C_},{C_}> (decoder 3x3 conv {C_}->{C_}: '
-                 f'fwd, dgrad, wgrad launches; exact fp32 MFMA)')
-    per_kernel_traffic, traffic_src = pmc_traffic(args, B, K)
-    traffic = None
-    if per_kernel_traffic and dom_n:
-        # launch-weighted mean over the forward / data-gradient / weight-gradient launches, like `achieved`
-        w = {c: prof[c]['launches'] for c in DOMINANT if c in prof}
-        if all(c in per_kernel_traffic for c in w):
-            traffic = sum(per_kernel_traffic[c] * n for c, n in w.items()) / sum(w.values())
-    per_form = {c: dict(ms_avg=prof[c]['ms_avg'], tflops=round(flops_per_launch / (prof[c]['ms_avg'] * 1e-3) / 1e12, 1),
-                        frac=round(flops_per_launch / (prof[c]['ms_avg'] * 1e-3) / 1e12 / peak, 4))
-                for c in DOMINANT if c in prof}
-    roofline = dict(bound='mfma', kernel=kname, achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
+    peak = PEAK_F16_MFMA_TFLOPS / SPLIT_PASSES if args.conv_precision == 1 else PEAK_F32_MFMA_TFLOPS
+    per_kernel_traffic, pmc_pipe, traffic_src = pmc_record(args, B, K)
+
+    def mfma_roofline(pr, steps_counted, step_ms, in_timed):
+        dom_ms = sum(pr[c]['ms_total'] for c in DOMINANT if c in pr)
+        dom_n = sum(pr[c]['launches'] for c in DOMINANT if c in pr)
+        achieved = flops_per_launch / (dom_ms / dom_n * 1e-3) / 1e12 if dom_n else 0.0
+        if args.conv_precision == 1:
+            # the kernel executes SPLIT_PASSES f16 MFMAs per algorithmic (fp32-class) multiply-add: the peak for ALGORITHMIC
+            # FLOPs is the dense f16 MFMA peak divided by the number of passes
+            kname = (f'conv3x3_ws_f16x3_kernel<{C_},EPI> + conv3x3_wgrad_f16x3_ws_kernel<{C_},{C_}> (decoder 3x3 conv {C_}->{C_}: '
+                     f'fwd, dgrad, wgrad launches; fp32 in/out, operands split into f16 hi+lo, 3 f16 MFMAs, fp32 accumulate)')
+        else:
+            kname = (f'conv3x3_tile_kernel<{C_},{C_}> + conv3x3_wgrad_tile_kernel<{C_},{C_}> (decoder 3x3 conv {C_}->{C_}: '
+                     f'fwd, dgrad, wgrad launches; exact fp32 MFMA)')
+        traffic = None
+        if per_kernel_traffic and dom_n:
+            # launch-weighted mean over the forward / data-gradient / weight-gradient launches, like `achieved`
+            w = {c: pr[c]['launches'] for c in DOMINANT if c in pr}
+            if all(c in per_kernel_traffic for c in w):
+                traffic = sum(per_kernel_traffic[c] * n for c, n in w.items()) / sum(w.values())
+        per_form = {c: dict(ms_avg=pr[c]['ms_avg'], tflops=round(flops_per_launch / (pr[c]['ms_avg'] * 1e-3) / 1e12, 1),
+                            frac=round(flops_per_launch / (pr[c]['ms_avg'] * 1e-3) / 1e12 / peak, 4))
+                    for c in DOMINANT if c in pr}
+        avg_ms = dom_ms / max(dom_n, 1)
+        return dict(bound='mfma', kernel=kname, achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
                     frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_src,
-                    traffic_per_kernel=per_kernel_traffic, matrix_pipe_pmc=PMC_PIPE,
-                    flops_per_launch=flops_per_launch, avg_launch_ms=round(dom_ms / max(dom_n, 1), 4),
-                    launches=dom_n, events_in_timed_region=timed_events, per_form=per_form,
-                    kernel_time_share=round(dom_ms / max(dom_n, 1) * (dom_n / (args.steps if timed_events else 2)) / ms_per_step, 4),
+                    traffic_per_kernel=({c: per_kernel_traffic[c] for c in DOMINANT if c in per_kernel_traffic}
+                                        if per_kernel_traffic else None),
+                    matrix_pipe_pmc=pmc_pipe, flops_per_launch=flops_per_launch, avg_launch_ms=round(avg_ms, 4),
+                    launches=dom_n, events_in_timed_region=in_timed, per_form=per_form,
+                    kernel_time_share=round(avg_ms * (dom_n / max(steps_counted, 1)) / step_ms, 4),
                     executed_mfma_tflops=round(achieved * (SPLIT_PASSES if args.conv_precision == 1 else 1), 1),
                     algorithmic_hbm_bytes_per_launch=2.0 * B * K * S * S * C_ * 4,
-                    hbm_gbps_algorithmic=round(2.0 * B * K * S * S * C_ * 4 / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9, 1))
+                    hbm_gbps_algorithmic=round(2.0 * B * K * S * S * C_ * 4 / (avg_ms * 1e-3) / 1e9, 1) if dom_n else None)
+
+    def hbm_roofline(pr, mode, steps_counted):
+        """The HBM regime: every helper category with known algorithmic bytes -> achieved GB/s vs 8 TB/s; the reported kernel is
+        the one with the largest time x (1 - frac) per step (what a perfect streaming kernel would give back)."""
+        alg = hbm_algorithmic_bytes(arch, B, mode)
+        cand = {}
+        for c, nbytes in alg.items():
+            if c not in pr:
+                continue
+            ms = pr[c]['ms_avg']
+            gbps = nbytes / (ms * 1e-3) / 1e9
+            cand[c] = dict(ms_avg=ms, launches_per_step=round(pr[c]['launches'] / steps_counted, 2), algorithmic_bytes=round(nbytes),
+                           gbps=round(gbps, 1), frac=round(gbps / PEAK_HBM_GBPS, 4),
+                           ms_per_step=round(pr[c]['ms_total'] / steps_counted, 3),
+                           ms_per_step_above_roof=round(pr[c]['ms_total'] / steps_counted * (1.0 - gbps / PEAK_HBM_GBPS), 3),
+                           traffic=(per_kernel_traffic or {}).get(c))
+        if not cand:
+            return None
+        worst = max(cand, key=lambda c: cand[c]['ms_per_step_above_roof'])
+        w = cand[worst]
+        return dict(bound='hbm', kernel=worst, achieved=w['gbps'], peak=PEAK_HBM_GBPS, unit='GB/s', frac=w['frac'],
+                    traffic=w['traffic'], traffic_source=traffic_src, algorithmic_bytes_per_launch=w['algorithmic_bytes'],
+                    avg_launch_ms=w['ms_avg'], launches_per_step=w['launches_per_step'], events_in_timed_region=False,
+                    selection='largest time x (1 - frac) per step over the HBM-bound helper categories (extra pass of '
+                              f'{steps_counted} steps, every launch bracketed with HIP events)',
+                    candidates=cand)
+
+    def level2_pass(fn, n=3):
+        model.set_option('graph', 0)
+        model.set_option('profile', 2)
+        for _ in range(n):
+            fn()
+        barrier()
+        model.set_option('profile', 0)
+        return read_prof(), n
+
+    prof_all, n2 = level2_pass(step)
+    for cat, v in prof_all.items():
+        prof.setdefault(cat, dict(v, note='untimed pass'))
+    roofline = mfma_roofline(prof if timed_events else prof_all, args.steps if timed_events else n2, ms_per_step, timed_events)
+    roofline_hbm = hbm_roofline(prof_all, args.mode, n2)
+
+    # secondary measurement (not `value`): the other step type on the same workload, with its own roofline
+    other = None
+    if args.mode == 'train':
+        istep, _ = make_step(model, x, 'infer')
+        istep()
+        model.set_option('graph', args.graph)
+        model.set_option('profile', 0 if args.graph else 1)
+        dti = timed(istep, args.steps)
+        iprof = read_prof()
+        model.set_option('profile', 0)
+        ims = dti / args.steps * 1e3
+        n_inf = args.steps
+        if not args.no_sustain and dti < SUSTAIN_S / 2:
+            n_more = int(math.ceil((SUSTAIN_S / 2 - dti) / (dti / args.steps)))
+            timed(istep, n_more)
+            n_inf += n_more
+        iprof_all, ni2 = level2_pass(istep)
+        other = dict(step='infer (reconstruct: T iterations + final decode)', ms_per_step=round(ims, 3), steps=args.steps,
+                     steps_run=n_inf, image_refinement_iters_per_s=round(world * B * T / (dti / args.steps), 2),
+                     roofline=mfma_roofline(iprof if iprof else iprof_all, args.steps if iprof else ni2, ims, bool(iprof)),
+                     roofline_hbm=hbm_roofline(iprof_all, 'infer', ni2), kernels=iprof_all)
 
     cfg_name = 'CLEVR6 128x128' if args.config == 'clevr6' else 'multi-dSprites 64x64'
     what = ('reconstruct: T iterations + final decode' if args.mode == 'infer'
@@ -317,7 +439,9 @@ def main():
                            step=args.mode, global_batch=B * world, slots=K, iters=T, img_size=S, hip_graph=bool(args.graph),
                            parallelism=f'dp{world} (images sharded over ranks; '
                                        f'{"one RCCL all-reduce of the flat gradient buffer per step" if args.mode == "train" else "no data-path collective"})'),
-               batch_iters_per_s=round(T / (dt / args.steps), 3), roofline=roofline, kernels=prof)
+               batch_iters_per_s=round(T / (dt / args.steps), 3), roofline=roofline, roofline_hbm=roofline_hbm, kernels=prof)
+    if sustained:
+        out['sustained'] = sustained
     if other:
         out['inference_step'] = other
 
@@ -335,20 +459,19 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = max_over_ranks(e0.elapsed_time(e1) / 20 * 1e3)
+        replicas_after = parallel.replicas_identical(model.parameters())
         out['rccl'] = dict(world_size=dist.get_world_size(), backend=dist.get_backend(), allreduce_bytes=nflat * 4,
-                           allreduce_us=round(us, 1), per_step=1 if args.mode == 'train' else 0)
+                           allreduce_us=round(us, 1), per_step=1 if args.mode == 'train' else 0,
+                           replicas_identical=bool(replicas_before and replicas_after),
+                           replicas_identical_before_first_step=bool(replicas_before),
+                           replicas_identical_after_last_step=bool(replicas_after))
 
     if rank == 0 and world == 1 and args.mode == 'train' and not args.no_exact_fp32 and args.conv_precision == 1:
         # the precision trade on the record: the same step on the exact fp32-MFMA path (v_mfma_f32_32x32x2_f32)
         model.set_option('conv_precision', 0)
         step()
         model.set_option('profile', 1)
-        barrier()
-        t2 = time.perf_counter()
-        for _ in range(2):
-            step()
-        barrier()
-        dtx = (time.perf_counter() - t2) / 2
+        dtx = timed(step, 2) / 2
         model.set_option('profile', 0)
         px = read_prof()
         xm = sum(px[c]['ms_total'] for c in DOMINANT if c in px)
@@ -358,6 +481,30 @@ def main():
                                  achieved_tflops=round(xa, 2), frac_of_157_3=round(xa / PEAK_F32_MFMA_TFLOPS, 4),
                                  speedup_of_default_path=round(dtx * 1e3 / ms_per_step, 2))
         model.set_option('conv_precision', 1)
+
+    if rank == 0 and world == 1 and not args.no_extra_configs and args.config == 'clevr6' and args.conv_precision == 1 \
+            and not (args.slots or args.iters) and args.mode == 'train':
+        # BASELINE configs[1] and the per-GPU shard of configs[4] on the same box, same process: 2 warm-up + 5 timed steps of each
+        # step type.  Side measurements - `value` above is configs[2].
+        side = {}
+        for tag, (cfgname, slots, iters, bsz) in dict(cfg2=('dsprites', 6, 5, 32), cfg5_shard=('clevr6', 11, 7, 8)).items():
+            m2, a2, _ = build_model(cfgname, slots, iters, device)
+            m2.manual_seed(99)
+            x2 = torch.from_numpy(synth.make_images(bsz, a2.IMG_SIZE, seed=0)).to(device)
+            rec = dict(workload=f'{"multi-dSprites 64x64" if cfgname == "dsprites" else "CLEVR 128x128"}, K={slots}, T={iters}, '
+                                f'batch {bsz}, 1 GPU', steps=5)
+            for md in ('train', 'infer'):
+                st2, _ = make_step(m2, x2, md)
+                for _ in range(2):
+                    st2()
+                d2 = timed(st2, 5) / 5
+                rec[f'{md}_ms'] = round(d2 * 1e3, 3)
+                rec[f'{md}_iters_per_s'] = round(bsz * iters / d2, 1)
+                del st2
+            side[tag] = rec
+            del m2, x2
+            torch.cuda.empty_cache()
+        out['configs'] = side
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, (xc, ec, ref_elbos, ref_grads) = cpu_baseline(args, arch, params, args.mode)

@@ -29,7 +29,7 @@ extern "C" {
 #define IODINE_ERR_STATE 3         /* call order violated (params not set, no forward before backward ...) */
 #define IODINE_ERR_WORKSPACE 4     /* caller-provided workspace too small */
 
-#define IODINE_ABI_VERSION 2
+#define IODINE_ABI_VERSION 3
 
 /* bit i set <=> the i-th entry of ARCH.ENCODING is enabled; order = code order of
  * IODINE.get_input_encoding (iodine.py:253-340).  Only IODINE_ENC_FULL (every shipped
@@ -120,6 +120,12 @@ int iodine_elbo(iodine_handle* h, void* stream, int batch, const float* x, const
 int iodine_last_elbo_outputs(iodine_handle* h, void* stream, int count, float* z, float* mean, float* mask,
                              float* mask_logits, float* pred);
 
+/* self.posterior.mean / self.posterior.logvar as the reference's module holds them after the last call (Gaussian.update,
+ * iodine.py:636-645, leaves lambda_T on the module after forward / encode; a following model.elbo(x) samples from it,
+ * iodine.py:170): post_mean / post_logvar (count,K,L) of the first `count` images of the last refinement call; either may be
+ * NULL. */
+int iodine_last_posterior(iodine_handle* h, void* stream, int count, float* post_mean, float* post_logvar);
+
 /* loss = model(x) -- IODINE.forward, iodine.py:115-158.  loss (1) and elbo_iter (T+1,3) are device outputs.
  * Keeps what iodine_train_backward needs in the workspace (the autograd graph of the reference). */
 int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float* x, const float* eps,
@@ -189,7 +195,9 @@ int iodine_set_option(iodine_handle* h, const char* key, double value);
 /* Sum of event-measured durations (ms) and number of launches of one kernel category since the last reset:
  * "conv_tile_fwd", "conv_tile_dgrad", "conv_tile_wgrad", "dec_out", "dec_out_dgrad", "dec_out_wgrad", "dec_out_bwd", "dec_l0",
  * "l0_reduce",
- * "pixel_pass1", "pixel_pass2", "refine_conv", "refine_head".  Synchronises on the recorded events. */
+ * "pixel_pass1", "pixel_pass2", "refine_l0" (first refinement layer), "refine_conv" (the others), "refine_head", "refine_wgrad",
+ * "refine_dgrad".  Synchronises on the recorded events.  Two more names report
+ * the hipGraph bookkeeping of option "graph" in *launches: "graph_captures" (graphs instantiated) and "graph_replays". */
 int iodine_profile_read(iodine_handle* h, const char* category, double* total_ms, long long* launches, int reset);
 /* Copy an internal buffer of the last call (name as listed in DESIGN.md "workspace") to dst (device). */
 int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter, float* dst, size_t max_floats,

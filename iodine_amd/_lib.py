@@ -20,7 +20,7 @@ ENC_FULL = 0xFFF
 EXPORTS = (
     'iodine_abi_version', 'iodine_create', 'iodine_destroy', 'iodine_last_error', 'iodine_num_params',
     'iodine_param_info', 'iodine_set_params', 'iodine_workspace_bytes', 'iodine_set_workspace',
-    'iodine_reconstruct', 'iodine_decode', 'iodine_elbo', 'iodine_last_elbo_outputs', 'iodine_randn',
+    'iodine_reconstruct', 'iodine_decode', 'iodine_elbo', 'iodine_last_elbo_outputs', 'iodine_last_posterior', 'iodine_randn',
     'iodine_train_forward', 'iodine_train_backward', 'iodine_train_backward_flat', 'iodine_logger_scalars',
     'iodine_adam_step', 'iodine_ari_table', 'iodine_set_option', 'iodine_profile_read', 'iodine_debug_copy', 'iodine_linspace_host', 'iodine_op_conv3x3', 'iodine_op_dec_out',
     'iodine_op_conv3x3_wgrad',
@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
     L.iodine_decode.argtypes = [vp, vp, ci] + [vp] * 4
     L.iodine_elbo.argtypes = [vp, vp, ci] + [vp] * 5
     L.iodine_last_elbo_outputs.argtypes = [vp, vp, ci] + [vp] * 5
+    L.iodine_last_posterior.argtypes = [vp, vp, ci, vp, vp]
     L.iodine_randn.argtypes = [vp, vp, C.c_longlong, C.c_ulonglong, C.c_ulonglong]
     L.iodine_train_forward.argtypes = [vp, vp, ci] + [vp] * 4
     L.iodine_train_backward.argtypes = [vp, vp, cf, C.POINTER(vp), ci]
@@ -94,7 +95,7 @@ def lib() -> C.CDLL:
     L.iodine_op_conv3x3.argtypes = [vp, ci] + [vp] * 5 + [ci] * 10
     L.iodine_op_dec_out.argtypes = [vp] + [vp] * 4 + [ci] * 3
     L.iodine_op_conv3x3_wgrad.argtypes = [vp] + [vp] * 4 + [ci] * 6
-    if L.iodine_abi_version() != 2:
+    if L.iodine_abi_version() != 3:
         raise RuntimeError('libiodine_hip.so ABI version mismatch')
     _lib = L
     return L

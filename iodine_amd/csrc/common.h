@@ -3,12 +3,44 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define IOD_DEVINL __device__ __forceinline__
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to (function, device): every launcher instance keeps a bit mask of
+// the devices it has configured (`devs`, a function-local static) instead of one process-wide flag, so a second device in the
+// same process - tests, one handle per device - gets the attribute too.  Idempotent, so a race between two threads is benign.
+inline hipError_t iod_set_max_lds(const void* fn, int bytes, std::atomic<unsigned>& devs)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned bit = 1u << (dev & 31);
+    if (devs.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) devs.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+// compute units of the CURRENT device (persistent grids are sized from it), cached per device
+inline hipError_t iod_cu_count(int* n_cu)
+{
+    static std::atomic<int> cache[32];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    int v = cache[dev & 31].load(std::memory_order_acquire);
+    if (!v) {
+        e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        cache[dev & 31].store(v, std::memory_order_release);
+    }
+    *n_cu = v;
+    return hipSuccess;
+}
 
 // Timing-only ablation hook for tools/helper_cost.py: a library built with -DIODINE_XSKIP_HOOK lets
 // iodine_set_option("xskip", mask) turn the tagged launchers into no-ops (results are then WRONG; the product build has no

@@ -411,7 +411,8 @@ int ensure_workspace(iodine_handle* h, int B, int mode)
     plan(h, B, mode, a, h->buf);
     h->fwd_done = false;                 // a re-planned arena no longer holds the saved forward / the last elbo() outputs
     h->last_elbo_iter = -1;
-    drop_graphs(h);
+    // captured graphs stay: their key holds the arena's base address, the batch and (through the entry point) the mode, and the
+    // carve-up is a pure function of those - a step that alternates training and reconstruct calls keeps replaying both
     return IODINE_OK;
 }
 
@@ -596,23 +597,23 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
     Buffers& b = h->buf;
     const int N = B * h->K;
     // split first layer: the channels every slot of an image shares are written and convolved once per image
-    const bool split = refine_split_on(h);
-    if (save) h->fwd_split = split;
+    const bool split = refine_split_on(h);     // (training: iodine_train_forward records the form in h->fwd_split - host state must
+                                               //  not be written here, a hipGraph replay does not execute this body)
     PROF(h, st, "pixel_pass2", launch_pixel_pass2(st, b.x4, b.dec_out, b.lnstat, h->lin, split ? b.enck[i] : b.enc[i], B, h->K, h->S,
                                                   (float)h->cfg.sigma, split ? b.encs[i] : nullptr));
     int s = h->S;
     const float* in = b.enc[i];
     for (int l = 0; l < h->Dr; ++l) {
         if (l == 0 && split) {
-            PROF(h, st, "refine_conv", launch_conv3x3_s2_f16x3(st, b.encs[i], h->ref_wsh16, h->ref_wshmeta, nullptr, b.rmap, B, s, 8,
-                                                               h->Cr));
-            PROF(h, st, "refine_conv", launch_conv3x3_s2_f16x3(st, b.enck[i], h->ref_wk16, h->ref_wkmeta, h->ref_b[0], b.ract[i][0], N,
-                                                               s, 12, h->Cr, b.rmap, h->K));
+            PROF(h, st, "refine_l0", launch_conv3x3_s2_f16x3(st, b.encs[i], h->ref_wsh16, h->ref_wshmeta, nullptr, b.rmap, B, s, 8,
+                                                             h->Cr));
+            PROF(h, st, "refine_l0", launch_conv3x3_s2_f16x3(st, b.enck[i], h->ref_wk16, h->ref_wkmeta, h->ref_b[0], b.ract[i][0], N,
+                                                             s, 12, h->Cr, b.rmap, h->K));
         } else if (h->precision == 1 && refine_f16_ok(h))
-            PROF(h, st, "refine_conv", launch_conv3x3_s2_f16x3(st, in, h->ref_wf16[l], h->ref_wmeta[l], h->ref_b[l],
+            PROF(h, st, l == 0 ? "refine_l0" : "refine_conv", launch_conv3x3_s2_f16x3(st, in, h->ref_wf16[l], h->ref_wmeta[l], h->ref_b[l],
                                                                b.ract[i][l], N, s, l == 0 ? 20 : h->Cr, h->Cr));
         else
-            PROF(h, st, "refine_conv", launch_conv3x3_gather(st, in, h->ref_w[l], h->ref_b[l], b.ract[i][l], N, s, s,
+            PROF(h, st, l == 0 ? "refine_l0" : "refine_conv", launch_conv3x3_gather(st, in, h->ref_w[l], h->ref_b[l], b.ract[i][l], N, s, s,
                                                              l == 0 ? 20 : h->Cr, h->Cr, 2));
         in = b.ract[i][l];
         s = ref_out_size(s);
@@ -916,8 +917,7 @@ int iodine_set_workspace(iodine_handle* h, void* dev_ptr, size_t bytes)
     h->buf = Buffers();
     h->fwd_done = false;
     h->last_elbo_iter = -1;
-    drop_graphs(h);
-    return IODINE_OK;
+    return IODINE_OK;                    // graphs are keyed by the arena address (see ensure_workspace)
 }
 
 int iodine_set_option(iodine_handle* h, const char* key, double value)
@@ -1070,6 +1070,20 @@ int iodine_last_elbo_outputs(iodine_handle* h, void* stream, int count, float* z
     return IODINE_OK;
 }
 
+int iodine_last_posterior(iodine_handle* h, void* stream, int count, float* post_mean, float* post_logvar)
+{
+    if (!h) return IODINE_ERR_INVALID;
+    if (h->last_elbo_iter < 0 || h->buf.bytes == 0)
+        return h->fail(IODINE_ERR_STATE, "iodine_last_posterior: no refinement has run on the current workspace");
+    if (count < 1 || count > h->last_elbo_batch)
+        return h->fail(IODINE_ERR_INVALID, "iodine_last_posterior: count must be in 1..batch of the last call");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = sizeof(float) * (size_t)count * h->K * h->L;
+    if (post_mean) HIPCHK(h, hipMemcpyAsync(post_mean, h->buf.pm, n, hipMemcpyDeviceToDevice, st));
+    if (post_logvar) HIPCHK(h, hipMemcpyAsync(post_logvar, h->buf.plv, n, hipMemcpyDeviceToDevice, st));
+    return IODINE_OK;
+}
+
 int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float* x, const float* eps, float* loss,
                          float* elbo_iter)
 {
@@ -1114,6 +1128,7 @@ int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float*
     if (rc) return rc;
     h->fwd_done = true;
     h->fwd_batch = B;
+    h->fwd_split = refine_split_on(h);     // layout of the saved refinement inputs (refine_split is part of the graph key)
     h->last_elbo_iter = T;
     h->last_elbo_batch = B;
     return IODINE_OK;
@@ -1136,6 +1151,7 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
     key.push_back(gs_bits);
     key.push_back((uintptr_t)grad_scale_dev);
     key.push_back((uintptr_t)accumulate);
+    key.push_back((uintptr_t)h->fwd_split);                // the backward body reads the saved inputs in the forward's layout
     auto body = [&]() -> int {
     Buffers& b = h->buf;
     const int B = h->fwd_batch, N = B * h->K, T = h->T, L = h->L, H = h->H, Cr = h->Cr, IN = H + 4 * L;
@@ -1326,6 +1342,12 @@ int iodine_profile_read(iodine_handle* h, const char* category, double* total_ms
 {
     if (!h || !category) return IODINE_ERR_INVALID;
     double tot = 0.0; long long cnt = 0;
+    if (!strcmp(category, "graph_captures") || !strcmp(category, "graph_replays")) {    // hipGraph bookkeeping (option "graph")
+        if (total_ms) *total_ms = 0.0;
+        if (launches) *launches = category[6] == 'c' ? h->graph_captures : h->graph_replays;
+        if (reset) { if (category[6] == 'c') h->graph_captures = 0; else h->graph_replays = 0; }
+        return IODINE_OK;
+    }
     for (auto& c : h->prof) {
         if (c.name != category) continue;
         for (size_t i = 0; i < c.used; ++i) {

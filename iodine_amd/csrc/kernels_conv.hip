@@ -169,13 +169,8 @@ static hipError_t launch_tile_inst(hipStream_t st, const float* in, const float*
     constexpr int CC = conv_cc(CIN);
     constexpr int CP = (CC == 4) ? 4 : CC + 4;
     constexpr size_t lds = (size_t)(18 * 18 * CP) * 4 + (size_t)conv_nqp(CIN) * COUT * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_tile_kernel<CIN, COUT, EPI>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
+    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_tile_kernel<CIN, COUT, EPI>, (int)lds, attr_devs); e != hipSuccess) return e;
     const int tiles = S / 16;
     hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, COUT, EPI>), dim3(N * tiles * tiles), dim3(256), lds, st, in,
                        reinterpret_cast<const float4*>(wpk), bias, aux, out, S, tiles);
@@ -920,13 +915,8 @@ static hipError_t launch_tile_f16x3_inst(hipStream_t st, const float* in, const 
     constexpr size_t lds_stage = (size_t)(18 * (TH + 2) + 1) * 80 + (size_t)9 * 2 * 2 * COUT * 16 + 16;
     constexpr size_t lds_epi = (size_t)4 * (TH * 4) * (COUT + 4) * 4;              // output tile, transposed for contiguous stores
     constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_tile_f16x3_kernel<CIN, COUT, EPI, TH>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
+    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_tile_f16x3_kernel<CIN, COUT, EPI, TH>, (int)lds, attr_devs); e != hipSuccess) return e;
     const int tiles = S / 16;
     hipLaunchKernelGGL((conv3x3_tile_f16x3_kernel<CIN, COUT, EPI, TH>), dim3(N * tiles * tiles * (16 / TH)), dim3(256), lds, st, in,
                        reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, S, tiles, rev);

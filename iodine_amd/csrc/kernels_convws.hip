@@ -666,20 +666,10 @@ static hipError_t launch_ws_inst(hipStream_t st, const float* in, const void* wp
 {
     constexpr size_t buf_in = (size_t)(18 * 10 + 1) * 160, buf_out = (size_t)128 * (C * 4 + 32);
     constexpr size_t lds = 2 * (buf_in > buf_out ? buf_in : buf_out);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_ws_f16x3_kernel<C, EPI>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess) return e;
-    }
+    static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
+    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_ws_f16x3_kernel<C, EPI>, (int)lds, attr_devs); e != hipSuccess) return e;
+    int n_cu = 0;
+    if (hipError_t e = iod_cu_count(&n_cu); e != hipSuccess) return e;
     int lgS = 0;
     while ((1 << lgS) < S) ++lgS;
     const int ntiles = N * (S / 16) * (S / 8);

@@ -835,12 +835,8 @@ hipError_t launch_refine_head(hipStream_t st, const float* feat, int N, int PL, 
     if (256 % C != 0) return hipErrorInvalidValue;
     if ((H + 4 * L) % 4 != 0 || H % 4 != 0 || L % 4 != 0 || C % 4 != 0) return hipErrorInvalidValue;
     const size_t lds = (size_t)(C + (H + 4 * L) + H + H + 256 + 16 * 4 * H) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)refine_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
+    if (hipError_t e = iod_set_max_lds((const void*)refine_head_kernel, 96 * 1024, attr_devs); e != hipSuccess) return e;
     if (lds > 96 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(refine_head_kernel, dim3(N), dim3(1024), lds, st, feat, PL, C, H, L, mlp_wT, mlp_b, wihT, whhT,
                        lstm_b, wmT, bm, wvT, bv, latent, h_prev, c_prev, h_out, c_out, pm, plv, sv_pooled, sv_s,

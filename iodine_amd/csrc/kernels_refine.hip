@@ -329,13 +329,8 @@ hipError_t launch_s2_inst(hipStream_t st, const float* in, const void* wpk, cons
                           const float* aux, float* out, int N, int Sc, int kdiv = 0)
 {
     constexpr size_t lds = (size_t)(17 * 17 + 1) * 80 + (size_t)4 * 4 * COUT * 16 + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_s2_f16x3_kernel<CIN_REAL, CIN, COUT, MODE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
+    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_s2_f16x3_kernel<CIN_REAL, CIN, COUT, MODE>, (int)lds, attr_devs); e != hipSuccess) return e;
     const int tiles = (Sc + 15) / 16;
     hipLaunchKernelGGL((conv3x3_s2_f16x3_kernel<CIN_REAL, CIN, COUT, MODE>), dim3(N * tiles * tiles, MODE == 0 ? 1 : 4),
                        dim3(256), lds, st, in, reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, Sc, tiles, kdiv);
@@ -594,13 +589,8 @@ hipError_t launch_s2_wgrad_inst(hipStream_t st, const float* a, const float* d, 
     constexpr int MT = CI / 32, NTT = NCO / 32, KS = 4 / (MT * NTT);
     constexpr size_t lds = (size_t)(2 * CI * (2 * TH + 1) * 20 + 2 * NCO * (TH * 8 + 4)) * 4 + 32;
     static_assert(lds >= 256 * 16, "bias reduction reuses the planes");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_s2_wgrad_f16x3_kernel<CI_REAL, CI, NCO, TH>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
+    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_s2_wgrad_f16x3_kernel<CI_REAL, CI, NCO, TH>, (int)lds, attr_devs); e != hipSuccess) return e;
     const int tiles_x = (Sc + 15) / 16, tiles_y = (Sc + TH - 1) / TH, ntiles = N * tiles_x * tiles_y;
     const int blocks = ntiles < 512 ? ntiles : 512;
     hipLaunchKernelGGL((conv3x3_s2_wgrad_f16x3_kernel<CI_REAL, CI, NCO, TH>), dim3(blocks), dim3(256), lds, st, a, d, part,

@@ -118,13 +118,8 @@ static hipError_t launch_wgrad_tile_inst(hipStream_t st, const float* a, const f
 {
     constexpr int MT = CI / 32, NTT = (NCO + 31) / 32, KS = 4 / (MT * NTT);
     constexpr size_t lds = (size_t)(10 * 18 * CI + 8 * 16 * NCO) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_tile_kernel<CI, NCO>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
+    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_wgrad_tile_kernel<CI, NCO>, (int)lds, attr_devs); e != hipSuccess) return e;
     const int tiles_x = S / 16, tiles_y = S / 8, ntiles = N * tiles_x * tiles_y;
     const int blocks = wgrad_tile_blocks(N, S);
     hipLaunchKernelGGL((conv3x3_wgrad_tile_kernel<CI, NCO>), dim3(blocks), dim3(256), lds, st, a, d, part, part_b, S,
@@ -1022,13 +1017,8 @@ static hipError_t launch_wgrad_f16_inst(hipStream_t st, const float* a, const fl
 {
     constexpr int MT = CI / 32, NTT = (NCO + 31) / 32, KS = 4 / (MT * NTT);
     constexpr size_t lds = (size_t)(2 * CI * 76 + 2 * NCO * 36) * 4 + 32;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_f16x3_kernel<CI, NCO>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
+    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_wgrad_f16x3_kernel<CI, NCO>, (int)lds, attr_devs); e != hipSuccess) return e;
     const int tiles_x = S / 16, tiles_y = S / 4, ntiles = N * tiles_x * tiles_y;
     const int blocks = wgrad_f16_blocks(N, S);
     hipLaunchKernelGGL((conv3x3_wgrad_f16x3_kernel<CI, NCO>), dim3(blocks), dim3(256), lds, st, a, d, part, part_b, S,
@@ -2071,13 +2061,8 @@ static hipError_t launch_wgrad_f16_ws_inst(hipStream_t st, const float* a, const
     constexpr size_t buf = TR ? (size_t)6 * 20 * (2 * CI * 2 + 64) + (size_t)4 * 16 * (2 * NCO * 2 + 64)
                               : (size_t)(2 * CI * 76 + 2 * NCO * 36) * 4;
     constexpr size_t lds = 2 * buf + 26 * 4 + 32;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_f16x3_ws_kernel<CI, NCO, TR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
+    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_wgrad_f16x3_ws_kernel<CI, NCO, TR>, (int)lds, attr_devs); e != hipSuccess) return e;
     const int tiles_x = S / 16, tiles_y = S / 4, ntiles = N * tiles_x * tiles_y;
     const int blocks = ntiles < 256 ? ntiles : 256;
     hipLaunchKernelGGL((conv3x3_wgrad_f16x3_ws_kernel<CI, NCO, TR>), dim3(blocks), dim3(512), lds, st, a, d, part, part_b, S,

@@ -183,6 +183,7 @@ class IODINE(nn.Module):
         self._draws = 0                 # Philox stream id: one per eps draw
         self._call_serial = 0           # bumped by every compute call; a backward must match the forward that saved state
         self._graph_stream = None
+        self._graph_bufs: Dict[tuple, torch.Tensor] = {}
 
     # ---- bookkeeping identical to the reference -------------------------------------------------
     def get_input_size(self):
@@ -254,6 +255,38 @@ class IODINE(nn.Module):
             cur.wait_stream(self._graph_stream)
             return out
 
+    # With option ``graph`` the library keys its hipGraphs on the full argument tuple, device addresses included.  Tensors the
+    # caching allocator hands out per call (inputs made contiguous, noise, outputs, the flat gradient buffer) would change that
+    # key from step to step - every call an eager run or a re-capture instead of a replay.  So in graph mode the library only
+    # ever sees persistent staging buffers owned by the module: inputs are copied in, outputs are cloned out.
+    def _graph_on(self):
+        return bool(self._options.get('graph'))
+
+    def _gbuf(self, name, shape, device):
+        key = (name, tuple(shape), str(device))
+        t = self._graph_bufs.get(key)
+        if t is None:
+            t = self._graph_bufs[key] = torch.empty(tuple(shape), device=device, dtype=torch.float32)
+        return t
+
+    def _stage(self, name, t):
+        """``t`` as the library should see it: itself, or (graph mode) its copy in the persistent buffer ``name``."""
+        if t is None or not self._graph_on():
+            return t
+        buf = self._gbuf(name, t.shape, t.device)
+        if buf.data_ptr() != t.data_ptr():
+            buf.copy_(t)
+        return buf
+
+    def _out(self, name, shape, device):
+        if self._graph_on():
+            return self._gbuf(name, shape, device)
+        return torch.empty(tuple(shape), device=device, dtype=torch.float32)
+
+    def _own(self, t):
+        """What the caller gets: the tensor itself, or (graph mode) a copy that the next call will not overwrite."""
+        return t.clone() if (t is not None and self._graph_on()) else t
+
     def manual_seed(self, seed: int):
         """Seed of the library's generator for the ``eps=None`` draws (Philox4x32-10; give every rank its own seed)."""
         self._seed, self._draws = int(seed) & (2 ** 64 - 1), 0
@@ -302,14 +335,14 @@ class IODINE(nn.Module):
 
     def _normals(self, eps, shape, device):
         if eps is None:
-            out = torch.empty(shape, device=device, dtype=torch.float32)
+            out = self._out('eps', shape, device)
             self._launch(device, lambda: _lib.check(_lib.lib().iodine_randn(self._stream(), _lib.ptr(out), out.numel(),
                                                                           self._seed, self._draws), None, 'iodine_randn'))
             self._draws += 1
             return out
         if tuple(eps.shape) != shape:
             raise RuntimeError(f'eps must have shape {shape}, got {tuple(eps.shape)}')
-        return eps.detach().to(device=device, dtype=torch.float32).contiguous()
+        return self._stage('eps', eps.detach().to(device=device, dtype=torch.float32).contiguous())
 
     def debug_buffer(self, name: str, iteration: int = 0) -> torch.Tensor:
         """Copy of an internal workspace buffer of the last call (tests only)."""
@@ -397,6 +430,15 @@ class IODINE(nn.Module):
         logger.update(**{f'mask_{i}': mask[0, i, 0] for i in range(K)})
         logger.update(**{f'pred_{i}': mean[0, i] for i in range(K)})
 
+    def _fetch_posterior(self, h, B, dev):
+        """``self.posterior.mean / logvar`` = lambda_T, what ``Gaussian.update`` (iodine.py:636-645) leaves on the reference's
+        module after ``forward``: a following ``model.elbo(x)`` samples from it."""
+        pm = torch.empty((B, self.K, self.dim_latent), device=dev, dtype=torch.float32)
+        plv = torch.empty_like(pm)
+        self._launch(dev, lambda: _lib.check(_lib.lib().iodine_last_posterior(h, self._stream(), B, _lib.ptr(pm), _lib.ptr(plv)),
+                                             h, 'iodine_last_posterior'))
+        self.posterior.mean, self.posterior.logvar = pm, plv
+
     @torch.no_grad()
     def _reconstruct(self, x, eps, want_images=True):
         x = self._check_x(x)
@@ -414,20 +456,21 @@ class IODINE(nn.Module):
         h = self._sync_params(dev)
         self._ensure_workspace(h, B, 0, dev)
         eps = self._eps(eps, B, dev)
+        xs = self._stage('x', x)
         K, L, S, T = self.K, self.dim_latent, self.img_size, self.n_iters
-        f = dict(device=dev, dtype=torch.float32)
-        pred = torch.empty((B, 3, S, S), **f) if want_images else None
-        mask = torch.empty((B, K, 1, S, S), **f) if want_images else None
-        mean = torch.empty((B, K, 3, S, S), **f) if want_images else None
-        z = torch.empty((B, K, L), **f)
-        pm, plv = torch.empty((B, K, L), **f), torch.empty((B, K, L), **f)
+        pred = self._out('r.pred', (B, 3, S, S), dev) if want_images else None
+        mask = self._out('r.mask', (B, K, 1, S, S), dev) if want_images else None
+        mean = self._out('r.mean', (B, K, 3, S, S), dev) if want_images else None
+        z = self._out('r.z', (B, K, L), dev)
+        pm, plv = self._out('r.pm', (B, K, L), dev), self._out('r.plv', (B, K, L), dev)
         stop = int(self._options.get('stop_after_iters', -1))
         n_it = stop if 0 <= stop <= T else T
-        elbo = torch.empty((n_it, 3), **f)
+        elbo = self._out('r.elbo', (n_it, 3), dev)
         self._call_serial += 1
         self._launch(dev, lambda: _lib.check(_lib.lib().iodine_reconstruct(
-            h, self._stream(), B, _lib.ptr(x), _lib.ptr(eps), _lib.ptr(pred), _lib.ptr(mask), _lib.ptr(mean), _lib.ptr(z),
+            h, self._stream(), B, _lib.ptr(xs), _lib.ptr(eps), _lib.ptr(pred), _lib.ptr(mask), _lib.ptr(mean), _lib.ptr(z),
             _lib.ptr(pm), _lib.ptr(plv), _lib.ptr(elbo)), h, 'iodine_reconstruct'))
+        pred, mask, mean, z, pm, plv, elbo = (self._own(t) for t in (pred, mask, mean, z, pm, plv, elbo))
         self.posterior.mean, self.posterior.logvar, self.elbo_terms = pm, plv, elbo
         if n_it > 0:
             self._fetch_last_elbo(h, x, elbo[-1])        # what the reference's last elbo() call left behind
@@ -454,12 +497,12 @@ class IODINE(nn.Module):
         h = self._sync_params(dev)
         self._ensure_workspace(h, B, 0, dev)
         K, S = self.K, self.img_size
-        f = dict(device=dev, dtype=torch.float32)
-        pred, mask, mean = torch.empty((B, 3, S, S), **f), torch.empty((B, K, 1, S, S), **f), torch.empty((B, K, 3, S, S), **f)
+        z = self._stage('d.z', z)
+        pred, mask, mean = self._out('r.pred', (B, 3, S, S), dev), self._out('r.mask', (B, K, 1, S, S), dev), self._out('r.mean', (B, K, 3, S, S), dev)
         self._call_serial += 1
         self._launch(dev, lambda: _lib.check(_lib.lib().iodine_decode(h, self._stream(), B, _lib.ptr(z), _lib.ptr(pred),
                                                                       _lib.ptr(mask), _lib.ptr(mean)), h, 'iodine_decode'))
-        return pred, mask, mean
+        return self._own(pred), self._own(mask), self._own(mean)
 
     @torch.no_grad()
     def elbo(self, x, eps=None):
@@ -491,11 +534,14 @@ class IODINE(nn.Module):
         if pm is None or plv is None or tuple(pm.shape) != shape or pm.device != dev:
             pm = plv = None
         else:
-            pm, plv = pm.detach().to(torch.float32).contiguous(), plv.detach().to(torch.float32).contiguous()
-        terms = torch.empty((3,), device=dev, dtype=torch.float32)
+            pm = self._stage('e.pm', pm.detach().to(torch.float32).contiguous())
+            plv = self._stage('e.plv', plv.detach().to(torch.float32).contiguous())
+        terms = self._out('e.terms', (3,), dev)
+        xs = self._stage('x', x)
         self._call_serial += 1
-        self._launch(dev, lambda: _lib.check(_lib.lib().iodine_elbo(h, self._stream(), B, _lib.ptr(x), _lib.ptr(pm), _lib.ptr(plv),
+        self._launch(dev, lambda: _lib.check(_lib.lib().iodine_elbo(h, self._stream(), B, _lib.ptr(xs), _lib.ptr(pm), _lib.ptr(plv),
                                                                     _lib.ptr(eps), _lib.ptr(terms)), h, 'iodine_elbo'))
+        terms = self._own(terms)
         self.elbo_terms = terms.view(1, 3)
         self._fetch_last_elbo(h, x, terms)
         return terms[0]
@@ -514,6 +560,7 @@ class IODINE(nn.Module):
         with torch.no_grad():
             h, dev = self._handle, x.device
             self._fetch_last_elbo(h, x, elbo_iter[-1])                                 # final elbo(): iodine.py:226-239
+            self._fetch_posterior(h, x.shape[0], dev)
             stats = torch.empty((2,), device=dev, dtype=torch.float32)
             self._launch(dev, lambda: _lib.check(_lib.lib().iodine_logger_scalars(h, self._stream(), _lib.ptr(stats)), h))
             logger.update(init_mean=stats[0], init_logvar=stats[1])                    # iodine.py:156-157
@@ -523,30 +570,34 @@ class IODINE(nn.Module):
         dev, B = x.device, x.shape[0]
         h = self._sync_params(dev)
         self._ensure_workspace(h, B, 1, dev)
-        loss = torch.empty((), device=dev, dtype=torch.float32)
-        elbo_iter = torch.empty((self.n_iters + 1, 3), device=dev, dtype=torch.float32)
+        loss = self._out('t.loss', (), dev)
+        elbo_iter = self._out('t.elbo', (self.n_iters + 1, 3), dev)
+        xs, eps = self._stage('x', x), self._stage('eps', eps)
         self._call_serial += 1
-        self._launch(dev, lambda: _lib.check(_lib.lib().iodine_train_forward(h, self._stream(), B, _lib.ptr(x), _lib.ptr(eps),
+        self._launch(dev, lambda: _lib.check(_lib.lib().iodine_train_forward(h, self._stream(), B, _lib.ptr(xs), _lib.ptr(eps),
                                                                              _lib.ptr(loss), _lib.ptr(elbo_iter)),
                                              h, 'iodine_train_forward'))
-        return loss, elbo_iter
+        return self._own(loss), self._own(elbo_iter)
 
     def _train_chunked(self, x, eps):
         """Forward + backward of every chunk (see _ChunkedTrainStep): returns the batch loss, the (T+1, 3) ELBO terms of the whole
         batch and d loss / d parameters as one flat buffer in named_parameters() order."""
         dev, B = x.device, x.shape[0]
-        flat = torch.empty(sum(p.numel() for p in self._ordered_params()), device=dev, dtype=torch.float32)
-        loss, terms, parts, sizes = None, None, [], []
+        flat = self._out('t.flat', (sum(p.numel() for p in self._ordered_params()),), dev)
+        loss, terms, parts, sizes, pms, plvs = None, None, [], [], [], []
         for c, (s, e) in enumerate(self._chunks(B, self.max_batch(training=True))):
             xc = x[s:e].contiguous()
             ec = self._eps(None if eps is None else eps[:, s:e], e - s, dev)
             lc, tc = self._train_forward(xc, ec)
             h = self._handle
             w = torch.full((), (e - s) / float(B), device=dev, dtype=torch.float32)
-            self._launch(dev, lambda: _lib.check(_lib.lib().iodine_train_backward_flat(h, self._stream(), _lib.ptr(w), _lib.ptr(flat),
+            ws = self._stage('t.gl', w)
+            self._launch(dev, lambda: _lib.check(_lib.lib().iodine_train_backward_flat(h, self._stream(), _lib.ptr(ws), _lib.ptr(flat),
                                                                                        1 if c else 0), h, 'iodine_train_backward'))
             with torch.no_grad():
                 self._fetch_last_elbo(h, xc, tc[-1])
+                self._fetch_posterior(h, e - s, dev)
+                pms.append(self.posterior.mean); plvs.append(self.posterior.logvar)
                 self.elbo_terms = tc
                 parts.append(self._chunk_state()); sizes.append(e - s)
                 if c == 0:
@@ -557,7 +608,8 @@ class IODINE(nn.Module):
             loss = lc * w if loss is None else loss + lc * w
         with torch.no_grad():
             self._merge_chunk_state(parts, sizes, x)
-        return loss, self.elbo_terms, flat
+            self.posterior.mean, self.posterior.logvar = torch.cat(pms, 0), torch.cat(plvs, 0)
+        return loss, self.elbo_terms, self._own(flat)
 
     def _train_backward(self, grad_loss, serial):
         if serial != self._call_serial:
@@ -567,15 +619,16 @@ class IODINE(nn.Module):
         h, dev = self._handle, self._handle_device
         params = self._ordered_params()
         sizes = [p.numel() for p in params]
-        flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        flat = self._out('t.flat', (sum(sizes),), dev)
+        gl = self._stage('t.gl', grad_loss.detach().to(device=dev, dtype=torch.float32).contiguous())
+        self._launch(dev, lambda: _lib.check(_lib.lib().iodine_train_backward_flat(h, self._stream(), _lib.ptr(gl), _lib.ptr(flat), 0),
+                                             h, 'iodine_train_backward'))
+        self._call_serial += 1                      # the saved forward is consumed (no retain_graph)
+        flat = self._own(flat)                      # graph mode: autograd may keep what we return as .grad; never the staging buffer
         views, off = [], 0
         for p, n in zip(params, sizes):
             views.append(flat[off:off + n].view_as(p))
             off += n
-        gl = grad_loss.detach().to(device=dev, dtype=torch.float32).contiguous()
-        self._launch(dev, lambda: _lib.check(_lib.lib().iodine_train_backward_flat(h, self._stream(), _lib.ptr(gl), _lib.ptr(flat), 0),
-                                             h, 'iodine_train_backward'))
-        self._call_serial += 1                      # the saved forward is consumed (no retain_graph)
         return views
 
 

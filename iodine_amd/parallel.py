@@ -79,3 +79,34 @@ def allreduce_mean(t: torch.Tensor, world: int = None, group=None) -> torch.Tens
     out = t.clone()
     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
     return out / world
+
+
+def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Every rank takes rank ``src``'s parameters (DataParallel replicates device 0's module on every forward,
+    lib/modeling/build.py:11-12; rank-per-GPU replicas are made identical once, before step 1, and stay identical because every
+    rank applies the same all-reduced gradients).  Writes bypass autograd's version counter, so the module re-packs its weights."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for p in model.parameters():
+            dist.broadcast(p.data, src, group=group)
+    if hasattr(model, 'mark_params_dirty'):
+        model.mark_params_dirty()
+
+
+def replicas_identical(params: Iterable[torch.nn.Parameter], group=None) -> bool:
+    """True iff every rank holds bitwise the same parameters: the int64 sum of the raw bit patterns of all tensors (exact,
+    order-independent) is gathered and compared - one small collective, run before the first step and after the last."""
+    if not dist.is_available() or not dist.is_initialized():
+        return True
+    world = dist.get_world_size(group)
+    if world == 1:
+        return True
+    with torch.no_grad():
+        ps = list(params)
+        h = torch.stack([p.detach().contiguous().view(torch.int32).to(torch.int64).sum() for p in ps]).sum().reshape(1)
+        n = torch.tensor([sum(p.numel() for p in ps)], dtype=torch.int64, device=h.device)
+        mine = torch.cat([h, n])
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine, group=group)
+    return all(torch.equal(got[0], t) for t in got)

@@ -21,7 +21,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.iodine_abi_version() == 2
+    assert L.iodine_abi_version() == 3
 
 
 def test_config_struct_matches_header_field_order():

@@ -77,6 +77,57 @@ def test_public_elbo_matches_reference_and_oracle():
     assert np.isfinite(v3.item()) and v3.item() != v2.item()
 
 
+def test_posterior_after_training_forward_is_lambda_T():
+    """Gaussian.update (iodine.py:636-645) leaves lambda_T on the reference's module after ``model(x)``; a following
+    ``model.elbo(x)`` samples from it (iodine.py:170) - in one call and through the chunked path."""
+    g = load_golden('tiny')
+    arch, params, x, eps, _ = golden_setup(g)
+    ref = O.train_forward(x, eps, params, arch)
+    for cap in (0, 1):
+        m = make_hip_model(arch, params)
+        if cap:
+            m.set_option('batch_cap', cap)
+        assert m.posterior.mean is None
+        m(x.to(DEV), eps.to(DEV))
+        assert rel_err(m.posterior.mean.cpu(), ref['post_mean'].detach()) < 1e-4
+        assert rel_err(m.posterior.logvar.cpu(), ref['post_logvar'].detach()) < 1e-4
+        v = m.elbo(x.to(DEV), eps[1].to(DEV))
+        t = O.elbo_terms(x, ref['post_mean'].detach(), ref['post_logvar'].detach(), eps[1], params, arch)
+        assert abs(v.item() - t['elbo'].item()) <= 1e-4 * abs(t['elbo'].item())
+
+
+def test_graph_mode_replays_with_fresh_caller_tensors():
+    """Option graph=1: the library only sees the module's persistent staging buffers, so steps whose inputs / outputs are new
+    allocations every time (a data loader's batches, autograd's gradient buffers) still replay ONE captured graph per entry
+    point instead of re-capturing; results are bitwise those of the eager path, and what the caller got back is never
+    overwritten by the next step."""
+    g = load_golden('tiny')
+    arch, params, x, eps, _ = golden_setup(g)
+    m0 = make_hip_model(arch, params)
+    m0.zero_grad(set_to_none=True)
+    l0 = m0(x.to(DEV), eps.to(DEV)); l0.backward()
+    g0 = [p.grad.clone() for p in m0.parameters()]
+    r0 = m0.reconstruct(x.to(DEV), eps.to(DEV))
+    m = make_hip_model(arch, params)
+    m.set_option('graph', 1)
+    keep = []
+    with torch.cuda.stream(torch.cuda.Stream()):
+        for step in range(5):
+            xd, ed = x.clone().to(DEV), eps.clone().to(DEV)               # fresh device allocations every step
+            junk = torch.empty(1000 + 37 * step, device=DEV)              # shifts what the caching allocator hands out next
+            m.zero_grad(set_to_none=True)
+            loss = m(xd, ed)
+            loss.backward()
+            keep.append((loss.detach(), [p.grad for p in m.parameters()], m.reconstruct(xd, ed), junk))
+        torch.cuda.synchronize()
+    for loss, grads, rec, _ in keep:
+        assert torch.equal(loss, l0.detach())
+        assert all(torch.equal(a, b) for a, b in zip(grads, g0))
+        assert all(torch.equal(a, b) for a, b in zip(rec, r0))
+    # three entry points (train forward, train backward, reconstruct): one capture each (second call), then replays
+    assert m.profile_read('graph_captures')[1] == 3 and m.profile_read('graph_replays')[1] == 9
+
+
 def test_saved_forward_has_an_identity():
     g = load_golden('tiny')
     arch, params, x, eps, _ = golden_setup(g)

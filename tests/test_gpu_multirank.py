@@ -1,0 +1,44 @@
+"""The N > 1 path on real devices: runs wherever the box has at least two ROCm devices (the 1-GPU boxes of the build loop skip
+it; tests/test_parallel_cpu.py and tests/test_bench_spawn_cpu.py cover the same code on gloo).  One process per GPU over RCCL,
+rendezvous on 127.0.0.1, HSA_ENABLE_IPC_MODE_LEGACY=0 (iodine_amd.launch.spawn)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from iodine_amd import launch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+two_devices = pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason='needs >= 2 ROCm devices')
+
+
+def _last_json(text):
+    return json.loads([ln for ln in text.splitlines() if ln.startswith('{')][-1])
+
+
+@two_devices
+def test_bench_two_ranks_over_rccl():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-exact-fp32'], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out['n_gpus'] == 2 and out['rccl']['world_size'] == 2 and out['rccl']['backend'] == 'nccl'
+    assert out['config']['global_batch'] == 64 and out['scaling'] == 'weak'
+    assert out['rccl']['replicas_identical'] is True
+    assert out['value'] > 0 and out['ms_per_step'] > 0
+
+
+@two_devices
+def test_two_rank_gradients_equal_the_unsharded_step():
+    r = launch.spawn(os.path.join(ROOT, 'tests', 'rccl_worker.py'), [], 2, capture=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out['world'] == 2 and out['backend'] == 'nccl'
+    assert out['same_params'] and out['in_place']
+    assert out['bitwise_equal_over_ranks']                      # every rank holds the same averaged gradients
+    assert out['grad_rel_l2_vs_unsharded'] < 2e-5
+    assert out['loss_rel_err_vs_unsharded'] < 1e-6 and out['loss_rel_err_vs_reference'] < 1e-4

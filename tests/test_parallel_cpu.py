@@ -43,8 +43,18 @@ def _worker(rank, world, port, ret, flat_layout=False):
         for k, p in ps.items():
             p.grad = grads[k].clone()
         assert parallel._shared_flat_view([p.grad for p in ps.values()]) is None
+    assert parallel.replicas_identical(ps.values())
     parallel.allreduce_gradients(ps.values(), world)
     loss = parallel.allreduce_mean(out['loss'].detach().reshape(1), world)
+    # a replica that drifted is detected, and broadcast_parameters repairs it
+    first = next(iter(ps.values()))
+    if rank == 1:
+        with torch.no_grad():
+            first.view(-1)[0] += 1e-3
+    assert not parallel.replicas_identical(ps.values())
+    holder = torch.nn.ParameterList(list(ps.values()))
+    parallel.broadcast_parameters(holder, 0)
+    assert parallel.replicas_identical(ps.values())
     if rank == 0:
         ret['loss'] = float(loss.item())
         ret['grads'] = {k: p.grad.numpy().copy() for k, p in ps.items()}

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 PMC passes of tools/pmc_traffic.sh into profiles/r02_pmc.json: per-launch HBM bytes
+"""Turn the rocprofv3 PMC passes of tools/pmc_traffic.sh into gpurun_out/<tag>_pmc.json (copied to profiles/): per-launch HBM bytes
 (FETCH_SIZE x2 [gfx950: 16 B/lane reads are tallied at half, MI355X_MICROARCH.md "HBM"] + WRITE_SIZE, both reported in KB)
 and matrix-pipe utilisation for the forward / data-gradient / weight-gradient launches of the decoder 3x3 conv, keyed by the
 bench.py category names, with the digest of the kernel sources they were measured on (bench.py quotes the numbers only while
 that digest matches the tree).
 
-    python tools/pmc_to_json.py gpurun_out/pmc_r02 [--config dsprites ...]
+Since round 3 the HBM-bound helper kernels are recorded too (bytes only), keyed by bench.py's category names: bench.py's
+``roofline_hbm.traffic`` comes from here.
+
+    python tools/pmc_to_json.py gpurun_out/pmc_r03 r03 [--config dsprites ...]
 """
 import collections
 import csv
@@ -19,7 +22,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+HELPERS = (('dec_out_stream_f16x3_kernel', 'dec_out'), ('dec_out_bwd_fused_f16x3_kernel', 'dec_out_bwd'), ('dec_l0_cells_kernel', 'dec_l0'),
+           ('dec_out_dgrad_f16x3_kernel', 'dec_out_dgrad'), ('pixel_pass1_kernel', 'pixel_pass1'), ('pixel_pass2_kernel', 'pixel_pass2'),
+           ('l0_rows_reduce_kernel', 'l0_reduce'), ('refine_head', 'refine_head'), ('conv3x3_s2_wgrad_f16x3_kernel', 'refine_wgrad'))
+
+
 def category(name):
+    for frag, cat in HELPERS:
+        if frag in name:
+            return cat
+    if 'conv3x3_s2_f16x3_kernel' in name:                    # <CR, CIN, COUT, MODE>: MODE 0 forward (CR 8 / 12 / 20 = first layer), 1 data gradient
+        targs = name.split('<', 1)[1].split('>')[0].replace(' ', '').split(',')
+        if targs[3] != '0':
+            return 'refine_dgrad'
+        return 'refine_l0' if targs[0] in ('8', '12', '20') else 'refine_conv'
     if 'conv3x3_wgrad_f16x3_ws_kernel' in name or 'conv3x3_wgrad_f16x3_kernel' in name:
         return 'conv_tile_wgrad'
     if 'conv3x3_ws_f16x3_kernel' in name:                    # <C, EPI>: 0 = forward, 1 / 4 = data gradient (stored / row sums)
@@ -64,8 +80,7 @@ def clocks(outdir, tag):
 
 
 def main():
-    outdir = sys.argv[1]
-    cfg = 'dsprites' if 'dsprites' in sys.argv[2:] else 'clevr6'
+XX
     from iodine_amd.build import source_digest
     try:
         commit = subprocess.run(['git', 'rev-parse', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip() or 'unknown'
@@ -76,7 +91,8 @@ def main():
     mfma, _ = per_launch(outdir, 'SQ_VALU_MFMA_BUSY_CYCLES')
     clk = clocks(outdir, 'SQ_VALU_MFMA_BUSY_CYCLES')
     kernels = {}
-    for c in ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad'):
+    cats = ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad') + tuple(sorted(set(fetch) - {'conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad'}))
+    for c in cats:
         if c not in fetch or c not in write:
             continue
         f = fetch[c]['FETCH_SIZE']
@@ -101,10 +117,10 @@ def main():
                method='rocprofv3 --pmc <one set per run> --kernel-trace over bench.py --steps 2 --warmup 1; '
                       'hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (tools/pmc_traffic.sh)',
                kernels=kernels)
-    path = os.path.join(ROOT, 'gpurun_out', 'r02_pmc.json')
+    path = os.path.join(ROOT, 'gpurun_out', f'{tag}_pmc.json')
     json.dump(rec, open(path, 'w'), indent=1)
     print(json.dumps(rec, indent=1))
-    print('wrote', path, '(copy to profiles/r02_pmc.json)')
+    print('wrote', path, f'(copy to profiles/{tag}_pmc.json)')
 
 
 if __name__ == '__main__':

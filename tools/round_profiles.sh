@@ -1,25 +1,25 @@
 #!/bin/bash
 # Everything the round's measured record is made of, in one GPU-box call (run from the repo root through gpurun):
-#   bash tools/round_profiles.sh r02      -> gpurun_out/<tag>_*  (copy what should be judged into profiles/)
-TAG=${1:-r02}
+#   bash tools/round_profiles.sh r03      -> gpurun_out/<tag>_*  (copy what should be judged into profiles/)
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd $REPO
 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
-python bench.py --mode infer --no-exact-fp32 > $OUT/${TAG}_bench_infer.json 2> /dev/null
+python bench.py --mode infer --no-exact-fp32 --no-sustain > $OUT/${TAG}_bench_infer.json 2> /dev/null
 for g in 0 1; do
-  python bench.py --config dsprites --graph $g --steps 30 --no-exact-fp32 > $OUT/${TAG}_bench_dsprites_train_graph$g.json 2> /dev/null
-  python bench.py --config dsprites --mode infer --graph $g --steps 30 --no-cpu-baseline > $OUT/${TAG}_bench_dsprites_infer_graph$g.json 2> /dev/null
+  python bench.py --config dsprites --graph $g --steps 30 --no-exact-fp32 --no-cpu-baseline --no-sustain > $OUT/${TAG}_bench_dsprites_train_graph$g.json 2> /dev/null
+  python bench.py --config dsprites --mode infer --graph $g --steps 30 --no-cpu-baseline --no-sustain > $OUT/${TAG}_bench_dsprites_infer_graph$g.json 2> /dev/null
 done
 cd /tmp && export TMPDIR=/tmp
 for mode in train infer; do
   rm -rf $OUT/${TAG}_prof_$mode
-  rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_$mode -- python $REPO/bench.py --mode $mode --steps 10 --warmup 2 --no-cpu-baseline --no-exact-fp32 > $OUT/${TAG}_prof_$mode.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_$mode -- python $REPO/bench.py --mode $mode --steps 10 --warmup 2 --no-cpu-baseline --no-exact-fp32 --no-extra-configs --no-sustain > $OUT/${TAG}_prof_$mode.log 2>&1
   python $REPO/tools/rocpd_summary.py $(ls $OUT/${TAG}_prof_$mode/*/*.db | head -1) > $OUT/${TAG}_${mode}_kernel_stats.md
 done
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_ds -- python $REPO/bench.py --config dsprites --steps 10 --warmup 2 --no-cpu-baseline --no-exact-fp32 > $OUT/${TAG}_prof_ds.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_ds -- python $REPO/bench.py --config dsprites --steps 10 --warmup 2 --no-cpu-baseline --no-exact-fp32 --no-extra-configs --no-sustain > $OUT/${TAG}_prof_ds.log 2>&1
 python $REPO/tools/rocpd_summary.py $(ls $OUT/${TAG}_prof_ds/*/*.db | head -1) > $OUT/${TAG}_dsprites_train_kernel_stats.md
 cd $REPO
-bash tools/pmc_traffic.sh > $OUT/${TAG}_pmc.log 2>&1
+bash tools/pmc_traffic.sh $TAG > $OUT/${TAG}_pmc.log 2>&1      # mandatory: roofline.traffic / roofline_hbm.traffic come from it
 ls $OUT | grep $TAG
