@@ -176,21 +176,16 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * must be followed by iodine_set_params before the next compute call),
  * "conv_variant" (split-fp16 stride-1 conv C -> C of the decoder: 6 = weight-stationary persistent kernel, weights in registers
  * -- default for power-of-two image sizes; 1 = LDS-tiled kernel, 16x16 tiles, two blocks per CU -- the fallback for other sizes;
- * 5 = the LDS-tiled kernel on 8x16 tiles; like conv_precision a change must be followed by iodine_set_params),
- * "fuse_l0" (1 -- default: in iodine_reconstruct the last decoder data gradient reduces its result to the broadcast layer's
- * row sums in its epilogue instead of storing it; 0 = store and reduce in a second kernel, as the training path does),
- * "out_variant" (output conv forward: 1 = streaming kernel -- default, 0 = LDS-staged),
- * "out_dgrad_variant" (output conv data gradient: 1 = split-fp16 streaming kernel -- default, 0 = generic fp32 tile kernel),
+ * like conv_precision a change must be followed by iodine_set_params),
+ * "fuse_l0" (1 -- default: the last decoder data gradient reduces its result to the broadcast layer's row sums in its epilogue
+ * instead of storing it; 0 = store and reduce in a second kernel),
  * "out_bwd_fused" (1 -- default: in training the output conv's data gradient and weight / bias gradient come from ONE pass
  * over the saved activation; 0 = two kernels, as iodine_reconstruct's data gradient + the GEMM-form weight gradient),
  * "refine_split" (1 -- default on the split-fp16 path: the first refinement layer is computed as a per-slot conv over the 11
  * encoding channels that differ between the slots of an image plus a per-image conv over the 6 they share; 0 = one conv
- * over the 20-float encoding per slot; a change takes effect with the next forward),
- * "zigzag" (1 -- default: odd decoder layers walk their tiles backwards so that a launch starts on what the previous one
- * wrote last; 0 = every launch in ascending order; results identical),
- * "wgrad_ws" (split-fp16 64->64 / 32->32 weight gradient: 2 = warp-specialised, natural-order staging + transposing LDS
- * reads -- default; 1 = warp-specialised with transposing stagers; 0 = one-role kernel).  All variants compute the same
- * arithmetic; the non-default ones exist for same-box A/B timing (tools/ab_bench.py). */
+ * over the 20-float encoding per slot; a change takes effect with the next forward).
+ * (The A/B-only selections of rounds 1-2 -- conv_variant 5, wgrad_ws, out_variant, out_dgrad_variant, zigzag -- were retired in
+ * round 3; their kernels and measurements live under tools/experiments/ and DESIGN.md 4.3-4.5.) */
 int iodine_set_option(iodine_handle* h, const char* key, double value);
 /* Sum of event-measured durations (ms) and number of launches of one kernel category since the last reset:
  * "conv_tile_fwd", "conv_tile_dgrad", "conv_tile_wgrad", "dec_out", "dec_out_dgrad", "dec_out_wgrad", "dec_out_bwd", "dec_l0",
@@ -208,8 +203,8 @@ int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter
 void iodine_linspace_host(int n, float* out);
 /* 3x3 conv, NHWC activations, OIHW weights; mode 0: stride-1 LDS-tiled fp32 MFMA (epi 0 bias+ELU, 1 multiply by
  * ELU'(aux), 2 none; transpose_flip=1 computes the data-gradient conv), mode 1: strided gather kernel (bias+ELU),
- * mode 2: stride-1 LDS-tiled split-fp16 (3 MFMA) variant of mode 0, mode 8: the same on 8x16 tiles, modes 5 / 6: split-fp16
- * stride-2 forward / data gradient of the refinement stack. */
+ * mode 2: stride-1 LDS-tiled split-fp16 (3 MFMA) variant of mode 0, modes 9 / 10: the weight-stationary split-fp16 kernel,
+ * modes 5 / 6: split-fp16 stride-2 forward / data gradient of the refinement stack. */
 int iodine_op_conv3x3(void* stream, int mode, const float* in_nhwc, const float* w_oihw, const float* bias,
                       const float* aux, float* out_nhwc, int n, int ih, int iw, int w_o, int w_i, int cin_pad,
                       int cout, int stride, int epi, int transpose_flip);

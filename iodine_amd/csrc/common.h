@@ -255,9 +255,7 @@ hipError_t launch_pack_conv_weights_f16(hipStream_t st, const float* src, int O,
                                         float* meta, void* dst);
 hipError_t launch_conv3x3_tile_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                      const float* bias, const float* aux, float* out, int N, int S, int cin, int cout,
-                                     int epi, int rev = 0, int th = 16);
-hipError_t launch_conv3x3_wgrad_f16x3(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
-                                      int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts);
+                                     int epi, int rev = 0);
 hipError_t launch_adam_multi(hipStream_t st, const long long* ptrs, const long long* offs, int n_tensors, long long total,
                              double lr, double beta1, double beta2, double eps, double wd, int step);
 hipError_t launch_randn_philox(hipStream_t st, float* out, long long n, unsigned long long seed, unsigned long long stream_id);
@@ -269,8 +267,6 @@ hipError_t launch_dec_out_dgrad_f16x3(hipStream_t st, const float* g, const void
                                       float* out, int N, int S, int C, float* tmax = nullptr);
 hipError_t launch_dec_out_stream_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                        const float* bias, float* out, int N, int S, int C);
-hipError_t launch_dec_out_gemm_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
-                                     const float* bias, float* out, int N, int S, int C);
 
 // kernels_convws.hip: weight-stationary split-fp16 3x3 conv C -> C (weights in registers, persistent blocks)
 hipError_t launch_pack_conv_weights_ws(hipStream_t st, const float* src, int C, int tflip, float* meta, void* dst);
@@ -298,4 +294,4 @@ hipError_t launch_dec_out_bwd_fused_f16x3(hipStream_t st, const float* a, const 
                                           float* out, float* tmax, float* part, float* part_b, int N, int S, int c,
                                           int* nparts, int* nbias_parts);
 hipError_t launch_conv3x3_wgrad_f16x3_ws(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
-                                         int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts, int variant);
+                                         int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts);

@@ -88,16 +88,12 @@ struct iodine_handle {
     std::vector<float*> dec_wf16, dec_wb16, dec_wmeta;   // split-fp16 packs (+ {scale, 1/scale, scale_b, 1/scale_b})
     std::vector<float*> dec_wsf, dec_wsb;                // the same weights in the register layout of the weight-stationary conv
     int precision = 1;                          // 0: exact fp32 MFMA, 1: 3 x fp16 MFMA split (fp32-class accuracy)
-    int wgrad_ws = 2;                           // decoder 64->64 weight gradient: 0 one-role kernel, 1 warp-specialised (transposing stagers + v_alignbit), 2 warp-specialised with ds_read_b64_tr_b16
-    int out_dgrad_variant = 1;                  // output conv data gradient: 1 = split-fp16 streaming kernel, 0 = generic fp32 tile kernel
     int out_bwd_fused = 1;                      // training: output conv data + weight gradient in one pass over the activation
     int fuse_l0 = 1;                            // inference: layer-1 data gradient reduces straight to the layer-0 row sums
     int refine_split = 1;                       // first refinement layer split into a per-slot and a per-image part (split-fp16 path)
     bool fwd_split = false;                     // the form the saved training forward used
-    int out_variant = 1;                        // output conv forward: 1 = streaming (fragments straight from global), 0 = LDS-staged
-    int zigzag = 1;                             // odd decoder layers walk the tiles backwards (Infinity Cache reuse)
     int variant = 6;                            // split-fp16 stride-1 conv: 6 = weight-stationary persistent kernel (power-of-two image sizes;
-                                                // other sizes use 1), 1 = LDS-tiled 16x16 tiles (2 blocks/CU), 5 = the same on 8x16 tiles
+                                                // other sizes use 1), 1 = LDS-tiled 16x16 tiles (2 blocks/CU)
     float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr, *dec_out_w16 = nullptr, *dec_out_meta = nullptr,
           *dec_out_wb16 = nullptr;               // split-fp16 pack of the output conv for its data gradient
     std::vector<float*> ref_w, ref_b;
@@ -176,14 +172,12 @@ hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, c
                       int N, int S, int cin, int cout, int epi, int layer)
 {
     if (conv_ws_ok(h) && cin == cout)
-        return launch_conv3x3_ws_f16x3(st, in, wpk_ws, wmeta, bias, aux, out, tmax_in, tmax_out, N, S, cout, epi,
-                                       h->zigzag ? (layer & 1) : 0);
+        return launch_conv3x3_ws_f16x3(st, in, wpk_ws, wmeta, bias, aux, out, tmax_in, tmax_out, N, S, cout, epi, layer & 1);
     // zig-zag: odd decoder layers walk the slot-images backwards (forward pass: l0 writes forwards, layer 1 reads
     // backwards, layer 2 forwards, ...; backward pass the same by layer), so a launch starts on the part of its input
     // that the previous launch wrote last - still in the 256 MiB Infinity Cache - instead of the part written first.
     // Tiles are independent: results do not depend on the order.  Measured -0.3 % on the cfg3 step (same-box A/B).
-    const int rev = h->zigzag ? (layer & 1) : 0;
-    return launch_conv3x3_tile_f16x3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi, rev, h->variant == 5 ? 8 : 16);
+    return launch_conv3x3_tile_f16x3(st, in, wpk, wmeta, bias, aux, out, N, S, cin, cout, epi, layer & 1);
 }
 
 template <typename T>
@@ -433,8 +427,8 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N, float* out = nullpt
                                                              b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
     }
     if (h->precision == 1)
-        PROF(h, st, "dec_out", (h->out_variant ? launch_dec_out_stream_f16x3 : launch_dec_out_gemm_f16x3)(st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b,
-                                                         out, N, h->S, h->Cd));
+        PROF(h, st, "dec_out", launch_dec_out_stream_f16x3(st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b, out, N, h->S,
+                                                           h->Cd));
     else
         PROF(h, st, "dec_out", launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, out, N, h->S, h->Cd));
     return IODINE_OK;
@@ -461,7 +455,7 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
     int cur = 0, nparts = 0, ncop = 0, nb = 0, rc;
     bool fused_l0 = false;
     // training: one pass over the last hidden activation gives the data gradient AND the weight / bias gradient
-    const bool out_fused = train_alpha != 0.f && h->precision == 1 && h->out_dgrad_variant && h->out_bwd_fused;
+    const bool out_fused = train_alpha != 0.f && h->precision == 1 && h->out_bwd_fused;
 #ifdef IODINE_XSKIP_HOOK
     if (!(g_iod_xskip & 256))
 #endif
@@ -474,7 +468,7 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
                                       b.wg_part_b, nb, h->gacc[bi]));
     } else
     {
-        if (h->precision == 1 && h->out_dgrad_variant)
+        if (h->precision == 1)
             PROF(h, st, "dec_out_dgrad", launch_dec_out_dgrad_f16x3(st, b.g, h->dec_out_wb16, h->dec_out_meta, b.act[Dd - 1],
                                                                      b.dpre[cur], N, h->S, Cd, conv_ws_ok(h) ? b.tmax_dpre[cur] : nullptr));
         else {
@@ -500,12 +494,9 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
     }
     for (int l = Dd - 1; l >= 1; --l) {
         if (train_alpha != 0.f) {
-            if (h->precision == 1 && h->wgrad_ws)
+            if (h->precision == 1)
                 PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_f16x3_ws(st, b.act[l - 1], b.dpre[cur], b.wg_part,
-                                                                              b.wg_part_b, N, h->S, Cd, Cd, &nparts, &ncop, &nb, h->wgrad_ws));
-            else if (h->precision == 1)
-                PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_f16x3(st, b.act[l - 1], b.dpre[cur], b.wg_part,
-                                                                           b.wg_part_b, N, h->S, Cd, Cd, &nparts, &ncop, &nb));
+                                                                              b.wg_part_b, N, h->S, Cd, Cd, &nparts, &ncop, &nb));
             else
                 PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_tile(st, b.act[l - 1], b.dpre[cur], b.wg_part,
                                                                           b.wg_part_b, N, h->S, Cd, Cd, &nparts, &ncop, &nb));
@@ -687,8 +678,8 @@ int run_graphed(iodine_handle* h, hipStream_t st, const std::vector<uintptr_t>& 
 std::vector<uintptr_t> graph_key(const iodine_handle* h, int entry, int batch, std::initializer_list<const void*> ptrs)
 {
     std::vector<uintptr_t> k = {(uintptr_t)entry, (uintptr_t)batch, (uintptr_t)h->stop_after, (uintptr_t)h->precision,
-                                (uintptr_t)h->variant, (uintptr_t)h->wgrad_ws, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_variant,
-                                (uintptr_t)h->out_dgrad_variant, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)h->zigzag, (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
+                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split,
+                                (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
     for (const void* p : ptrs) k.push_back((uintptr_t)p);
     return k;
 }
@@ -926,18 +917,14 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "stop_after_iters")) { h->stop_after = (int)value; return IODINE_OK; }
     if (!strcmp(key, "profile")) { h->profile = (int)value; return IODINE_OK; }
     if (!strcmp(key, "graph")) { h->graph = value != 0; if (!h->graph) drop_graphs(h); return IODINE_OK; }
-    if (!strcmp(key, "wgrad_ws")) { h->wgrad_ws = (int)value; return IODINE_OK; }   // 0 one-role, 1 ws + alignbit, 2 ws + transposing LDS reads
 #ifdef IODINE_XSKIP_HOOK
     if (!strcmp(key, "xskip")) { g_iod_xskip = (int)value; return IODINE_OK; }       // timing-only ablation builds (common.h)
 #endif
-    if (!strcmp(key, "out_dgrad_variant")) { h->out_dgrad_variant = value != 0; return IODINE_OK; }
     if (!strcmp(key, "out_bwd_fused")) { h->out_bwd_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "fuse_l0")) { h->fuse_l0 = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_split")) { h->refine_split = value != 0; return IODINE_OK; }
-    if (!strcmp(key, "out_variant")) { h->out_variant = value != 0; return IODINE_OK; }
-    if (!strcmp(key, "zigzag")) { h->zigzag = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {
-        if (value != 1 && value != 5 && value != 6) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1, 5 or 6");
+        if (value != 1 && value != 6) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1 (LDS-tiled) or 6 (weight-stationary)");
         if (((int)value == 6) != (h->variant == 6)) h->params_set = false;   // the other kernel's weight packs are not kept up to date
         h->variant = (int)value;
         return IODINE_OK;
@@ -1444,14 +1431,14 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, c
         if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(ws): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
         return IODINE_OK;
     }
-    if (mode == 2 || mode == 8) {   // split-fp16 tile kernel (8 = 8x16 tiles)
+    if (mode == 2) {                // split-fp16 LDS-tiled kernel
         float* meta = nullptr;
         const size_t bytes = (size_t)(cin_pad / 16) * 9 * 2 * 2 * cout * 16;
         if (hipMalloc((void**)&wpk, bytes + 64) != hipSuccess) return IODINE_ERR_HIP;
         meta = (float*)((char*)wpk + bytes);
         hipError_t e2 = launch_pack_conv_weights_f16(st, w, w_o, w_i, cin_pad, cout, tflip, meta, wpk);
         if (e2 == hipSuccess)
-            e2 = launch_conv3x3_tile_f16x3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi, 0, mode == 8 ? 8 : 16);
+            e2 = launch_conv3x3_tile_f16x3(st, in, wpk, meta, bias, aux, out, n, ih, cin_pad, cout, epi, 0);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
         (void)hipFree(wpk);
         if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(f16x3): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
@@ -1498,10 +1485,7 @@ int iodine_op_conv3x3_wgrad(void* stream, const float* in, const float* d, float
         e = launch_dec_out_wgrad_gemm_f16x3(st, in, d, part, part_b, n, s, ci_pad, &nparts, &nb);
         if (e == hipSuccess) e = launch_wgrad_reduce(st, part, nparts, ci_pad, 4, 4, ci_real, ci_real, 1.f, gw, fold);
     } else if (stride == 1) {
-        const char* ws = getenv("IODINE_WGRAD_WS");                 // kernel-level tests cover both forms
-        e = (ws && ws[0] == '0') ? launch_conv3x3_wgrad_f16x3(st, in, d, part, part_b, n, s, ci_pad, co, &nparts, &cip, &nb)
-                                 : launch_conv3x3_wgrad_f16x3_ws(st, in, d, part, part_b, n, s, ci_pad, co, &nparts, &cip, &nb,
-                                                                 ws ? atoi(ws) : 2);
+        e = launch_conv3x3_wgrad_f16x3_ws(st, in, d, part, part_b, n, s, ci_pad, co, &nparts, &cip, &nb);
         // stride-1 partial tiles are [9][ci][co padded to 32]
         if (e == hipSuccess) e = launch_wgrad_reduce(st, part, nparts, ci_pad, cip, co, ci_real, ci_real, 1.f, gw, fold);
     } else {

@@ -212,14 +212,16 @@ def test_hip_graph_replay_is_bit_identical(case):
     m.set_option('graph', 0)
 
 
-OPTIONS = [('conv_precision', 0), ('conv_variant', 1), ('conv_variant', 5), ('wgrad_ws', 0), ('wgrad_ws', 1), ('out_variant', 0),
-           ('out_dgrad_variant', 0), ('out_bwd_fused', 0), ('fuse_l0', 0), ('refine_split', 0), ('zigzag', 0)]
+OPTIONS = [('conv_precision', 0), ('conv_variant', 1), ('out_bwd_fused', 0), ('fuse_l0', 0), ('refine_split', 0), ('graph', 1)]
 
 
+@pytest.mark.parametrize('case', ['cfg1_dsprites_k4_t3_b4', 'cfg3_clevr_k7_t5_b1'])
 @pytest.mark.parametrize('opt,val', OPTIONS)
-def test_every_kernel_option_end_to_end(opt, val):
-    """Each non-default kernel selection through a whole reconstruct + training step against the reference golden (cfg1)."""
-    g = load_golden('cfg1_dsprites_k4_t3_b4')
+def test_every_kernel_option_end_to_end(opt, val, case):
+    """Each non-default kernel selection through a whole reconstruct + training step against the reference goldens: cfg1
+    (64 x 64, 32 channels) and the cfg3 golden (128 x 128, 64 channels, B = 1 - where the weight-stationary / LDS-tiled / exact
+    kernels differ most)."""
+    g = load_golden(case)
     arch, params, x, eps, _ = golden_setup(g)
     m = make_hip_model(arch, params)
     m.set_option(opt, val)

@@ -87,11 +87,11 @@ def test_dec_out_conv(C_, S, N):
     assert rel_err(out.cpu(), ref) < 2e-6
 
 
-@pytest.mark.parametrize('mode', [2, 8])
+@pytest.mark.parametrize('mode', [2])
 @pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 2), (64, 128, 1), (64, 16, 300), (32, 32, 70)])
 def test_conv_tile_f16x3_forward_and_dgrad(C_, S, N, mode):
-    """split-fp16 (hi+lo, 3 MFMA) variant: fp32-class accuracy (dropped lo*lo term ~2^-22); modes: 2 = 16x16 tiles,
-    8 = 8x16 tiles / three blocks per CU (bitwise equal to mode 2: same MFMA order)"""
+    """split-fp16 (hi+lo, 3 MFMA) LDS-tiled kernel (op mode 2; the fallback for image sizes that are not a power of two):
+    fp32-class accuracy (dropped lo*lo term ~2^-22)"""
     x = _rand(N, C_, S, S, seed=21)
     w = _rand(C_, C_, 3, 3, seed=22, scale=3.0 / (C_ * 9) ** 0.5)
     b = _rand(C_, seed=23, scale=0.5)
@@ -103,9 +103,6 @@ def test_conv_tile_f16x3_forward_and_dgrad(C_, S, N, mode):
     refd = (F.conv_transpose2d(g.double(), w.double(), padding=1) * torch.where(a > 0, torch.ones_like(a), a + 1).double()).float()
     gotd = _conv_op(mode, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 1, 1, nhwc(refd).shape)
     assert rel_err(gotd, nhwc(refd)) < 3e-6, rel_err(gotd, nhwc(refd))
-    if mode == 8:
-        assert torch.equal(got, _conv_op(2, nhwc(x), w, b, None, N, S, S, C_, C_, C_, C_, 1, 0, 0, ref.shape))
-        assert torch.equal(gotd, _conv_op(2, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 1, 1, nhwc(refd).shape))
 
 
 @pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 2), (64, 128, 2), (64, 16, 300), (32, 64, 9), (32, 32, 70)])
