@@ -277,6 +277,14 @@ hipError_t launch_conv3x3_ws_f16x3(hipStream_t st, const float* in, const void* 
 inline size_t conv_ws_wpk_bytes(int C) { return (size_t)(C / 16) * (C / 32) * 9 * 2 * 64 * 16; }
 inline size_t conv_ws_tmax_floats(int N, int S) { return (size_t)N * (S / 16) * (S / 8) * 4; }
 
+// tools/experiments/kernels_wino.hip (experiment, only in libraries built by tools/wino_variants.sh): Winograd F(2x2, 3x3) form
+size_t conv_wino_wpk_bytes(int C);
+size_t conv_wino_scratch_floats(int C);
+hipError_t launch_pack_conv_weights_wino(hipStream_t st, const float* src, int C, int tflip, float* meta, void* dst, float* scratch);
+hipError_t launch_conv3x3_wino_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
+                                     const float* aux, float* out, const float* tmax_in, float* tmax_out, int N, int S, int c,
+                                     int epi, int rev);
+
 // kernels_refine.hip: split-fp16 stride-2 convs of the refinement network
 hipError_t launch_conv3x3_s2_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
                                    float* out, int N, int S, int cin_real, int cout, const float* addmap = nullptr, int kdiv = 0);

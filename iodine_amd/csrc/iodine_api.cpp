@@ -1431,6 +1431,23 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, c
         if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(ws): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
         return IODINE_OK;
     }
+#ifdef IODINE_WITH_WINO
+    if (mode == 11) {               // Winograd F(2x2, 3x3) split-fp16 kernel (C = 64): experiment libraries only (tools/wino_variants.sh)
+        if (cin_pad != cout || w_o != cout || w_i != cout || ih != iw || ih % 16 != 0) { g_create_error = "iodine_op_conv3x3(wino): shape"; return IODINE_ERR_INVALID; }
+        const size_t wb = conv_wino_wpk_bytes(cout), tf = conv_ws_tmax_floats(n, ih), sf = conv_wino_scratch_floats(cout);
+        char* buf = nullptr;
+        if (hipMalloc((void**)&buf, wb + 64 + (2 * tf + sf) * sizeof(float)) != hipSuccess) return IODINE_ERR_HIP;
+        float* meta = (float*)(buf + wb);
+        float *tin = (float*)(buf + wb + 64), *tout = tin + tf, *scr = tout + tf;
+        hipError_t e2 = launch_pack_conv_weights_wino(st, w, cout, tflip, meta, buf, scr);
+        if (e2 == hipSuccess) e2 = launch_cell_max(st, in, tin, n, ih, cout);
+        if (e2 == hipSuccess) e2 = launch_conv3x3_wino_f16x3(st, in, buf, meta, bias, aux, out, tin, tout, n, ih, cout, epi, 0);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+        (void)hipFree(buf);
+        if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(wino): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
+        return IODINE_OK;
+    }
+#endif
     if (mode == 2) {                // split-fp16 LDS-tiled kernel
         float* meta = nullptr;
         const size_t bytes = (size_t)(cin_pad / 16) * 9 * 2 * 2 * cout * 16;
