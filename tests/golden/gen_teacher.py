@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""TEACHER-FORCED trajectories for the split-fp16 robustness tests: the CPU oracle (oracle/iodine_oracle.py, fp32
+ATen arithmetic, pinned to the reference by tests/golden/*.npz) trains the tiny and the cfg1 architecture on blob scenes with Adam for
+100 resp. 40 steps - long enough for the masks to sharpen and the inner gradients r (x - mu) / sigma^2 to spread over many orders of
+magnitude - and the parameters are stored at a few checkpoints.  The tests load each checkpoint into the HIP module AND into the oracle
+and compare loss / ELBOs / every gradient on the same inputs (tests/test_gpu_trained_weights.py): parity is then demonstrated on weights
+after real training, not only on init-like synthetic ones.
+
+Stored per checkpoint: every parameter (float32), the oracle's loss at that step, the mask sharpness (mean max-over-slots mask).
+Usage:  python tests/golden/gen_teacher.py        (CPU, a few minutes)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(HERE))
+from iodine_amd import synth  # noqa: E402
+from oracle import iodine_oracle as O  # noqa: E402
+
+RUNS = {   # name: (family, K, T, B, steps, checkpoints, lr)
+    'teacher_tiny': ('tiny', 3, 2, 4, 100, (10, 30, 60, 100), 2e-3),
+    'teacher_cfg1': ('dsprites', 4, 3, 4, 40, (20, 40), 1e-3),
+}
+SEED_W, SEED_X, SEED_E = 11, 12, 1000
+
+
+def run(name, fam, K, T, B, steps, ckpts, lr):
+    arch = {'tiny': O.tiny_arch, 'dsprites': O.dsprites_arch}[fam](slots=K, iters=T)
+    pn = synth.make_params(O.param_shapes(arch), seed=SEED_W)
+    params = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in pn.items()}
+    imgs, _ = synth.make_images(B, arch.img_size, seed=SEED_X, kind='blobs')
+    x = torch.from_numpy(imgs)
+    opt = torch.optim.Adam(list(params.values()), lr=lr)
+    out = dict(meta_family=fam, meta_K=K, meta_T=T, meta_B=B, meta_steps=steps, meta_lr=lr, meta_ckpts=np.array(ckpts),
+               meta_seeds=np.array([SEED_W, SEED_X, SEED_E]))
+    losses = []
+    for s in range(1, steps + 1):
+        eps = torch.from_numpy(synth.make_eps(T, B, K, arch.dim_latent, seed=SEED_E + s))
+        res = O.train_forward(x, eps, params, arch)
+        opt.zero_grad()
+        res['loss'].backward()
+        opt.step()
+        losses.append(float(res['loss'].detach()))
+        if s in ckpts:
+            sharp = float(res['final_mask'].detach().max(dim=1).values.mean())
+            out[f'ckpt{s}.mask_sharpness'] = sharp
+            for k, v in params.items():
+                out[f'ckpt{s}.param.{k}'] = v.detach().numpy().copy()
+            print(f'  [{name}] step {s}: loss {losses[-1]:.3f}, mean max-mask {sharp:.3f}', flush=True)
+    out['losses'] = np.array(losses)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    for name, cfg in RUNS.items():
+        run(name, *cfg)

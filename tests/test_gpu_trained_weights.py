@@ -1,0 +1,60 @@
+"""Parity on weights AFTER training: tests/golden/teacher_*.npz hold parameters the CPU oracle reached after
+10 ... 100 Adam steps on blob scenes (tests/golden/gen_teacher.py).  Each checkpoint is loaded into the HIP module and into the oracle;
+one training step on the same images / noise must agree: loss and ELBO trajectory to 1e-4, every parameter gradient to 1e-3 rel-L2
+(the north_star gate), and reconstruct's ELBOs / masks likewise.  A second pass SHARPENS the masks artificially (mask-logit row of the
+output conv x 8: the softmax over slots saturates, r -> 0 / 1, and the inner gradients r (x - mu) / sigma^2 inside one 8 x 16 cell
+spread over many orders of magnitude) - the regime where a per-cell scale for the fp16 split is weakest."""
+import numpy as np
+import pytest
+import torch
+
+from iodine_amd import synth
+from oracle import iodine_oracle as O
+from util import load_golden, make_hip_model, rel_err, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+CASES = [('teacher_tiny', c, k) for c in (10, 30, 60, 100) for k in (1.0, 8.0)] + [('teacher_cfg1', c, k) for c in (20, 40) for k in (1.0, 8.0)]
+
+
+@pytest.mark.parametrize('name,ckpt,sharpen', CASES)
+def test_training_step_on_trained_weights(name, ckpt, sharpen):
+    t = load_golden(name)
+    fam, K, T, B = str(t['meta_family']), int(t['meta_K']), int(t['meta_T']), int(t['meta_B'])
+    arch = {'tiny': O.tiny_arch, 'dsprites': O.dsprites_arch}[fam](slots=K, iters=T)
+    sw, sx, se = (int(v) for v in t['meta_seeds'])
+    params = {k: torch.from_numpy(t[f'ckpt{ckpt}.param.{k}']).clone() for k in O.param_shapes(arch)}
+    if sharpen != 1.0:
+        params['decoder.conv.weight'][3] *= sharpen
+        params['decoder.conv.bias'][3] *= sharpen
+    imgs, _ = synth.make_images(B, arch.img_size, seed=sx, kind='blobs')
+    x = torch.from_numpy(imgs)
+    eps = torch.from_numpy(synth.make_eps(T, B, K, arch.dim_latent, seed=se + 5000 + ckpt))
+    out, rg = O.train_step_grads(x, eps, params, arch)
+    sharp = float(out['final_mask'].max(dim=1).values.mean())
+    m = make_hip_model(arch, params)
+    m.zero_grad(set_to_none=True)
+    loss = m(x.to(DEV), eps.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_loss = float(out['loss'])
+    scale = max(abs(ref_loss), float(out['elbos'].abs().max()))
+    e_loss = abs(loss.item() - ref_loss) / scale
+    e_elbo = float((m.elbo_terms[:, 0].double().cpu() - out['elbos'].double()).abs().max()) / scale
+    num = sum(float(((p.grad.double().cpu() - rg[n].double()) ** 2).sum()) for n, p in m.named_parameters())
+    den = sum(float((rg[n].double() ** 2).sum()) for n, _ in m.named_parameters())
+    e_grad = (num / den) ** 0.5
+    worst = max(((rel_l2(p.grad.cpu().numpy(), rg[n].numpy()), n) for n, p in m.named_parameters()
+                 if n != 'decoder.conv.bias' and float(rg[n].abs().max()) > 0), default=(0.0, ''))
+    print(f'[trained weights] {name} step {ckpt} sharpen x{sharpen:g}: mean max-mask {sharp:.3f}, loss {e_loss:.1e}, ELBOs {e_elbo:.1e}, '
+          f'grad rel-L2 {e_grad:.1e}, worst tensor {worst[1]} {worst[0]:.1e}')
+    assert np.isfinite(ref_loss)
+    assert e_loss < 1e-4 and e_elbo < 1e-4, (e_loss, e_elbo)
+    assert e_grad < 1e-3, e_grad
+    assert worst[0] < 5e-3, worst
+    # inference step on the same weights
+    ref = O.reconstruct(x, eps, params, arch)
+    pred, mask, mean = m.reconstruct(x.to(DEV), eps.to(DEV))
+    assert rel_err(m.elbo_terms[:, 0].cpu(), ref['elbos']) < 1e-4
+    assert rel_err(pred.cpu(), ref['pred']) < 1e-3
+    assert (mask[:, :, 0].argmax(1).cpu() == ref['mask'][:, :, 0].argmax(1)).float().mean() >= 0.999
