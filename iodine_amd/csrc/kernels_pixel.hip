@@ -22,12 +22,19 @@ struct PixelTerms {
     float ll_sum;         // sum_c logsumexp_k(log(m_k + 1e-12) + l_kc)
     float like;           // exp(ll_sum)
     float mix;            // sum_k m_k * pk_k
+    float loo[K];         // leave-one-out likelihood (iodine.py:321-328), see pixel_terms
 };
 
 template <int K>
 IOD_DEVINL void pixel_terms(const float4 xv, const float4* __restrict__ dec, size_t slot_stride, size_t p,
                             float inv2s2, float invs2, float lconst, PixelTerms<K>& t)
 {
+    // No fp contraction in here: pass 1 (layer-norm statistics) and pass 2 (the values that get normalised) inline this function
+    // separately, and hipcc's default -ffp-contract=fast fuses multiplies into adds differently per instantiation.  A 1-ulp
+    // difference upstream is harmless everywhere except in the leave-one-out channel below, whose value at a saturated mask is
+    // rounding noise x 1e5: a noise spike that pass 2 sees but pass 1's statistics do not contain is normalised to 100 sigma
+    // instead of being absorbed by the standard deviation (as in the reference, which computes the channel once).
+#pragma clang fp contract(off)
     const float xs[3] = {xv.x, xv.y, xv.z};
     float mx = -INFINITY;
 #pragma unroll
@@ -73,9 +80,27 @@ IOD_DEVINL void pixel_terms(const float4 xv, const float4* __restrict__ dec, siz
         }
     }
     t.like = expf(t.ll_sum);
+    // Leave-one-out likelihood, iodine.py:321-328: (sum_j m_j p_j - m_k p_k) / (1 - m_k + 1e-5).  Where a mask saturates
+    // (m_k -> 1) this is a cancellation divided by 1e-5: the value IS rounding noise amplified 1e5 x, in the reference too.  The
+    // only defensible target is the reference's own sequence of rounded fp32 operations - product, sequential sum over the
+    // slots (torch.sum over dim 1), difference with the SAME rounded product, denominator (1 - m) + 1e-5.  hipcc's default fp
+    // contraction fuses m_k * p_k into the sum / the difference (an EXACT product where the reference has a rounded one: the
+    // numerator then goes negative by an ulp where the reference's is exactly 0, i.e. -0.2 instead of 0 after the division) and
+    // does so differently in the three kernels that inline this function.  HIP's __fmul_rn / __fadd_rn do NOT help: they are
+    // plain operators in a header compiled with contraction on, and LLVM fuses them after inlining.  What helps is the
+    // `fp contract(off)` pragma at the top of this function with the arithmetic written as plain operators HERE.  Found by
+    // tests/test_gpu_trained_weights.py (sharpened masks): pass 2 of the split first refinement layer computed -101 sigma at a
+    // pixel where pass 1's statistics had seen 0, and the ELBO of the following iterations was off by 8e-4 relative.
+    float prod[K];
     t.mix = 0.f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) { t.pk[k] = expf(lsum[k]); t.mix += t.m[k] * t.pk[k]; }
+    for (int k = 0; k < K; ++k) {
+        t.pk[k] = expf(lsum[k]);
+        prod[k] = t.m[k] * t.pk[k];
+        t.mix = k == 0 ? prod[0] : t.mix + prod[k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) t.loo[k] = (t.mix - prod[k]) / ((1.f - t.m[k]) + 1e-5f);
 }
 
 // sum of a double over the wave (valid in every lane).  Lane swaps / DPP in the VALU on the two 32-bit halves: __shfl_down on a
@@ -139,7 +164,7 @@ void pixel_pass1_kernel(const float4* __restrict__ x4, const float4* __restrict_
             o.z = t.g1[k][2] * t.mu[k][2] * (1.f - t.mu[k][2]);
             o.w = t.m[k] * (t.g2[k] - tg);
             g_b[(size_t)k * P + p] = o;
-            const float loo = (t.mix - t.m[k] * t.pk[k]) / (1.f - t.m[k] + 1e-5f);
+            const float loo = t.loo[k];
             st[3 + 6 * k + 0] += t.g1[k][0] + t.g1[k][1] + t.g1[k][2];
             st[3 + 6 * k + 1] += t.g1[k][0] * t.g1[k][0] + t.g1[k][1] * t.g1[k][1] + t.g1[k][2] * t.g1[k][2];
             st[3 + 6 * k + 2] += t.g2[k];
@@ -253,7 +278,7 @@ void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict_
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const float* ln = s_ln + k * 8;
-                const float loo = (t.mix - t.m[k] * t.pk[k]) / (1.f - t.m[k] + 1e-5f);
+                const float loo = t.loo[k];
                 float4* tw12 = reinterpret_cast<float4*>(s_tr[wv] + lane * 12);
                 tw12[0] = make_float4(t.mu[k][0], t.mu[k][1], t.mu[k][2], t.m[k]);
                 tw12[1] = make_float4(t.logit[k], t.pk[k] / psum, (t.g1[k][0] - ln[0]) * ln[1], (t.g1[k][1] - ln[0]) * ln[1]);
@@ -276,7 +301,7 @@ void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict_
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float* ln = s_ln + k * 8;
-            const float loo = (t.mix - t.m[k] * t.pk[k]) / (1.f - t.m[k] + 1e-5f);
+            const float loo = t.loo[k];
             tw[0] = make_float4(xv.x, xv.y, xv.z, t.mu[k][0]);
             tw[1] = make_float4(t.mu[k][1], t.mu[k][2], t.m[k], t.logit[k]);
             tw[2] = make_float4(t.pk[k] / psum, (t.g1[k][0] - ln[0]) * ln[1], (t.g1[k][1] - ln[0]) * ln[1],
