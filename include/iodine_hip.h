@@ -32,8 +32,11 @@ extern "C" {
 #define IODINE_ABI_VERSION 3
 
 /* bit i set <=> the i-th entry of ARCH.ENCODING is enabled; order = code order of
- * IODINE.get_input_encoding (iodine.py:253-340).  Only IODINE_ENC_FULL (every shipped
- * config) is implemented; anything else is rejected, never silently approximated. */
+ * IODINE.get_input_encoding (iodine.py:253-340).  Accepted: IODINE_ENC_FULL (every shipped IODINE config) and any list that keeps
+ * 'posterior' and 'grad_post' and at least one image-shaped entry - in particular the reference's DEFAULT list
+ * (lib/config/defaults.py:57-80: everything but 'coordinate', 15 input channels).  The first refinement layer's weight then has
+ * that many input channels; absent channels are zero weights inside the library.  Lists without both latent entries are
+ * rejected with a message, never approximated. */
 #define IODINE_ENC_POSTERIOR      (1u << 0)
 #define IODINE_ENC_GRAD_POST      (1u << 1)
 #define IODINE_ENC_IMAGE          (1u << 2)
@@ -58,7 +61,7 @@ typedef struct iodine_config {
     double sigma;          /* ARCH.SIGMA       */
     int layernorm;         /* ARCH.LAYERNORM   */
     int stop_gradient;     /* ARCH.STOP_GRADIENT (stored, unused: iodine.py:21 has no caller) */
-    unsigned encoding;     /* ARCH.ENCODING as IODINE_ENC_* bits */
+    unsigned encoding;     /* ARCH.ENCODING as IODINE_ENC_* bits (see above for what is accepted) */
     int ref_conv_chan;     /* ARCH.REF.CONV_CHAN   (32 or 64) */
     int ref_conv_layers;   /* ARCH.REF.CONV_LAYERS */
     int ref_mlp_units;     /* ARCH.REF.MLP_UNITS   */

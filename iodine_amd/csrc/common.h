@@ -289,6 +289,8 @@ hipError_t launch_conv3x3_wino_f16x3(hipStream_t st, const float* in, const void
 hipError_t launch_conv3x3_s2_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
                                    float* out, int N, int S, int cin_real, int cout, const float* addmap = nullptr, int kdiv = 0);
 hipError_t launch_ref_split_weights(hipStream_t st, const float* w, int O, float* w_slot, float* w_sh);
+hipError_t launch_enc_expand_weights(hipStream_t st, const float* w, int O, int n_in, const int* map17, float* w17);
+hipError_t launch_enc_gather_grad(hipStream_t st, const float* g17, int O, int n_in, const int* map17, float* gw);
 hipError_t launch_ref_unsplit_grad(hipStream_t st, const float* g20, int O, float* gw);
 hipError_t launch_enc_join(hipStream_t st, const float* enck, const float* encs, float* enc, int N, int K, int P);
 hipError_t launch_conv3x3_s2_dgrad_f16x3(hipStream_t st, const float* d, const void* wpk, const float* wmeta, const float* aux,

@@ -106,6 +106,11 @@ struct iodine_handle {
     float *ref_wk = nullptr, *ref_wsh = nullptr;           // split first layer: weights in the internal channel order [Cr][12][9], [Cr][8][9]
     float *ref_wk16 = nullptr, *ref_wsh16 = nullptr, *ref_wkmeta = nullptr, *ref_wshmeta = nullptr;   // and their packs
     float* ref_g20 = nullptr;                              // [Cr][20][9] weight gradient in the internal order
+    // ARCH.ENCODING subsets: reference input channel j of the first refinement layer = internal channel enc_map[j] (code order of
+    // iodine.py:277-340); n_in < 17 -> weights expanded to / gradients gathered from the 17 internal channels
+    int n_in = 17;
+    int enc_map[17];
+    float *ref_w17 = nullptr, *ref_g17 = nullptr;          // [Cr][17][9]
     std::vector<float*> gacc;                   // one per parameter, reference shapes (slices of gacc_arena)
     float* gacc_arena = nullptr;
     size_t gacc_total = 0;
@@ -200,7 +205,7 @@ void build_param_table(iodine_handle* h)
         h->params.push_back(p);
     };
     const iodine_config& c = h->cfg;
-    int cin = 17;
+    int cin = h->n_in;
     for (int i = 0; i < c.ref_conv_layers; ++i) {
         add("refine.mlc.layers." + std::to_string(i) + ".weight", {c.ref_conv_chan, cin, 3, 3});
         add("refine.mlc.layers." + std::to_string(i) + ".bias", {c.ref_conv_chan});
@@ -239,7 +244,12 @@ int param_index(const iodine_handle* h, const std::string& name)
 std::string validate(const iodine_config& c)
 {
     char m[256];
-    if (c.encoding != IODINE_ENC_FULL) return "only the full 12-entry ARCH.ENCODING list (17 input channels) is implemented";
+    if (c.encoding & ~IODINE_ENC_FULL) return "ARCH.ENCODING has unknown entries";
+    if ((c.encoding & (IODINE_ENC_POSTERIOR | IODINE_ENC_GRAD_POST)) != (IODINE_ENC_POSTERIOR | IODINE_ENC_GRAD_POST))
+        return "ARCH.ENCODING must contain 'posterior' and 'grad_post' (the LSTM input of the refinement head is built for both; every "
+               "shipped config and lib/config/defaults.py:57-80 have them); any subset of the image-shaped entries is accepted";
+    if (!(c.encoding & (IODINE_ENC_FULL & ~(IODINE_ENC_POSTERIOR | IODINE_ENC_GRAD_POST))))
+        return "ARCH.ENCODING has no image-shaped entry: the refinement conv stack would have no input";
     if (c.img_channels != 3) return "ARCH.IMG_CHANNELS must be 3";
     if (c.dec_kernel_size != 3 || c.ref_kernel_size != 3) return "only KERNEL_SIZE 3 is implemented (all BASELINE configs)";
     if (c.ref_stride != 2) return "only REF.STRIDE 2 is implemented";
@@ -703,6 +713,17 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     h->L = cfg->dim_latent; h->T = cfg->iters; h->K = cfg->slots; h->S = cfg->img_size; h->P = h->S * h->S;
     h->Cd = cfg->dec_conv_chan; h->Dd = cfg->dec_conv_layers; h->Cr = cfg->ref_conv_chan; h->Dr = cfg->ref_conv_layers;
     h->H = cfg->ref_mlp_units;
+    {
+        // image-shaped entries in CODE order (iodine.py:277-340) with their channel counts
+        static const struct { unsigned bit; int first, count; } ent[10] = {
+            {IODINE_ENC_IMAGE, 0, 3}, {IODINE_ENC_MEANS, 3, 3}, {IODINE_ENC_MASK, 6, 1}, {IODINE_ENC_MASK_LOGITS, 7, 1},
+            {IODINE_ENC_MASK_POSTERIOR, 8, 1}, {IODINE_ENC_GRAD_MEANS, 9, 3}, {IODINE_ENC_GRAD_MASK, 12, 1},
+            {IODINE_ENC_LIKELIHOOD, 13, 1}, {IODINE_ENC_LEAVE_ONE_OUT, 14, 1}, {IODINE_ENC_COORDINATE, 15, 2}};
+        h->n_in = 0;
+        for (const auto& e : ent)
+            if (cfg->encoding & e.bit) for (int q = 0; q < e.count; ++q) h->enc_map[h->n_in++] = e.first + q;
+        for (int j = h->n_in; j < 17; ++j) h->enc_map[j] = -1;
+    }
     build_param_table(h);
 
     auto bail = [&](hipError_t e, const char* what) {
@@ -756,6 +777,7 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     }
     // split first layer: one 16-channel chunk each for the per-slot (12 real) and the per-image (8 real) channels
     ALLOC(h->ref_wk, (size_t)Cr * 12 * 9); ALLOC(h->ref_wsh, (size_t)Cr * 8 * 9); ALLOC(h->ref_g20, (size_t)Cr * 20 * 9);
+    ALLOC(h->ref_w17, (size_t)Cr * 17 * 9); ALLOC(h->ref_g17, (size_t)Cr * 17 * 9);
     ALLOC(h->ref_wk16, (size_t)9 * 2 * 2 * Cr * 4); ALLOC(h->ref_wsh16, (size_t)9 * 2 * 2 * Cr * 4);
     ALLOC(h->ref_wkmeta, (size_t)4); ALLOC(h->ref_wshmeta, (size_t)4);
     // gradient accumulators: ONE buffer, parameters back to back in named_parameters() order (the layout the wrapper's
@@ -846,8 +868,14 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     HIPCHK(h, launch_pack_dec_out_dgrad(st, P("decoder.conv.weight"), Cd, h->dec_out_meta, h->dec_out_wb16));   // same scale
     // refinement conv stack
     const bool ref_fp32 = h->precision == 0 || !refine_f16_ok(h);
+    // first layer: the reference weight has n_in input channels (ARCH.ENCODING subset); the kernels see 17
+    const float* w0 = P("refine.mlc.layers.0.weight");
+    if (h->n_in < 17) {
+        HIPCHK(h, launch_enc_expand_weights(st, w0, Cr, h->n_in, h->enc_map, h->ref_w17));
+        w0 = h->ref_w17;
+    }
     for (int l = 0; l < h->Dr; ++l) {
-        const float* w = P("refine.mlc.layers." + std::to_string(l) + ".weight");
+        const float* w = l == 0 ? w0 : P("refine.mlc.layers." + std::to_string(l) + ".weight");
         if (ref_fp32) HIPCHK(h, launch_pack_conv_weights(st, w, Cr, l == 0 ? 17 : Cr, l == 0 ? 20 : Cr, Cr, 0, h->ref_w[l]));
         HIPCHK(h, queue_copy(h->ref_b[l], P("refine.mlc.layers." + std::to_string(l) + ".bias"), Cr));
     }
@@ -856,14 +884,14 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
                                            h->ref_wb[l]));
     if (refine_f16_ok(h)) {
         for (int l = 0; l < h->Dr; ++l) {
-            const float* w = P("refine.mlc.layers." + std::to_string(l) + ".weight");
+            const float* w = l == 0 ? w0 : P("refine.mlc.layers." + std::to_string(l) + ".weight");
             HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cr, l == 0 ? 17 : Cr, l == 0 ? 32 : Cr, Cr, 0, h->ref_wmeta[l],
                                                    h->ref_wf16[l]));
             if (l > 0)
                 HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cr, Cr, Cr, Cr, 2, h->ref_wmeta[l] + 2, h->ref_wb16[l]));
         }
         // split first layer (refine_split): the same weights in the internal channel order, packed as two 16-channel convs
-        HIPCHK(h, launch_ref_split_weights(st, P("refine.mlc.layers.0.weight"), Cr, h->ref_wk, h->ref_wsh));
+        HIPCHK(h, launch_ref_split_weights(st, w0, Cr, h->ref_wk, h->ref_wsh));
         HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wk, Cr, 12, 16, Cr, 0, h->ref_wkmeta, h->ref_wk16));
         HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wsh, Cr, 8, 16, Cr, 0, h->ref_wshmeta, h->ref_wsh16));
     }
@@ -1196,6 +1224,11 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
             const int cip = l == 0 ? 20 : Cr, ireal = l == 0 ? 17 : Cr;
             int nparts = 0, cipad = 0;
             const std::string base = "refine.mlc.layers." + std::to_string(l);
+            // the layer's weight-gradient destination: the accumulator itself, or (first layer of an ARCH.ENCODING subset) a
+            // 17-channel scratch that is gathered into the n_in-channel accumulator afterwards
+            const bool gather0 = l == 0 && h->n_in < 17;
+            float* gw_dst = gather0 ? h->ref_g17 : G(base + ".weight");
+            if (gather0) HIPCHK(h, hipMemsetAsync(h->ref_g17, 0, (size_t)Cr * 17 * 9 * sizeof(float), st));
             if (l == 0 && h->fwd_split) {
                 // split first layer: 12 per-slot + 8 per-image channels from two tensors, gradient in the internal channel
                 // order, then added to the reference layout
@@ -1205,20 +1238,21 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
                 HIPCHK(h, hipMemsetAsync(h->ref_g20, 0, (size_t)Cr * 20 * 9 * sizeof(float), st));
                 HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, 20, 20, 1.f, h->ref_g20, b.wg_fold,
                                               b.wg_part_b, nb, G(base + ".bias")));
-                HIPCHK(h, launch_ref_unsplit_grad(st, h->ref_g20, Cr, G(base + ".weight")));
+                HIPCHK(h, launch_ref_unsplit_grad(st, h->ref_g20, Cr, gw_dst));
             } else if (h->precision == 1 && refine_f16_ok(h)) {
                 int nb = 0;
                 PROF(h, st, "refine_wgrad", launch_conv3x3_s2_wgrad_f16x3(st, in, b.rdpre[l], b.wg_part, b.wg_part_b, NT, sz[l],
                                                                           cip, Cr, &nparts, &cipad, &nb));
-                HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, G(base + ".weight"), b.wg_fold,
+                HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, gw_dst, b.wg_fold,
                                               b.wg_part_b, nb, G(base + ".bias")));
             } else {
                 PROF(h, st, "refine_wgrad", launch_conv3x3_wgrad_gather(st, in, b.rdpre[l], b.wg_part, NT, sz[l], sz[l], cip, Cr, 2,
                                                                         &nparts, &cipad));
-                HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, G(base + ".weight"), b.wg_fold));
+                HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, gw_dst, b.wg_fold));
                 PROF(h, st, "refine_bias_grad", launch_colsum_tall(st, b.rdpre[l], NT * sz[l + 1] * sz[l + 1], Cr, 1.f,
                                                                    G(base + ".bias"), b.wg_part_b, (size_t)512 * 64));
             }
+            if (gather0) HIPCHK(h, launch_enc_gather_grad(st, h->ref_g17, Cr, h->n_in, h->enc_map, G(base + ".weight")));
             if (l > 0) {
                 if (h->precision == 1 && refine_f16_ok(h))
                     PROF(h, st, "refine_dgrad", launch_conv3x3_s2_dgrad_f16x3(st, b.rdpre[l], h->ref_wb16[l], h->ref_wmeta[l] + 2,

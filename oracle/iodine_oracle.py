@@ -38,6 +38,8 @@ FULL_ENCODING = (
     'mask_posterior', 'grad_means', 'grad_mask', 'likelihood',
     'leave_one_out_likelihood', 'coordinate',
 )
+# the reference's default ARCH.ENCODING (lib/config/defaults.py:57-80): everything but 'coordinate'
+DEFAULT_ENCODING = tuple(e for e in FULL_ENCODING if e != 'coordinate')
 
 
 @dataclass
@@ -62,9 +64,17 @@ class Arch:
 
     @property
     def n_input_channels(self) -> int:
-        # iodine.py:345-374 with the full encoding list: 3+3+1+1+1+3+1+1+1+2 = 17
+        # iodine.py:345-374; the full encoding list gives 3+3+1+1+1+3+1+1+1+2 = 17, the reference's DEFAULT list
+        # (lib/config/defaults.py:57-80, no 'coordinate') 15
         c = self.img_channels
-        return c + c + 1 + 1 + 1 + c + 1 + 1 + 1 + 2
+        sizes = dict(image=c, means=c, mask=1, mask_logits=1, mask_posterior=1, grad_means=c, grad_mask=1, likelihood=1,
+                     leave_one_out_likelihood=1, coordinate=2)
+        return sum(n for k, n in sizes.items() if k in self.encoding)
+
+    @property
+    def latent_size(self) -> int:
+        # iodine.py:345-374: 2L for 'posterior' + 2L for 'grad_post'
+        return 2 * self.dim_latent * (('posterior' in self.encoding) + ('grad_post' in self.encoding))
 
 
 def clevr_arch(slots=7, iters=5) -> Arch:
@@ -99,7 +109,7 @@ def param_shapes(a: Arch) -> "Dict[str, Tuple[int, ...]]":
         cin = a.ref_chan
     shapes['refine.mlp.layers.0.weight'] = (H, a.ref_chan)
     shapes['refine.mlp.layers.0.bias'] = (H,)
-    shapes['refine.lstm.weight_ih'] = (4 * H, H + 4 * L)
+    shapes['refine.lstm.weight_ih'] = (4 * H, H + 4 * L)      # iodine.py:462 hard-codes 4 L: both latent entries must be enabled
     shapes['refine.lstm.weight_hh'] = (4 * H, H)
     shapes['refine.lstm.bias_ih'] = (4 * H,)
     shapes['refine.lstm.bias_hh'] = (4 * H,)
@@ -212,30 +222,37 @@ def elbo_terms(x: Tensor, post_mean: Tensor, post_logvar: Tensor, eps: Tensor,
 def input_encoding(x: Tensor, t: Dict[str, Tensor], post_mean: Tensor, post_logvar: Tensor,
                    g_mean: Tensor, g_mask: Tensor, g_pm: Tensor, g_plv: Tensor,
                    a: Arch) -> Tuple[Tensor, Tensor]:
-    """``get_input_encoding`` for the full encoding list: (B,K,17,S,S), (B,K,4L).
-    Channel order is fixed by the code order of iodine.py:277-340."""
+    """``get_input_encoding``: (B,K,17,S,S), (B,K,4L) for the full encoding list; an entry missing from ``a.encoding`` drops its
+    channels (iodine.py:253-340 tests ``in self.encodings`` entry by entry).  Channel order is fixed by the CODE order of
+    iodine.py:277-340, not by the order of the list."""
     B, K = post_mean.shape[:2]
     S = a.img_size
     ln = layernorm if a.layernorm else (lambda v: v)
-    latent = torch.cat((post_mean, post_logvar, ln(g_pm), ln(g_plv)), dim=-1)
+    lat = []
+    if 'posterior' in a.encoding:
+        lat += [post_mean, post_logvar]
+    if 'grad_post' in a.encoding:
+        lat += [ln(g_pm), ln(g_plv)]
+    latent = torch.cat(lat, dim=-1) if lat else post_mean.new_zeros(B, K, 0)
     k_like = torch.exp(t['k_ll'].sum(dim=2, keepdim=True))              # (B,K,1,S,S)
     mask_post = k_like / k_like.sum(dim=1, keepdim=True)
     like = torch.exp(t['ll_px'].sum(dim=1, keepdim=True))[:, None].expand(B, K, 1, S, S)
     mixture = (t['mask'] * k_like).sum(dim=1, keepdim=True)
     loo = (mixture - t['mask'] * k_like) / (1 - t['mask'] + 1e-5)
     coords = coord_planes(S, x.dtype, x.device)[None, None].expand(B, K, 2, S, S)
-    enc = torch.cat((
-        x[:, None].expand(B, K, a.img_channels, S, S),   # 0-2  image
-        t['mean'],                                       # 3-5  means
-        t['mask'],                                       # 6    mask
-        t['logits'],                                     # 7    mask_logits
-        mask_post,                                       # 8    mask_posterior
-        ln(g_mean),                                      # 9-11 grad_means
-        ln(g_mask),                                      # 12   grad_mask
-        ln(like.contiguous()),                           # 13   likelihood
-        ln(loo),                                         # 14   leave_one_out_likelihood
-        coords,                                          # 15-16 coordinate
-    ), dim=2)
+    parts = (
+        ('image', x[:, None].expand(B, K, a.img_channels, S, S)),       # 0-2  image
+        ('means', t['mean']),                                            # 3-5  means
+        ('mask', t['mask']),                                             # 6    mask
+        ('mask_logits', t['logits']),                                    # 7    mask_logits
+        ('mask_posterior', mask_post),                                   # 8    mask_posterior
+        ('grad_means', ln(g_mean)),                                      # 9-11 grad_means
+        ('grad_mask', ln(g_mask)),                                       # 12   grad_mask
+        ('likelihood', ln(like.contiguous())),                           # 13   likelihood
+        ('leave_one_out_likelihood', ln(loo)),                           # 14   leave_one_out_likelihood
+        ('coordinate', coords),                                          # 15-16 coordinate
+    )
+    enc = torch.cat([v for k, v in parts if k in a.encoding], dim=2)
     return enc.detach(), latent.detach()
 
 

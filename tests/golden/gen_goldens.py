@@ -46,16 +46,21 @@ CASES = {
     'cfg2_dsprites_k6_t5_b2': ('dsprites', 6, 5, 2, 'uniform'),
     'cfg3_clevr_k7_t5_b1': ('clevr', 7, 5, 1, 'blobs'),
     'cfg5_clevr_k11_t7_b1': ('clevr', 11, 7, 1, 'uniform'),
+    # the reference's DEFAULT ARCH.ENCODING (lib/config/defaults.py:57-80): no 'coordinate' -> 15 input channels (round 3)
+    'tiny_default_enc': ('tiny', 3, 2, 2, 'uniform'),
+    'cfg1_default_enc': ('dsprites', 4, 3, 2, 'blobs'),
 }
+# encoding list per case (default: the full 12-entry list of the shipped IODINE configs)
+CASE_ENCODING = {'tiny_default_enc': [e for e in ENCODING if e != 'coordinate'], 'cfg1_default_enc': [e for e in ENCODING if e != 'coordinate']}
 DEC_GAIN = 3.0
 POST_SCALE = 0.1
 SEED_W, SEED_X, SEED_E = 0, 0, 1
 
 
-def make_arch_ns(fam, K, T):
+def make_arch_ns(fam, K, T, encoding=None):
     f = ARCHS[fam]
     return SimpleNamespace(
-        DIM_LATENT=f['L'], ITERS=T, SLOTS=K, ENCODING=list(ENCODING), IMG_CHANNELS=3,
+        DIM_LATENT=f['L'], ITERS=T, SLOTS=K, ENCODING=list(encoding or ENCODING), IMG_CHANNELS=3,
         IMG_SIZE=f['S'], SIGMA=0.10, LAYERNORM=True, STOP_GRADIENT=False,
         REF=SimpleNamespace(CONV_CHAN=f['ref'][0], CONV_LAYERS=f['ref'][1], MLP_UNITS=f['ref'][2],
                             KERNEL_SIZE=3, STRIDE=2),
@@ -82,8 +87,8 @@ class EpsReplay:
         return e
 
 
-def build_reference(fam, K, T, dtype):
-    model = RefIODINE(make_arch_ns(fam, K, T))
+def build_reference(fam, K, T, dtype, encoding=None):
+    model = RefIODINE(make_arch_ns(fam, K, T, encoding))
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     params = synth.make_params(shapes, seed=SEED_W, dec_gain=DEC_GAIN, posterior_scale=POST_SCALE)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
@@ -110,8 +115,10 @@ def run_case(case):
     out = dict(meta_K=K, meta_T=T, meta_B=B, meta_S=S, meta_L=L, meta_kind=kind, meta_family=fam,
                meta_dec_gain=DEC_GAIN, meta_post_scale=POST_SCALE,
                meta_seeds=np.array([SEED_W, SEED_X, SEED_E]))
+    if case in CASE_ENCODING:
+        out['meta_encoding'] = ','.join(CASE_ENCODING[case])
     for tag, dtype in (('f32', torch.float32), ('f64', torch.float64)):
-        model, shapes = build_reference(fam, K, T, dtype)
+        model, shapes = build_reference(fam, K, T, dtype, CASE_ENCODING.get(case))
         x = torch.from_numpy(imgs).to(dtype)
         e = torch.from_numpy(eps).to(dtype)
 
@@ -140,7 +147,7 @@ def run_case(case):
         out[f'{tag}.train.post_logvar'] = model.posterior.logvar.detach().double().numpy().copy()
         for n, prm in model.named_parameters():
             g = prm.grad if prm.grad is not None else torch.zeros_like(prm)
-            if case == 'tiny':
+            if case.startswith('tiny'):
                 out[f'{tag}.train.grad.{n}'] = g.detach().double().numpy().copy()
             else:
                 summarize(f'{tag}.train.grad.{n}', g, out)
@@ -157,7 +164,7 @@ def run_case(case):
         out[f'{tag}.recon.elbos'] = torch.stack(elbo_log).double().numpy().copy()
         out[f'{tag}.recon.post_mean'] = model.posterior.mean.detach().double().numpy().copy()
         out[f'{tag}.recon.post_logvar'] = model.posterior.logvar.detach().double().numpy().copy()
-        if case == 'tiny':
+        if case.startswith('tiny'):
             out[f'{tag}.recon.pred'] = pred.detach().double().numpy().copy()
             out[f'{tag}.recon.mask'] = mask.detach().double().numpy().copy()
             out[f'{tag}.recon.mean'] = mean.detach().double().numpy().copy()

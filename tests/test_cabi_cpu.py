@@ -34,12 +34,14 @@ def test_config_struct_matches_header_field_order():
 def test_create_rejects_unsupported_configs_with_message():
     L = _lib.lib()
     cfg = _lib.Config(dim_latent=16, iters=3, slots=4, img_size=64, img_channels=3, sigma=0.1, layernorm=1,
-                      stop_gradient=0, encoding=_lib.ENC_FULL & ~(1 << 11), ref_conv_chan=32, ref_conv_layers=3,
+                      stop_gradient=0, encoding=_lib.ENC_FULL & ~(1 << 1), ref_conv_chan=32, ref_conv_layers=3,
                       ref_mlp_units=128, ref_kernel_size=3, ref_stride=2, dec_conv_chan=32, dec_conv_layers=5,
                       dec_kernel_size=3)
     h = C.c_void_p()
-    assert L.iodine_create(C.byref(cfg), C.byref(h)) == 1 and not h.value
-    assert b'ENCODING' in L.iodine_last_error(None)
+    assert L.iodine_create(C.byref(cfg), C.byref(h)) == 1 and not h.value      # no 'grad_post': the LSTM input would be 2L narrower
+    assert b'ENCODING' in L.iodine_last_error(None) and b'grad_post' in L.iodine_last_error(None)
+    cfg.encoding = 0x3                                                          # only the latent entries: no conv input at all
+    assert L.iodine_create(C.byref(cfg), C.byref(h)) == 1 and b'image-shaped' in L.iodine_last_error(None)
     cfg.encoding = _lib.ENC_FULL
     cfg.dec_kernel_size = 5                       # configs/test.yaml uses 5: rejected, not approximated
     assert L.iodine_create(C.byref(cfg), C.byref(h)) == 1

@@ -10,7 +10,7 @@ import torch
 
 from iodine_amd import synth
 from oracle import iodine_oracle as O
-from util import make_hip_model, rel_err, rel_l2
+from util import golden_setup, load_golden, make_hip_model, rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -80,3 +80,58 @@ def test_unsupported_configurations_fail_loudly():
     big.max_batch = lambda training=False: 10 ** 9
     with pytest.raises(RuntimeError, match='batch too large'):
         big.reconstruct(torch.empty(300, 3, 128, 128, device=DEV))
+
+
+# ---- ARCH.ENCODING subsets (round 3): the reference's DEFAULT list has no 'coordinate' (lib/config/defaults.py:57-80) -----------
+@pytest.mark.parametrize('case', ['tiny_default_enc', 'cfg1_default_enc'])
+@pytest.mark.parametrize('opt', [None, ('refine_split', 0), ('conv_precision', 0)])
+def test_default_encoding_without_coordinate(case, opt):
+    """15 input channels: weights / gradients of the first refinement layer have the reference's shape (C, 15, 3, 3); against the
+    goldens generated from the unmodified reference with its default ENCODING, and against the oracle"""
+    g = load_golden(case)
+    arch, params, x, eps, _ = golden_setup(g)
+    assert 'coordinate' not in arch.encoding and params['refine.mlc.layers.0.weight'].shape[1] == 15
+    m = make_hip_model(arch, params)
+    assert m.get_input_size() == (15, 4 * arch.dim_latent)
+    if opt:
+        m.set_option(*opt)
+    xd, ed = x.to(DEV), eps.to(DEV)
+    m.zero_grad(set_to_none=True)
+    loss = m(xd, ed)
+    loss.backward()
+    assert abs(loss.item() - float(g['f32.train.loss'])) <= 1e-4 * abs(float(g['f32.train.loss']))
+    assert rel_err(m.elbo_terms[:, 0].cpu(), g['f32.train.elbos']) < 1e-4
+    out, rg = O.train_step_grads(x, eps, params, arch)
+    bad = [(n, rel_l2(p.grad.cpu().numpy(), rg[n].numpy())) for n, p in m.named_parameters()
+           if n != 'decoder.conv.bias' and not rel_l2(p.grad.cpu().numpy(), rg[n].numpy()) < 2e-3]
+    assert not bad, bad
+    assert tuple(m.refine.mlc.layers[0].weight.grad.shape) == (arch.ref_chan, 15, 3, 3)
+    if case.startswith('tiny'):
+        for n, p in m.named_parameters():
+            assert rel_l2(p.grad.cpu().numpy(), g['f64.train.grad.' + n]) < 2e-3 or n == 'decoder.conv.bias', n
+    pred, mask, mean = m.reconstruct(xd, ed)
+    assert rel_err(m.elbo_terms[:, 0].cpu(), g['f32.recon.elbos']) < 1e-4
+    ref = O.reconstruct(x, eps, params, arch)
+    assert rel_err(pred.cpu(), ref['pred']) < 2e-4
+
+
+def test_encoding_subset_in_the_middle_of_the_list():
+    """an arbitrary subset of the image-shaped entries (here without 'mask_posterior' and 'grad_mask': 15 channels, holes in the
+    middle of the code order) against the oracle; lists without both latent entries are refused"""
+    g = load_golden('tiny')
+    arch, _, x, eps, _ = golden_setup(g)
+    arch.encoding = tuple(e for e in O.FULL_ENCODING if e not in ('mask_posterior', 'grad_mask'))
+    pn = synth.make_params(O.param_shapes(arch), seed=5, dec_gain=3.0, posterior_scale=0.1)
+    params = {k: torch.from_numpy(v) for k, v in pn.items()}
+    m = make_hip_model(arch, params)
+    m.zero_grad(set_to_none=True)
+    loss = m(x.to(DEV), eps.to(DEV))
+    loss.backward()
+    out, rg = O.train_step_grads(x, eps, params, arch)
+    assert abs(loss.item() - float(out['loss'])) <= 1e-4 * abs(float(out['loss']))
+    bad = [(n, rel_l2(p.grad.cpu().numpy(), rg[n].numpy())) for n, p in m.named_parameters()
+           if n != 'decoder.conv.bias' and not rel_l2(p.grad.cpu().numpy(), rg[n].numpy()) < 2e-3]
+    assert not bad, bad
+    arch.encoding = tuple(e for e in O.FULL_ENCODING if e != 'posterior')
+    with pytest.raises(RuntimeError, match='grad_post'):
+        make_hip_model(arch, {k: torch.zeros(s) for k, s in O.param_shapes(arch).items()}).reconstruct(x.to(DEV), eps.to(DEV))

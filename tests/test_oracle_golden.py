@@ -29,9 +29,12 @@ def test_param_shapes_match_reference_state_dict():
     assert sum(int(np.prod(s)) for s in O.param_shapes(O.dsprites_arch(slots=4, iters=3)).values()) == 240036
 
 
+@pytest.mark.parametrize('case', ['tiny', 'tiny_default_enc'])
 @pytest.mark.parametrize('tag,dtype,tol', [('f32', torch.float32, 2e-5), ('f64', torch.float64, 1e-11)])
-def test_tiny_full_tensors(tag, dtype, tol):
-    g = load_golden('tiny')
+def test_tiny_full_tensors(tag, dtype, tol, case):
+    """every tensor of a training step and of reconstruct; 'tiny_default_enc' = the reference's DEFAULT ARCH.ENCODING
+    (lib/config/defaults.py:57-80: no 'coordinate', 15 input channels)"""
+    g = load_golden(case)
     arch, params, x, eps, _ = golden_setup(g, dtype)
     out, grads = O.train_step_grads(x, eps, params, arch)
     assert abs(out['loss'].item() - float(g[f'{tag}.train.loss'])) <= tol * abs(float(g[f'{tag}.train.loss']))
@@ -77,7 +80,7 @@ def test_closed_form_inner_gradients_match_autograd():
 
 
 @pytest.mark.parametrize('case', ['cfg1_dsprites_k4_t3_b4', 'cfg2_dsprites_k6_t5_b2',
-                                  'cfg3_clevr_k7_t5_b1', 'cfg5_clevr_k11_t7_b1'])
+                                  'cfg3_clevr_k7_t5_b1', 'cfg5_clevr_k11_t7_b1', 'cfg1_default_enc'])
 def test_config_scalars(case):
     g = load_golden(case)
     arch, params, x, eps, gt = golden_setup(g)
