@@ -80,7 +80,9 @@ def clocks(outdir, tag):
 
 
 def main():
-XX
+    outdir = sys.argv[1]
+    tag = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith('-') else 'r03'
+    cfg = 'dsprites' if 'dsprites' in sys.argv[2:] else 'clevr6'
     from iodine_amd.build import source_digest
     try:
         commit = subprocess.run(['git', 'rev-parse', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip() or 'unknown'
