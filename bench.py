@@ -233,7 +233,12 @@ def main():
                   file=sys.stderr, flush=True)
         sys.exit(2)
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if ndev < max(world, 1) or local >= ndev:
+    # test hook (tests/test_gpu_multirank.py on a 1-GPU box): IODINE_BENCH_SHARE_DEVICE=1 puts every rank on device 0 and runs the
+    # collectives over gloo - RCCL refuses two ranks on one device.  Everything else of the N > 1 path is the code that ships.
+    share = os.environ.get('IODINE_BENCH_SHARE_DEVICE') == '1' and world > 1
+    if share:
+        local = 0
+    if ndev < (1 if share else max(world, 1)) or local >= ndev:
         if rank == 0:
             print(f'bench.py: --gpus {world} needs {world} visible ROCm devices on this node, found {ndev} '
                   f'(rank {rank} of {world}, LOCAL_RANK {local})', file=sys.stderr, flush=True)
@@ -242,7 +247,10 @@ def main():
     torch.cuda.set_device(device)                 # before the process group: RCCL binds the communicator to this device
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if share:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     model, arch, params = build_model(args.config, args.slots, args.iters, device)
     B, T, K, S = args.batch, arch.ITERS, arch.SLOTS, arch.IMG_SIZE

@@ -16,9 +16,13 @@ from iodine_amd import parallel  # noqa: E402
 from util import golden_setup, load_golden, make_hip_model, rel_l2  # noqa: E402
 
 rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
-dev = torch.device('cuda', local)
+share = os.environ.get('IODINE_BENCH_SHARE_DEVICE') == '1'        # 1-GPU box: both ranks on device 0, collectives over gloo
+dev = torch.device('cuda', 0 if share else local)
 torch.cuda.set_device(dev)
-dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+if share:
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+else:
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
 g = load_golden('cfg1_dsprites_k4_t3_b4')
 arch, params, x, eps, _ = golden_setup(g)

@@ -42,3 +42,35 @@ def test_two_rank_gradients_equal_the_unsharded_step():
     assert out['bitwise_equal_over_ranks']                      # every rank holds the same averaged gradients
     assert out['grad_rel_l2_vs_unsharded'] < 2e-5
     assert out['loss_rel_err_vs_unsharded'] < 1e-6 and out['loss_rel_err_vs_reference'] < 1e-4
+
+
+# ---- the same two tests with BOTH ranks on one device and the collectives over gloo: runs on the 1-GPU boxes of the build loop.
+# Two processes drive the HIP library on the same GPU at once (two handles, two arenas, two streams), shard the images, all-reduce the
+# flat gradient buffer in place and step Adam - everything of the N > 1 path except RCCL itself (which refuses two ranks on one device).
+def _shared_env():
+    e = dict(os.environ)
+    e['IODINE_BENCH_SHARE_DEVICE'] = '1'
+    return e
+
+
+def test_two_ranks_sharing_one_device_bench_path():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '8',
+                        '--no-cpu-baseline', '--no-exact-fp32', '--no-sustain'], capture_output=True, text=True, timeout=1500,
+                       env=_shared_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out['n_gpus'] == 2 and out['rccl']['world_size'] == 2 and out['rccl']['backend'] == 'gloo'
+    assert out['config']['global_batch'] == 16 and out['scaling'] == 'weak'
+    assert out['rccl']['replicas_identical'] is True          # after Adam steps on all-reduced gradients the replicas still agree bitwise
+    assert out['value'] > 0 and out['ms_per_step'] > 0 and out['roofline']['frac'] > 0
+
+
+def test_two_ranks_sharing_one_device_gradients_equal_the_unsharded_step():
+    r = launch.spawn(os.path.join(ROOT, 'tests', 'rccl_worker.py'), [], 2, env=_shared_env(), capture=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out['world'] == 2 and out['backend'] == 'gloo'
+    assert out['same_params'] and out['in_place']
+    assert out['bitwise_equal_over_ranks']
+    assert out['grad_rel_l2_vs_unsharded'] < 2e-5
+    assert out['loss_rel_err_vs_unsharded'] < 1e-6 and out['loss_rel_err_vs_reference'] < 1e-4
