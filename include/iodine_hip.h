@@ -62,14 +62,14 @@ typedef struct iodine_config {
     int layernorm;         /* ARCH.LAYERNORM   */
     int stop_gradient;     /* ARCH.STOP_GRADIENT (stored, unused: iodine.py:21 has no caller) */
     unsigned encoding;     /* ARCH.ENCODING as IODINE_ENC_* bits (see above for what is accepted) */
-    int ref_conv_chan;     /* ARCH.REF.CONV_CHAN   (32 or 64) */
+    int ref_conv_chan;     /* ARCH.REF.CONV_CHAN   (32 or 64: tuned kernels; other divisors of 256: generic fallback path) */
     int ref_conv_layers;   /* ARCH.REF.CONV_LAYERS */
     int ref_mlp_units;     /* ARCH.REF.MLP_UNITS   */
-    int ref_kernel_size;   /* ARCH.REF.KERNEL_SIZE (3) */
+    int ref_kernel_size;   /* ARCH.REF.KERNEL_SIZE (3: tuned kernels; 5, 7: generic fallback path, kernels_generic.hip) */
     int ref_stride;        /* ARCH.REF.STRIDE      (2) */
-    int dec_conv_chan;     /* ARCH.DEC.CONV_CHAN   (32 or 64) */
+    int dec_conv_chan;     /* ARCH.DEC.CONV_CHAN   (32 or 64: tuned kernels; other multiples of 4 in 8..256: generic path) */
     int dec_conv_layers;   /* ARCH.DEC.CONV_LAYERS (>= 2) */
-    int dec_kernel_size;   /* ARCH.DEC.KERNEL_SIZE (3) */
+    int dec_kernel_size;   /* ARCH.DEC.KERNEL_SIZE (3: tuned kernels; 5 - the reference's default - and 7: generic path) */
 } iodine_config;
 
 typedef struct iodine_handle iodine_handle;

@@ -289,8 +289,22 @@ hipError_t launch_conv3x3_wino_f16x3(hipStream_t st, const float* in, const void
 hipError_t launch_conv3x3_s2_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
                                    float* out, int N, int S, int cin_real, int cout, const float* addmap = nullptr, int kdiv = 0);
 hipError_t launch_ref_split_weights(hipStream_t st, const float* w, int O, float* w_slot, float* w_sh);
-hipError_t launch_enc_expand_weights(hipStream_t st, const float* w, int O, int n_in, const int* map17, float* w17);
-hipError_t launch_enc_gather_grad(hipStream_t st, const float* g17, int O, int n_in, const int* map17, float* gw);
+hipError_t launch_enc_expand_weights(hipStream_t st, const float* w, int O, int n_in, const int* map17, float* w17, int kk = 9);
+hipError_t launch_enc_gather_grad(hipStream_t st, const float* g17, int O, int n_in, const int* map17, float* gw, int kk = 9);
+
+// kernels_generic.hip: fallback fp32 convs for any odd kernel size / channel count (correctness path, see the file header)
+constexpr int GEN_WGRAD_SLICES = 64;
+hipError_t launch_gen_pack_weights(hipStream_t st, const float* w, int Co, int Ci, int k, float* wt);
+hipError_t launch_gen_broadcast(hipStream_t st, const float* z, const float* lin, int N, int L, int S, float* bc);
+hipError_t launch_gen_conv_fwd(hipStream_t st, const float* in, const float* wt, const float* bias, float* out, int N, int Si, int Ci,
+                               int ldc, int Co, int k, int s, int elu);
+hipError_t launch_gen_conv_dgrad(hipStream_t st, const float* dout, const float* wt, const float* aux, float* din, int N, int Si, int Ci,
+                                 int ldi, int Co, int k, int s);
+size_t gen_wgrad_scratch_floats(int Ci, int Co, int k);
+hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* dout, float* scratch, int N, int Si, int Ci, int ldc,
+                                 int Ci_dst, int Co, int k, int s, float alpha, float* gw, float* gb);
+hipError_t launch_gen_sum_pixels(hipStream_t st, const float* src, int N, int P, int C, int ld, int ldo, float* out);
+hipError_t launch_gen_identity(hipStream_t st, float* m, int rows, int L);
 hipError_t launch_ref_unsplit_grad(hipStream_t st, const float* g20, int O, float* gw);
 hipError_t launch_enc_join(hipStream_t st, const float* enck, const float* encs, float* enc, int N, int K, int P);
 hipError_t launch_conv3x3_s2_dgrad_f16x3(hipStream_t st, const float* d, const void* wpk, const float* wmeta, const float* aux,

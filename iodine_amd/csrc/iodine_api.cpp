@@ -57,6 +57,7 @@ struct Buffers {               // workspace carve-up for one batch size / mode
     float* carry_h[2] = {nullptr, nullptr};
     float* carry_c[2] = {nullptr, nullptr};
     std::vector<float*> rdpre;                 // gradient wrt refinement pre-activations, per layer
+    float *bc = nullptr, *dbc = nullptr, *gen_scr = nullptr;   // generic path: materialised broadcast input, its gradient, wgrad partials
 };
 
 }  // namespace
@@ -110,7 +111,13 @@ struct iodine_handle {
     // iodine.py:277-340); n_in < 17 -> weights expanded to / gradients gathered from the 17 internal channels
     int n_in = 17;
     int enc_map[17];
-    float *ref_w17 = nullptr, *ref_g17 = nullptr;          // [Cr][17][9]
+    float *ref_w17 = nullptr, *ref_g17 = nullptr;          // [Cr][17][kr * kr]
+    // GENERIC fallback path (kernels_generic.hip): KERNEL_SIZE other than 3 or CONV_CHAN other than 32 / 64.  Weights re-packed to
+    // [tap][ci][co]; the broadcast layer is materialised; nothing of the tuned conv kernels runs.
+    bool generic = false;
+    int kd = 3, kr = 3;                                    // DEC / REF kernel sizes
+    std::vector<float*> gen_wdec, gen_wref;                // [layer]: packed weights
+    float *gen_wout = nullptr, *gen_b0 = nullptr, *gen_ident = nullptr;   // output conv pack, bias of decoder layer 0, [9 Cd][L] identity
     std::vector<float*> gacc;                   // one per parameter, reference shapes (slices of gacc_arena)
     float* gacc_arena = nullptr;
     size_t gacc_total = 0;
@@ -170,7 +177,7 @@ hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, c
         if (e1_) HIPCHK(h, hipEventRecord(e1_, st));                                 \
     } while (0)
 
-bool conv_ws_ok(const iodine_handle* h) { return h->variant == 6 && h->precision == 1 && h->S >= 16 && (h->S & (h->S - 1)) == 0; }
+bool conv_ws_ok(const iodine_handle* h) { return !h->generic && h->variant == 6 && h->precision == 1 && h->S >= 16 && (h->S & (h->S - 1)) == 0; }
 
 hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, const void* wpk, const void* wpk_ws,
                       const float* wmeta, const float* bias, const float* aux, float* out, const float* tmax_in, float* tmax_out,
@@ -207,7 +214,7 @@ void build_param_table(iodine_handle* h)
     const iodine_config& c = h->cfg;
     int cin = h->n_in;
     for (int i = 0; i < c.ref_conv_layers; ++i) {
-        add("refine.mlc.layers." + std::to_string(i) + ".weight", {c.ref_conv_chan, cin, 3, 3});
+        add("refine.mlc.layers." + std::to_string(i) + ".weight", {c.ref_conv_chan, cin, c.ref_kernel_size, c.ref_kernel_size});
         add("refine.mlc.layers." + std::to_string(i) + ".bias", {c.ref_conv_chan});
         cin = c.ref_conv_chan;
     }
@@ -224,11 +231,11 @@ void build_param_table(iodine_handle* h)
     add("refine.logvar_update.bias", {L});
     cin = c.dim_latent + 2;
     for (int i = 0; i < c.dec_conv_layers; ++i) {
-        add("decoder.mlc.layers." + std::to_string(i) + ".weight", {c.dec_conv_chan, cin, 3, 3});
+        add("decoder.mlc.layers." + std::to_string(i) + ".weight", {c.dec_conv_chan, cin, c.dec_kernel_size, c.dec_kernel_size});
         add("decoder.mlc.layers." + std::to_string(i) + ".bias", {c.dec_conv_chan});
         cin = c.dec_conv_chan;
     }
-    add("decoder.conv.weight", {4, c.dec_conv_chan, 3, 3});
+    add("decoder.conv.weight", {4, c.dec_conv_chan, c.dec_kernel_size, c.dec_kernel_size});
     add("decoder.conv.bias", {4});
     add("posterior.init_mean", {L});
     add("posterior.init_logvar", {L});
@@ -251,11 +258,15 @@ std::string validate(const iodine_config& c)
     if (!(c.encoding & (IODINE_ENC_FULL & ~(IODINE_ENC_POSTERIOR | IODINE_ENC_GRAD_POST))))
         return "ARCH.ENCODING has no image-shaped entry: the refinement conv stack would have no input";
     if (c.img_channels != 3) return "ARCH.IMG_CHANNELS must be 3";
-    if (c.dec_kernel_size != 3 || c.ref_kernel_size != 3) return "only KERNEL_SIZE 3 is implemented (all BASELINE configs)";
+    // KERNEL_SIZE 3 with 32 / 64 channels runs on the tuned kernels; other odd kernel sizes and channel counts on the generic
+    // fallback path (kernels_generic.hip)
+    for (int k : {c.dec_kernel_size, c.ref_kernel_size})
+        if (k != 3 && k != 5 && k != 7) return "KERNEL_SIZE must be 3, 5 or 7 (odd: the reference pads with KERNEL_SIZE // 2, iodine.py:419,580)";
     if (c.ref_stride != 2) return "only REF.STRIDE 2 is implemented";
     if (c.img_size < 16 || c.img_size % 16 != 0) return "ARCH.IMG_SIZE must be a positive multiple of 16";
-    if (c.dec_conv_chan != 32 && c.dec_conv_chan != 64) return "DEC.CONV_CHAN must be 32 or 64";
-    if (c.ref_conv_chan != 32 && c.ref_conv_chan != 64) return "REF.CONV_CHAN must be 32 or 64";
+    if (c.dec_conv_chan < 8 || c.dec_conv_chan > 256 || c.dec_conv_chan % 4 != 0) return "DEC.CONV_CHAN must be a multiple of 4 in 8..256";
+    if (c.ref_conv_chan < 4 || c.ref_conv_chan > 256 || 256 % c.ref_conv_chan != 0) return "REF.CONV_CHAN must divide 256 (4 ... 256)";
+    if (9 * c.dec_conv_chan < c.dim_latent) return "DIM_LATENT must not exceed 9 * DEC.CONV_CHAN";
     if (c.dec_conv_layers < 2) return "DEC.CONV_LAYERS must be >= 2";
     if (c.ref_conv_layers < 1 || (c.img_size >> c.ref_conv_layers) < 1) return "REF.CONV_LAYERS out of range for IMG_SIZE";
     if (c.slots < 1 || c.slots > 12) return "ARCH.SLOTS must be in 1..12";
@@ -377,6 +388,15 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
         int s = h->S;
         for (int l = 0; l < h->Dr; ++l) { s = ref_out_size(s); b.rdpre[l] = a.take<float>((size_t)T * N * s * s * Cr); }
     }
+    if (h->generic) {
+        b.bc = a.take<float>((size_t)N * P * (L + 2));
+        b.dbc = a.take<float>((size_t)N * P * (L + 2));
+        if (mode == 1) {
+            size_t scr = std::max(gen_wgrad_scratch_floats(L + 2, Cd, h->kd), gen_wgrad_scratch_floats(Cd, Cd, h->kd));
+            scr = std::max(scr, std::max(gen_wgrad_scratch_floats(17, Cr, h->kr), gen_wgrad_scratch_floats(Cr, Cr, h->kr)));
+            b.gen_scr = a.take<float>(scr);
+        }
+    }
     b.bytes = (a.off + 255) & ~(size_t)255;
 }
 
@@ -421,10 +441,22 @@ int ensure_workspace(iodine_handle* h, int B, int mode)
 }
 
 // one decoder forward pass from z (already in buf.V via dec_v) -> dec_out
-int decoder_forward(iodine_handle* h, hipStream_t st, int N, float* out = nullptr)
+int decoder_forward(iodine_handle* h, hipStream_t st, int N, const float* z, float* out = nullptr)
 {
     Buffers& b = h->buf;
     if (!out) out = b.dec_out;
+    if (h->generic) {
+        // fallback: materialised broadcast input, every layer a generic fp32 conv (kernels_generic.hip)
+        HIPCHK(h, launch_gen_broadcast(st, z, h->lin, N, h->L, h->S, b.bc));
+        const float* in = b.bc;
+        for (int l = 0; l < h->Dd; ++l) {
+            PROF(h, st, "gen_conv", launch_gen_conv_fwd(st, in, h->gen_wdec[l], l == 0 ? h->gen_b0 : h->dec_b[l], b.act[l], N, h->S,
+                                                        l == 0 ? h->L + 2 : h->Cd, l == 0 ? h->L + 2 : h->Cd, h->Cd, h->kd, 1, 1));
+            in = b.act[l];
+        }
+        PROF(h, st, "gen_conv", launch_gen_conv_fwd(st, in, h->gen_wout, h->dec_out_b, out, N, h->S, h->Cd, h->Cd, 4, h->kd, 1, 0));
+        return IODINE_OK;
+    }
     const bool ws = conv_ws_ok(h);
     PROF(h, st, "dec_l0", launch_dec_l0(st, b.V, h->cmap, b.act[0], N, h->S, h->Cd, ws ? b.tmax_act[0] : nullptr));
     for (int l = 1; l < h->Dd; ++l) {
@@ -458,10 +490,44 @@ int reduce_wgrad(iodine_handle* h, hipStream_t st, int nparts, int ci_pad, int c
 // (B*elbo).backward(), iodine.py:90,137).  Leaves d(pre-activation) of layer 0 in the returned buffer.
 // With train_alpha != 0 the decoder weight gradients of this pass are accumulated on the way with that factor
 // (= -w_i / B): they are what the outer loss.backward() (train.py:63) would compute for this decoder pass.
+// the same on the generic fallback path: plain chain of data gradients (and, in training, weight gradients with the pass factor);
+// the gradient wrt z is the pixel sum of the broadcast input's gradient, left in the first L entries of every row of buf.Rc
+// (dz_latent multiplies that by the identity in h->gen_ident)
+int decoder_backward_generic(iodine_handle* h, hipStream_t st, int N, float train_alpha)
+{
+    Buffers& b = h->buf;
+    const int Cd = h->Cd, Dd = h->Dd, L = h->L, S = h->S, k = h->kd;
+    auto G = [&](const std::string& name) { return h->gacc[param_index(h, name)]; };
+    int cur = 0;
+    PROF(h, st, "gen_conv", launch_gen_conv_dgrad(st, b.g, h->gen_wout, b.act[Dd - 1], b.dpre[cur], N, S, Cd, Cd, 4, k, 1));
+    if (train_alpha != 0.f)
+        PROF(h, st, "gen_conv", launch_gen_conv_wgrad(st, b.act[Dd - 1], b.g, b.gen_scr, N, S, Cd, Cd, Cd, 4, k, 1, train_alpha,
+                                                      G("decoder.conv.weight"), G("decoder.conv.bias")));
+    for (int l = Dd - 1; l >= 0; --l) {
+        const std::string base = "decoder.mlc.layers." + std::to_string(l);
+        const float* in = l == 0 ? b.bc : b.act[l - 1];
+        const int ci = l == 0 ? L + 2 : Cd;
+        if (train_alpha != 0.f)
+            PROF(h, st, "gen_conv", launch_gen_conv_wgrad(st, in, b.dpre[cur], b.gen_scr, N, S, ci, ci, ci, Cd, k, 1, train_alpha,
+                                                          G(base + ".weight"), G(base + ".bias")));
+        if (l > 0) {
+            PROF(h, st, "gen_conv", launch_gen_conv_dgrad(st, b.dpre[cur], h->gen_wdec[l], b.act[l - 1], b.dpre[cur ^ 1], N, S, Cd, Cd, Cd, k, 1));
+            cur ^= 1;
+        } else {
+            // only the L latent channels of the broadcast input carry a gradient that is needed
+            PROF(h, st, "gen_conv", launch_gen_conv_dgrad(st, b.dpre[cur], h->gen_wdec[0], nullptr, b.dbc, N, S, L, L + 2, Cd, k, 1));
+        }
+    }
+    HIPCHK(h, hipMemsetAsync(b.Rc, 0, sizeof(float) * (size_t)N * 9 * Cd, st));
+    HIPCHK(h, launch_gen_sum_pixels(st, b.dbc, N, h->P, L, L + 2, 9 * Cd, b.Rc));
+    return IODINE_OK;
+}
+
 int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0, float train_alpha, int it)
 {
     Buffers& b = h->buf;
     const int Cd = h->Cd, Dd = h->Dd;
+    if (h->generic) { *dpre0 = nullptr; return decoder_backward_generic(h, st, N, train_alpha); }
     int cur = 0, nparts = 0, ncop = 0, nb = 0, rc;
     bool fused_l0 = false;
     // training: one pass over the last hidden activation gives the data gradient AND the weight / bias gradient
@@ -565,7 +631,7 @@ int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps
     Buffers& b = h->buf;
     const int N = B * h->K;
     HIPCHK(h, launch_dec_v(st, b.pm, b.plv, eps_i, nullptr, h->wcls, b.z[i], b.V, N, h->L, h->Cd));
-    int rc = decoder_forward(h, st, N);
+    int rc = decoder_forward(h, st, N, b.z[i]);
     if (rc) return rc;
     PROF(h, st, "pixel_pass1", launch_pixel_pass1(st, b.x4, b.dec_out, b.g, b.part, B, h->K, h->P, (float)h->cfg.sigma));
     HIPCHK(h, launch_pixel_finalize(st, b.part, B, h->K, h->P, h->cfg.layernorm, b.lnstat, b.ll_img));
@@ -575,8 +641,8 @@ int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps
     float* dpre0 = nullptr;
     rc = decoder_backward_data(h, st, N, &dpre0, train_alpha, i);
     if (rc) return rc;
-    HIPCHK(h, launch_dz_latent(st, b.Rc, h->wclsT, b.pm, b.plv, eps_i, N, h->L, h->Cd, h->cfg.layernorm, b.g_pm[i],
-                               b.g_plv[i], b.latent[i]));
+    HIPCHK(h, launch_dz_latent(st, b.Rc, h->generic ? h->gen_ident : h->wclsT, b.pm, b.plv, eps_i, N, h->L, h->Cd, h->cfg.layernorm,
+                               b.g_pm[i], b.g_plv[i], b.latent[i]));
     return IODINE_OK;
 }
 
@@ -584,7 +650,7 @@ bool refine_split_on(const iodine_handle* h);
 
 bool refine_f16_ok(const iodine_handle* h)
 {
-    if (h->Cr != 64 && h->Cr != 32) return false;
+    if (h->generic || (h->Cr != 64 && h->Cr != 32)) return false;
     int s = h->S;
     for (int l = 0; l < h->Dr; ++l) { if (s % 2 != 0) return false; s /= 2; }
     return true;
@@ -605,7 +671,10 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
     int s = h->S;
     const float* in = b.enc[i];
     for (int l = 0; l < h->Dr; ++l) {
-        if (l == 0 && split) {
+        if (h->generic) {
+            PROF(h, st, "gen_conv", launch_gen_conv_fwd(st, in, h->gen_wref[l], h->ref_b[l], b.ract[i][l], N, s, l == 0 ? 17 : h->Cr,
+                                                        l == 0 ? 20 : h->Cr, h->Cr, h->kr, 2, 1));
+        } else if (l == 0 && split) {
             PROF(h, st, "refine_l0", launch_conv3x3_s2_f16x3(st, b.encs[i], h->ref_wsh16, h->ref_wshmeta, nullptr, b.rmap, B, s, 8,
                                                              h->Cr));
             PROF(h, st, "refine_l0", launch_conv3x3_s2_f16x3(st, b.enck[i], h->ref_wk16, h->ref_wkmeta, h->ref_b[0], b.ract[i][0], N,
@@ -713,6 +782,8 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     h->L = cfg->dim_latent; h->T = cfg->iters; h->K = cfg->slots; h->S = cfg->img_size; h->P = h->S * h->S;
     h->Cd = cfg->dec_conv_chan; h->Dd = cfg->dec_conv_layers; h->Cr = cfg->ref_conv_chan; h->Dr = cfg->ref_conv_layers;
     h->H = cfg->ref_mlp_units;
+    h->kd = cfg->dec_kernel_size; h->kr = cfg->ref_kernel_size;
+    h->generic = h->kd != 3 || h->kr != 3 || (h->Cd != 32 && h->Cd != 64) || (h->Cr != 32 && h->Cr != 64);
     {
         // image-shaped entries in CODE order (iodine.py:277-340) with their channel counts
         static const struct { unsigned bit; int first, count; } ent[10] = {
@@ -777,7 +848,14 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     }
     // split first layer: one 16-channel chunk each for the per-slot (12 real) and the per-image (8 real) channels
     ALLOC(h->ref_wk, (size_t)Cr * 12 * 9); ALLOC(h->ref_wsh, (size_t)Cr * 8 * 9); ALLOC(h->ref_g20, (size_t)Cr * 20 * 9);
-    ALLOC(h->ref_w17, (size_t)Cr * 17 * 9); ALLOC(h->ref_g17, (size_t)Cr * 17 * 9);
+    ALLOC(h->ref_w17, (size_t)Cr * 17 * h->kr * h->kr); ALLOC(h->ref_g17, (size_t)Cr * 17 * h->kr * h->kr);
+    if (h->generic) {
+        const int kkd = h->kd * h->kd, kkr = h->kr * h->kr;
+        h->gen_wdec.assign(h->Dd, nullptr); h->gen_wref.assign(h->Dr, nullptr);
+        for (int l = 0; l < h->Dd; ++l) ALLOC(h->gen_wdec[l], (size_t)kkd * (l == 0 ? L + 2 : Cd) * Cd);
+        for (int l = 0; l < h->Dr; ++l) ALLOC(h->gen_wref[l], (size_t)kkr * (l == 0 ? 17 : Cr) * Cr);
+        ALLOC(h->gen_wout, (size_t)kkd * Cd * 4); ALLOC(h->gen_b0, (size_t)Cd); ALLOC(h->gen_ident, (size_t)9 * Cd * L);
+    }
     ALLOC(h->ref_wk16, (size_t)9 * 2 * 2 * Cr * 4); ALLOC(h->ref_wsh16, (size_t)9 * 2 * 2 * Cr * 4);
     ALLOC(h->ref_wkmeta, (size_t)4); ALLOC(h->ref_wshmeta, (size_t)4);
     // gradient accumulators: ONE buffer, parameters back to back in named_parameters() order (the layout the wrapper's
@@ -842,6 +920,27 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         return hipSuccess;
     };
     const int L = h->L, Cd = h->Cd, Cr = h->Cr, H = h->H;
+    if (h->generic) {
+        // fallback path: [tap][ci][co] packs of every conv, plain bias copies, the head below as on the tuned path
+        for (int l = 0; l < h->Dd; ++l) {
+            const std::string base = "decoder.mlc.layers." + std::to_string(l);
+            HIPCHK(h, launch_gen_pack_weights(st, P(base + ".weight"), Cd, l == 0 ? L + 2 : Cd, h->kd, h->gen_wdec[l]));
+            HIPCHK(h, queue_copy(l == 0 ? h->gen_b0 : h->dec_b[l], P(base + ".bias"), Cd));
+        }
+        HIPCHK(h, launch_gen_pack_weights(st, P("decoder.conv.weight"), 4, Cd, h->kd, h->gen_wout));
+        HIPCHK(h, queue_copy(h->dec_out_b, P("decoder.conv.bias"), 4));
+        for (int l = 0; l < h->Dr; ++l) {
+            const std::string base = "refine.mlc.layers." + std::to_string(l);
+            const float* w = P(base + ".weight");
+            if (l == 0 && h->n_in < 17) {
+                HIPCHK(h, launch_enc_expand_weights(st, w, Cr, h->n_in, h->enc_map, h->ref_w17, h->kr * h->kr));
+                w = h->ref_w17;
+            }
+            HIPCHK(h, launch_gen_pack_weights(st, w, Cr, l == 0 ? 17 : Cr, h->kr, h->gen_wref[l]));
+            HIPCHK(h, queue_copy(h->ref_b[l], P(base + ".bias"), Cr));
+        }
+        HIPCHK(h, launch_gen_identity(st, h->gen_ident, 9 * Cd, L));
+    } else {
     // decoder
     HIPCHK(h, launch_dec_l0_prepare(st, P("decoder.mlc.layers.0.weight"), P("decoder.mlc.layers.0.bias"), h->lin, Cd, L,
                                     h->S, h->wcls, h->wclsT, h->cmap));
@@ -895,6 +994,7 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wk, Cr, 12, 16, Cr, 0, h->ref_wkmeta, h->ref_wk16));
         HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wsh, Cr, 8, 16, Cr, 0, h->ref_wshmeta, h->ref_wsh16));
     }
+    }   // !generic
     auto copy_raw = [&](float* dst, const std::string& name) {
         return queue_copy(dst, P(name), h->params[param_index(h, name)].numel());
     };
@@ -995,7 +1095,7 @@ int iodine_reconstruct(iodine_handle* h, void* stream, int batch, const float* x
             // buffer so that buf.dec_out keeps the outputs of the LAST elbo() call: the reference's self.mean / self.mask
             // and its logger entries are those (iodine.py:226-239), not the final decode.
             HIPCHK(h, launch_dec_v(st, b.pm, b.plv, eps + (size_t)T * eps_stride, nullptr, h->wcls, b.z[T], b.V, N, h->L, h->Cd));
-            const int r = decoder_forward(h, st, N, b.g);
+            const int r = decoder_forward(h, st, N, b.z[T], b.g);
             if (r) return r;
             HIPCHK(h, launch_final_out(st, b.g, pred, mask, mean, nullptr, B, h->K, h->P));
             if (z) HIPCHK(h, hipMemcpyAsync(z, b.z[T], sizeof(float) * eps_stride, hipMemcpyDeviceToDevice, st));
@@ -1025,7 +1125,7 @@ int iodine_decode(iodine_handle* h, void* stream, int batch, const float* z, flo
     auto body = [&]() -> int {
         Buffers& b = h->buf;
         HIPCHK(h, launch_dec_v(st, nullptr, nullptr, nullptr, z, h->wcls, nullptr, b.V, N, h->L, h->Cd));
-        const int r = decoder_forward(h, st, N, b.g);         // not buf.dec_out: that belongs to the last elbo() call
+        const int r = decoder_forward(h, st, N, z, b.g);      // not buf.dec_out: that belongs to the last elbo() call
         if (r) return r;
         HIPCHK(h, launch_final_out(st, b.g, pred, mask, mean, nullptr, batch, h->K, h->P));
         return IODINE_OK;
@@ -1228,8 +1328,11 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
             // 17-channel scratch that is gathered into the n_in-channel accumulator afterwards
             const bool gather0 = l == 0 && h->n_in < 17;
             float* gw_dst = gather0 ? h->ref_g17 : G(base + ".weight");
-            if (gather0) HIPCHK(h, hipMemsetAsync(h->ref_g17, 0, (size_t)Cr * 17 * 9 * sizeof(float), st));
-            if (l == 0 && h->fwd_split) {
+            if (gather0) HIPCHK(h, hipMemsetAsync(h->ref_g17, 0, (size_t)Cr * 17 * h->kr * h->kr * sizeof(float), st));
+            if (h->generic) {
+                PROF(h, st, "gen_conv", launch_gen_conv_wgrad(st, in, b.rdpre[l], b.gen_scr, NT, sz[l], ireal, cip, ireal, Cr, h->kr, 2, 1.f,
+                                                              gw_dst, G(base + ".bias")));
+            } else if (l == 0 && h->fwd_split) {
                 // split first layer: 12 per-slot + 8 per-image channels from two tensors, gradient in the internal channel
                 // order, then added to the reference layout
                 int nb = 0;
@@ -1252,9 +1355,12 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
                 PROF(h, st, "refine_bias_grad", launch_colsum_tall(st, b.rdpre[l], NT * sz[l + 1] * sz[l + 1], Cr, 1.f,
                                                                    G(base + ".bias"), b.wg_part_b, (size_t)512 * 64));
             }
-            if (gather0) HIPCHK(h, launch_enc_gather_grad(st, h->ref_g17, Cr, h->n_in, h->enc_map, G(base + ".weight")));
+            if (gather0) HIPCHK(h, launch_enc_gather_grad(st, h->ref_g17, Cr, h->n_in, h->enc_map, G(base + ".weight"), h->kr * h->kr));
             if (l > 0) {
-                if (h->precision == 1 && refine_f16_ok(h))
+                if (h->generic)
+                    PROF(h, st, "gen_conv", launch_gen_conv_dgrad(st, b.rdpre[l], h->gen_wref[l], b.ract[0][l - 1], b.rdpre[l - 1], NT, sz[l],
+                                                                  Cr, Cr, Cr, h->kr, 2));
+                else if (h->precision == 1 && refine_f16_ok(h))
                     PROF(h, st, "refine_dgrad", launch_conv3x3_s2_dgrad_f16x3(st, b.rdpre[l], h->ref_wb16[l], h->ref_wmeta[l] + 2,
                                                                               b.ract[0][l - 1], b.rdpre[l - 1], NT, sz[l], Cr));
                 else

@@ -674,39 +674,39 @@ __global__ void enc_join_kernel(const float* __restrict__ enck, const float* __r
 // pixel_pass2 writes there does not matter) and its gradient is GATHERED back ----------------------------------------------
 namespace {
 struct EncMap { int c[17]; };
-// w [O][n_in][9] -> w17 [O][17][9]
-__global__ void enc_expand_weights_kernel(const float* __restrict__ w, int O, int n_in, EncMap map, float* __restrict__ w17)
+// w [O][n_in][kk] -> w17 [O][17][kk]   (kk = taps: 9, or 25 / 49 on the generic path)
+__global__ void enc_expand_weights_kernel(const float* __restrict__ w, int O, int n_in, int kk, EncMap map, float* __restrict__ w17)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= O * 17 * 9) return;
-    const int t = idx % 9, c = (idx / 9) % 17, o = idx / 153;
+    if (idx >= O * 17 * kk) return;
+    const int t = idx % kk, c = (idx / kk) % 17, o = idx / (17 * kk);
     float v = 0.f;
-    for (int j = 0; j < n_in; ++j) if (map.c[j] == c) v = w[((size_t)o * n_in + j) * 9 + t];
+    for (int j = 0; j < n_in; ++j) if (map.c[j] == c) v = w[((size_t)o * n_in + j) * kk + t];
     w17[idx] = v;
 }
-// gw [O][n_in][9] += g17 [O][17][9] at the present channels
-__global__ void enc_gather_grad_kernel(const float* __restrict__ g17, int O, int n_in, EncMap map, float* __restrict__ gw)
+// gw [O][n_in][kk] += g17 [O][17][kk] at the present channels
+__global__ void enc_gather_grad_kernel(const float* __restrict__ g17, int O, int n_in, int kk, EncMap map, float* __restrict__ gw)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= O * n_in * 9) return;
-    const int t = idx % 9, j = (idx / 9) % n_in, o = idx / (9 * n_in);
-    gw[idx] += g17[((size_t)o * 17 + map.c[j]) * 9 + t];
+    if (idx >= O * n_in * kk) return;
+    const int t = idx % kk, j = (idx / kk) % n_in, o = idx / (kk * n_in);
+    gw[idx] += g17[((size_t)o * 17 + map.c[j]) * kk + t];
 }
 }  // namespace
 
-hipError_t launch_enc_expand_weights(hipStream_t st, const float* w, int O, int n_in, const int* map17, float* w17)
+hipError_t launch_enc_expand_weights(hipStream_t st, const float* w, int O, int n_in, const int* map17, float* w17, int kk)
 {
     EncMap m;
     for (int j = 0; j < 17; ++j) m.c[j] = j < n_in ? map17[j] : -1;
-    hipLaunchKernelGGL(enc_expand_weights_kernel, dim3((O * 153 + 255) / 256), dim3(256), 0, st, w, O, n_in, m, w17);
+    hipLaunchKernelGGL(enc_expand_weights_kernel, dim3((O * 17 * kk + 255) / 256), dim3(256), 0, st, w, O, n_in, kk, m, w17);
     return hipGetLastError();
 }
 
-hipError_t launch_enc_gather_grad(hipStream_t st, const float* g17, int O, int n_in, const int* map17, float* gw)
+hipError_t launch_enc_gather_grad(hipStream_t st, const float* g17, int O, int n_in, const int* map17, float* gw, int kk)
 {
     EncMap m;
     for (int j = 0; j < 17; ++j) m.c[j] = j < n_in ? map17[j] : -1;
-    hipLaunchKernelGGL(enc_gather_grad_kernel, dim3((O * n_in * 9 + 255) / 256), dim3(256), 0, st, g17, O, n_in, m, gw);
+    hipLaunchKernelGGL(enc_gather_grad_kernel, dim3((O * n_in * kk + 255) / 256), dim3(256), 0, st, g17, O, n_in, kk, m, gw);
     return hipGetLastError();
 }
 

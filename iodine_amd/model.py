@@ -633,14 +633,14 @@ class IODINE(nn.Module):
 
 
 def arch_namespace(dim_latent, iters, slots, img_size, ref, dec, sigma=0.10, layernorm=True,
-                   encoding=_lib.ENC_ORDER):
+                   encoding=_lib.ENC_ORDER, kernels=(3, 3)):
     """Build an ``ARCH``-shaped namespace (the yacs node of lib/config/defaults.py:35-100) from plain
-    values; ref = (CONV_CHAN, CONV_LAYERS, MLP_UNITS), dec = (CONV_CHAN, CONV_LAYERS)."""
+    values; ref = (CONV_CHAN, CONV_LAYERS, MLP_UNITS), dec = (CONV_CHAN, CONV_LAYERS), kernels = (REF, DEC) KERNEL_SIZE."""
     from types import SimpleNamespace as NS
     return NS(DIM_LATENT=dim_latent, ITERS=iters, SLOTS=slots, ENCODING=list(encoding), IMG_CHANNELS=3,
               IMG_SIZE=img_size, SIGMA=sigma, LAYERNORM=layernorm, STOP_GRADIENT=False,
-              REF=NS(CONV_CHAN=ref[0], CONV_LAYERS=ref[1], MLP_UNITS=ref[2], KERNEL_SIZE=3, STRIDE=2),
-              DEC=NS(CONV_CHAN=dec[0], CONV_LAYERS=dec[1], KERNEL_SIZE=3))
+              REF=NS(CONV_CHAN=ref[0], CONV_LAYERS=ref[1], MLP_UNITS=ref[2], KERNEL_SIZE=kernels[0], STRIDE=2),
+              DEC=NS(CONV_CHAN=dec[0], CONV_LAYERS=dec[1], KERNEL_SIZE=kernels[1]))
 
 
 def clevr6_arch(slots=7, iters=5):

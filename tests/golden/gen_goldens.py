@@ -49,22 +49,26 @@ CASES = {
     # the reference's DEFAULT ARCH.ENCODING (lib/config/defaults.py:57-80): no 'coordinate' -> 15 input channels (round 3)
     'tiny_default_enc': ('tiny', 3, 2, 2, 'uniform'),
     'cfg1_default_enc': ('dsprites', 4, 3, 2, 'blobs'),
+    # KERNEL_SIZE 5 (the reference's default DEC.KERNEL_SIZE, lib/config/defaults.py:100; configs/test.yaml:40,44 use 5 for both
+    # stacks) together with its default ENCODING: the generic fallback path of the library (round 3)
+    'tiny_k5': ('tiny', 3, 2, 2, 'uniform'),
 }
+CASE_KERNEL = {'tiny_k5': (5, 5)}          # (REF.KERNEL_SIZE, DEC.KERNEL_SIZE)
 # encoding list per case (default: the full 12-entry list of the shipped IODINE configs)
-CASE_ENCODING = {'tiny_default_enc': [e for e in ENCODING if e != 'coordinate'], 'cfg1_default_enc': [e for e in ENCODING if e != 'coordinate']}
+CASE_ENCODING = {c: [e for e in ENCODING if e != 'coordinate'] for c in ('tiny_default_enc', 'cfg1_default_enc', 'tiny_k5')}
 DEC_GAIN = 3.0
 POST_SCALE = 0.1
 SEED_W, SEED_X, SEED_E = 0, 0, 1
 
 
-def make_arch_ns(fam, K, T, encoding=None):
+def make_arch_ns(fam, K, T, encoding=None, kernels=(3, 3)):
     f = ARCHS[fam]
     return SimpleNamespace(
         DIM_LATENT=f['L'], ITERS=T, SLOTS=K, ENCODING=list(encoding or ENCODING), IMG_CHANNELS=3,
         IMG_SIZE=f['S'], SIGMA=0.10, LAYERNORM=True, STOP_GRADIENT=False,
         REF=SimpleNamespace(CONV_CHAN=f['ref'][0], CONV_LAYERS=f['ref'][1], MLP_UNITS=f['ref'][2],
-                            KERNEL_SIZE=3, STRIDE=2),
-        DEC=SimpleNamespace(CONV_CHAN=f['dec'][0], CONV_LAYERS=f['dec'][1], KERNEL_SIZE=3))
+                            KERNEL_SIZE=kernels[0], STRIDE=2),
+        DEC=SimpleNamespace(CONV_CHAN=f['dec'][0], CONV_LAYERS=f['dec'][1], KERNEL_SIZE=kernels[1]))
 
 
 class EpsReplay:
@@ -87,8 +91,8 @@ class EpsReplay:
         return e
 
 
-def build_reference(fam, K, T, dtype, encoding=None):
-    model = RefIODINE(make_arch_ns(fam, K, T, encoding))
+def build_reference(fam, K, T, dtype, encoding=None, kernels=(3, 3)):
+    model = RefIODINE(make_arch_ns(fam, K, T, encoding, kernels))
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     params = synth.make_params(shapes, seed=SEED_W, dec_gain=DEC_GAIN, posterior_scale=POST_SCALE)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
@@ -117,8 +121,10 @@ def run_case(case):
                meta_seeds=np.array([SEED_W, SEED_X, SEED_E]))
     if case in CASE_ENCODING:
         out['meta_encoding'] = ','.join(CASE_ENCODING[case])
+    if case in CASE_KERNEL:
+        out['meta_kernels'] = np.array(CASE_KERNEL[case])
     for tag, dtype in (('f32', torch.float32), ('f64', torch.float64)):
-        model, shapes = build_reference(fam, K, T, dtype, CASE_ENCODING.get(case))
+        model, shapes = build_reference(fam, K, T, dtype, CASE_ENCODING.get(case), CASE_KERNEL.get(case, (3, 3)))
         x = torch.from_numpy(imgs).to(dtype)
         e = torch.from_numpy(eps).to(dtype)
 

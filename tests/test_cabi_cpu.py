@@ -43,9 +43,13 @@ def test_create_rejects_unsupported_configs_with_message():
     cfg.encoding = 0x3                                                          # only the latent entries: no conv input at all
     assert L.iodine_create(C.byref(cfg), C.byref(h)) == 1 and b'image-shaped' in L.iodine_last_error(None)
     cfg.encoding = _lib.ENC_FULL
-    cfg.dec_kernel_size = 5                       # configs/test.yaml uses 5: rejected, not approximated
+    cfg.dec_kernel_size = 4                       # even kernel sizes do not exist in the reference (padding = KERNEL_SIZE // 2)
     assert L.iodine_create(C.byref(cfg), C.byref(h)) == 1
     assert b'KERNEL_SIZE' in L.iodine_last_error(None)
+    cfg.dec_kernel_size = 5
+    cfg.ref_conv_chan = 48                        # the refinement head pools in groups that divide 256
+    assert L.iodine_create(C.byref(cfg), C.byref(h)) == 1
+    assert b'REF.CONV_CHAN' in L.iodine_last_error(None)
 
 
 def test_linspace_matches_torch():

@@ -67,8 +67,10 @@ def test_unsupported_configurations_fail_loudly():
     IODINE(ok).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
     with pytest.raises((RuntimeError, ValueError)):                          # 13 slots: beyond the instantiated kernels
         IODINE(arch_namespace(8, 2, 13, 16, (32, 2, 32), (32, 2))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
-    with pytest.raises((RuntimeError, ValueError)):                          # channel counts other than 32 / 64
+    with pytest.raises((RuntimeError, ValueError)):                          # REF.CONV_CHAN must divide 256 (head pooling)
         IODINE(arch_namespace(8, 2, 3, 16, (48, 2, 32), (48, 2))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
+    with pytest.raises((RuntimeError, ValueError)):                          # even kernel size
+        IODINE(arch_namespace(8, 2, 3, 16, (32, 2, 32), (32, 2), kernels=(3, 4))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
     m = IODINE(ok).to(DEV)
     with pytest.raises((RuntimeError, ValueError)):                          # wrong image size for this ARCH
         m.reconstruct(torch.rand(1, 3, 32, 32, device=DEV))
@@ -135,3 +137,54 @@ def test_encoding_subset_in_the_middle_of_the_list():
     arch.encoding = tuple(e for e in O.FULL_ENCODING if e != 'posterior')
     with pytest.raises(RuntimeError, match='grad_post'):
         make_hip_model(arch, {k: torch.zeros(s) for k, s in O.param_shapes(arch).items()}).reconstruct(x.to(DEV), eps.to(DEV))
+
+
+# ---- the GENERIC fallback path (round 3): KERNEL_SIZE 5 / 7 and channel counts other than 32 / 64 ----------------------------
+def _step_vs_oracle(arch, params, x, eps, tol_grad=2e-3):
+    m = make_hip_model(arch, params)
+    xd, ed = x.to(DEV), eps.to(DEV)
+    m.zero_grad(set_to_none=True)
+    loss = m(xd, ed)
+    loss.backward()
+    out, rg = O.train_step_grads(x, eps, params, arch)
+    assert abs(loss.item() - float(out['loss'])) <= 1e-4 * abs(float(out['loss']))
+    assert rel_err(m.elbo_terms[:, 0].cpu(), out['elbos']) < 1e-4
+    bad = [(n, rel_l2(p.grad.cpu().numpy(), rg[n].numpy())) for n, p in m.named_parameters()
+           if n != 'decoder.conv.bias' and not rel_l2(p.grad.cpu().numpy(), rg[n].numpy()) < tol_grad]
+    assert not bad, bad
+    for n, p in m.named_parameters():
+        assert tuple(p.grad.shape) == tuple(params[n].shape), n
+    ref = O.reconstruct(x, eps, params, arch)
+    pred, mask, mean = m.reconstruct(xd, ed)
+    assert rel_err(m.elbo_terms[:, 0].cpu(), ref['elbos']) < 1e-4
+    assert rel_err(pred.cpu(), ref['pred']) < 2e-4 and rel_err(mask.cpu(), ref['mask']) < 2e-4
+    p2, k2, m2 = m.reconstruct(xd, ed)
+    assert torch.equal(p2, pred) and torch.equal(k2, mask)                  # deterministic (fixed-order sums)
+    return m
+
+
+def test_kernel_size_5_matches_the_reference_golden():
+    """KERNEL_SIZE 5 in both stacks + the default ENCODING: tests/golden/tiny_k5.npz comes from the unmodified reference"""
+    g = load_golden('tiny_k5')
+    arch, params, x, eps, _ = golden_setup(g)
+    assert (arch.ref_kernel, arch.dec_kernel) == (5, 5) and tuple(params['decoder.conv.weight'].shape) == (4, 32, 5, 5)
+    m = _step_vs_oracle(arch, params, x, eps)
+    m.zero_grad(set_to_none=True)
+    loss = m(x.to(DEV), eps.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - float(g['f32.train.loss'])) <= 1e-4 * abs(float(g['f32.train.loss']))
+    assert rel_err(m.elbo_terms[:, 0].cpu(), g['f32.train.elbos']) < 1e-4
+    for n, p in m.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), g['f64.train.grad.' + n]) < 2e-3 or n == 'decoder.conv.bias', n
+    pred, mask, mean = m.reconstruct(x.to(DEV), eps.to(DEV))
+    assert rel_err(pred.cpu(), g['f32.recon.pred']) < 2e-4 and rel_err(mean.cpu(), g['f32.recon.mean']) < 2e-4
+
+
+@pytest.mark.parametrize('what', ['dec5_ref3', 'k7', 'chan16', 'chan48_dec', 'chan128'])
+def test_generic_path_configurations(what):
+    """the reference's default kernel sizes (REF 3, DEC 5), KERNEL_SIZE 7, and channel counts the tuned kernels are not built for"""
+    kw = dict(dec5_ref3=dict(ref_kernel=3, dec_kernel=5), k7=dict(ref_kernel=7, dec_kernel=7), chan16=dict(ref_chan=16, dec_chan=16),
+              chan48_dec=dict(dec_chan=48), chan128=dict(ref_chan=128, dec_chan=128))[what]
+    arch = dataclasses.replace(O.tiny_arch(slots=3, iters=2, img_size=32 if what == 'dec5_ref3' else 16), **kw)
+    params, x, eps = _case(arch, 2, seed=11)
+    _step_vs_oracle(arch, params, x, eps)

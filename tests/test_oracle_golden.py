@@ -29,11 +29,11 @@ def test_param_shapes_match_reference_state_dict():
     assert sum(int(np.prod(s)) for s in O.param_shapes(O.dsprites_arch(slots=4, iters=3)).values()) == 240036
 
 
-@pytest.mark.parametrize('case', ['tiny', 'tiny_default_enc'])
+@pytest.mark.parametrize('case', ['tiny', 'tiny_default_enc', 'tiny_k5'])
 @pytest.mark.parametrize('tag,dtype,tol', [('f32', torch.float32, 2e-5), ('f64', torch.float64, 1e-11)])
 def test_tiny_full_tensors(tag, dtype, tol, case):
     """every tensor of a training step and of reconstruct; 'tiny_default_enc' = the reference's DEFAULT ARCH.ENCODING
-    (lib/config/defaults.py:57-80: no 'coordinate', 15 input channels)"""
+    (lib/config/defaults.py:57-80: no 'coordinate', 15 input channels); 'tiny_k5' = that with KERNEL_SIZE 5 in both stacks"""
     g = load_golden(case)
     arch, params, x, eps, _ = golden_setup(g, dtype)
     out, grads = O.train_step_grads(x, eps, params, arch)

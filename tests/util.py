@@ -28,6 +28,8 @@ def golden_setup(g, dtype=torch.float32):
     arch = FAMILIES[fam](K, T)
     if 'meta_encoding' in g.files:                      # cases generated with a non-default ARCH.ENCODING list
         arch.encoding = tuple(str(g['meta_encoding']).split(','))
+    if 'meta_kernels' in g.files:                       # (REF.KERNEL_SIZE, DEC.KERNEL_SIZE) other than 3
+        arch.ref_kernel, arch.dec_kernel = (int(v) for v in g['meta_kernels'])
     assert arch.img_size == S and arch.dim_latent == L
     shapes = O.param_shapes(arch)
     pn = synth.make_params(shapes, seed=sw, dec_gain=float(g['meta_dec_gain']),
@@ -60,7 +62,8 @@ def hip_arch(arch):
     from iodine_amd.model import arch_namespace
     return arch_namespace(arch.dim_latent, arch.iters, arch.slots, arch.img_size,
                           (arch.ref_chan, arch.ref_layers, arch.ref_mlp), (arch.dec_chan, arch.dec_layers),
-                          sigma=arch.sigma, layernorm=arch.layernorm, encoding=arch.encoding)
+                          sigma=arch.sigma, layernorm=arch.layernorm, encoding=arch.encoding,
+                          kernels=(arch.ref_kernel, arch.dec_kernel))
 
 
 def make_hip_model(arch, params, device='cuda:0'):
