@@ -186,7 +186,10 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * over the saved activation; 0 = two kernels, as iodine_reconstruct's data gradient + the GEMM-form weight gradient),
  * "refine_split" (1 -- default on the split-fp16 path: the first refinement layer is computed as a per-slot conv over the 11
  * encoding channels that differ between the slots of an image plus a per-image conv over the 6 they share; 0 = one conv
- * over the 20-float encoding per slot; a change takes effect with the next forward).
+ * over the 20-float encoding per slot; a change takes effect with the next forward),
+ * "head_fused" (1 -- default: the back-propagation through time of the refinement head runs as ONE launch, a block per 8 slots
+ * walking the T iterations; 0 = nine launches per iteration -- also the automatic fallback when MLP_UNITS is too large for the
+ * fused kernel's LDS footprint).
  * (The A/B-only selections of rounds 1-2 -- conv_variant 5, wgrad_ws, out_variant, out_dgrad_variant, zigzag -- were retired in
  * round 3; their kernels and measurements live under tools/experiments/ and DESIGN.md 4.3-4.5.) */
 int iodine_set_option(iodine_handle* h, const char* key, double value);

@@ -250,6 +250,10 @@ hipError_t launch_lstm_bwd_pointwise(hipStream_t st, const float* gates, const f
                                      float* dc0, int N, int H);
 hipError_t launch_mlp_bwd_pointwise(hipStream_t st, const float* du, int ldu, const float* s, float* ds, int N, int H);
 hipError_t launch_pool_bwd(hipStream_t st, const float* dpooled, const float* act, float* dpre, int N, int PL, int C);
+bool head_bptt_fits(int L, int H, int Cr);
+hipError_t launch_head_bptt(hipStream_t st, const float* g_pm, const float* g_plv, const float* gates, const float* cst, const float* u,
+                            const float* Wm, const float* Wv, const float* Whh, const float* Wih, const float* Wmlp, float* ddm,
+                            float* ddv, float* dgates, float* ds, float* dpooled, int T, int N, int B, int L, int H, int Cr);
 // split-precision (3 x fp16 MFMA) variant of the stride-1 tile conv
 hipError_t launch_pack_conv_weights_f16(hipStream_t st, const float* src, int O, int I, int cin, int cout, int tflip,
                                         float* meta, void* dst);

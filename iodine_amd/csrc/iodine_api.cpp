@@ -92,6 +92,7 @@ struct iodine_handle {
     int out_bwd_fused = 1;                      // training: output conv data + weight gradient in one pass over the activation
     int fuse_l0 = 1;                            // inference: layer-1 data gradient reduces straight to the layer-0 row sums
     int refine_split = 1;                       // first refinement layer split into a per-slot and a per-image part (split-fp16 path)
+    int head_fused = 1;                         // training backward: the head's BPTT recurrence as ONE launch (0 = 9 launches per iteration)
     bool fwd_split = false;                     // the form the saved training forward used
     int variant = 6;                            // split-fp16 stride-1 conv: 6 = weight-stationary persistent kernel (power-of-two image sizes;
                                                 // other sizes use 1), 1 = LDS-tiled 16x16 tiles (2 blocks/CU)
@@ -757,7 +758,7 @@ int run_graphed(iodine_handle* h, hipStream_t st, const std::vector<uintptr_t>& 
 std::vector<uintptr_t> graph_key(const iodine_handle* h, int entry, int batch, std::initializer_list<const void*> ptrs)
 {
     std::vector<uintptr_t> k = {(uintptr_t)entry, (uintptr_t)batch, (uintptr_t)h->stop_after, (uintptr_t)h->precision,
-                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split,
+                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)h->head_fused,
                                 (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
     for (const void* p : ptrs) k.push_back((uintptr_t)p);
     return k;
@@ -1051,6 +1052,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "out_bwd_fused")) { h->out_bwd_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "fuse_l0")) { h->fuse_l0 = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_split")) { h->refine_split = value != 0; return IODINE_OK; }
+    if (!strcmp(key, "head_fused")) { h->head_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {
         if (value != 1 && value != 6) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1 (LDS-tiled) or 6 (weight-stationary)");
         if (((int)value == 6) != (h->variant == 6)) h->params_set = false;   // the other kernel's weight packs are not kept up to date
@@ -1271,6 +1273,11 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
     Buffers& b = h->buf;
     const int B = h->fwd_batch, N = B * h->K, T = h->T, L = h->L, H = h->H, Cr = h->Cr, IN = H + 4 * L;
     auto G = [&](const std::string& name) { return h->gacc[param_index(h, name)]; };
+    if (h->head_fused && head_bptt_fits(L, H, Cr)) {
+        // the whole BPTT recurrence of the head in one launch (rows are independent: a block walks i = T-1 .. 0 for its rows)
+        PROF(h, st, "head_bwd", launch_head_bptt(st, b.g_pm[0], b.g_plv[0], b.gates[0], b.c[0], b.u[0], h->raw_wm, h->raw_wv, h->raw_whh,
+                                                 h->raw_wih, h->raw_mlp_w, b.ddm, b.ddv, b.dgates, b.ds, b.dpooled, T, N, B, L, H, Cr));
+    } else {
     int cf = 0;                                            // carry buffer flip
     for (int i = T - 1; i >= 0; --i) {
         // d loss / d delta_i = -w_{i+1}/B * d(B*ELBO_{i+1})/d lambda_{i+1}   (lambda_{i+1} = detach(lambda_i) + delta_i)
@@ -1292,6 +1299,7 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
         HIPCHK(h, launch_sgemm(st, 0, 0, N, H, 4 * H, 1.f, dgates, 4 * H, h->raw_wih, IN, 0.f, b.dxin, H));
         HIPCHK(h, launch_mlp_bwd_pointwise(st, b.dxin, H, b.u[i], ds, N, H));
         HIPCHK(h, launch_sgemm(st, 0, 0, N, Cr, H, 1.f, ds, H, h->raw_mlp_w, Cr, 0.f, b.dpooled + (size_t)i * N * Cr, Cr));
+    }
     }
     {
         // Weight gradients of the head: sums over the iterations of X_i^T D_i = ONE GEMM per parameter over all T * N rows

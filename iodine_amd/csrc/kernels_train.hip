@@ -768,6 +768,197 @@ hipError_t launch_mlp_bwd_pointwise(hipStream_t st, const float* du, int ldu, co
     return hipGetLastError();
 }
 
+// =========================================================================================
+// Back-propagation through time of the refinement HEAD (read-out layers, LSTM cell, double-ELU MLP, average pool) for all T
+// iterations in ONE launch.  Every row (slot) of the head is independent of the others - only the weight gradients sum over
+// rows, and those stay separate GEMMs over all T * N rows - so a block takes HB rows and walks i = T-1 .. 0 itself:
+//   ddm, ddv = alpha_i * d(B ELBO_{i+1}) / d lambda_{i+1}          (lambda_{i+1} = detach(lambda_i) + delta_i, iodine.py:642-643)
+//   dc1  = ddm . Wm + ddv . Wv                                      (read-out from the CELL state, iodine.py:488-492)
+//   dgates, dc0 = LSTM cell backward (+ the carries dh, dc of iteration i + 1)
+//   dh0  = dgates . Whh        (carry)         dxin = dgates . Wih[:, :H]
+//   ds   = dxin * ELU'(ELU(s)) * ELU'(s)       dpooled = ds . Wmlp
+// It replaces 9 launches per iteration (2 scale, 4 + 1 SGEMM, 2 pointwise: 45 launches, ~0.45 ms per cfg3 step - each of them
+// tens of microseconds of latency for a few MFLOP) by one.  The row vectors sit in LDS, a weight element is read once per block and used
+// for all HB rows; the k loop is latency-bound, so 1024 threads split it four ways with eight loads in flight each (head_matvec).
+// =========================================================================================
+constexpr int HB = 4;      // rows per block
+constexpr int HKG = 4;     // k groups: 1024 threads = HKG x 256 column threads (a latency-bound loop: loads in flight are what counts)
+
+// vout[w][r][j] = sum_k vin[r][k] * W[w][k * ldw[w] + j]   for r < HB, j < J; vin / vout / s_part in LDS.  Thread (kg, jj) sums the
+// k range of group kg for the columns jj, jj + 256, ... in ascending k; the HKG partial sums are added in group order (deterministic).
+template <int NW>
+IOD_DEVINL void head_matvec(const float* const (&W)[NW], const int (&ldw)[NW], int K, int J, const float* __restrict__ vin, int ldv,
+                            float* const (&vout)[NW], int ldo, float* __restrict__ s_part)
+{
+    const int jj = threadIdx.x & 255, kg = threadIdx.x >> 8;
+    const int kq = (K + HKG - 1) / HKG, k0 = kg * kq, k1 = min(K, k0 + kq);
+    for (int jb = 0; jb < J; jb += 256) {
+        const int j = jb + jj;
+        float acc[NW][HB];
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int r = 0; r < HB; ++r) acc[w][r] = 0.f;
+        if (j < J) {
+            int k = k0;
+            for (; k + 7 < k1; k += 8) {
+                float wv[NW][8];
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) wv[w][u] = W[w][(size_t)(k + u) * ldw[w] + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int r = 0; r < HB; ++r) {
+                        const float x = vin[r * ldv + k + u];
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) acc[w][r] = fmaf(x, wv[w][u], acc[w][r]);
+                    }
+            }
+            for (; k < k1; ++k)
+#pragma unroll
+                for (int r = 0; r < HB; ++r) {
+                    const float x = vin[r * ldv + k];
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) acc[w][r] = fmaf(x, W[w][(size_t)k * ldw[w] + j], acc[w][r]);
+                }
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int r = 0; r < HB; ++r) s_part[((kg * NW + w) * HB + r) * 256 + jj] = acc[w][r];
+        }
+        __syncthreads();
+        // fixed-order sum over the k groups: thread (kg, jj) finishes (w, r) pairs kg, kg + HKG, ...
+        if (j < J) {
+            for (int q = kg; q < NW * HB; q += HKG) {
+                const int w = q / HB, r = q % HB;
+                float sum = s_part[((0 * NW + w) * HB + r) * 256 + jj];
+#pragma unroll
+                for (int g = 1; g < HKG; ++g) sum += s_part[((g * NW + w) * HB + r) * 256 + jj];
+                vout[w][r * ldo + j] = sum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024)
+void head_bptt_kernel(const float* __restrict__ g_pm, const float* __restrict__ g_plv, const float* __restrict__ gates,
+                      const float* __restrict__ cst, const float* __restrict__ u, const float* __restrict__ Wm,
+                      const float* __restrict__ Wv, const float* __restrict__ Whh, const float* __restrict__ Wih,
+                      const float* __restrict__ Wmlp, float* __restrict__ ddm_o, float* __restrict__ ddv_o,
+                      float* __restrict__ dgates_o, float* __restrict__ ds_o, float* __restrict__ dpooled_o, int T, int N, int B,
+                      int L, int H, int Cr)
+{
+    extern __shared__ float s_hb[];
+    float* s_dd = s_hb;                              // [HB][2L]   ddm | ddv
+    float* s_dc1 = s_dd + HB * 2 * L;                // [HB][H]    (two halves summed: see below)
+    float* s_dc1b = s_dc1 + HB * H;                  // [HB][H]
+    float* s_dg = s_dc1b + HB * H;                   // [HB][4H]
+    float* s_dh = s_dg + HB * 4 * H;                 // [HB][H]    carry dh (from iteration i + 1)
+    float* s_dcc = s_dh + HB * H;                    // [HB][H]    carry dc
+    float* s_dx = s_dcc + HB * H;                    // [HB][H]    dxin, then ds
+    float* s_dhn = s_dx + HB * H;                    // [HB][H]    new carry dh
+    float* s_part = s_dhn + HB * H;                  // [HKG][2][HB][256] partial sums of head_matvec
+    const int tid = threadIdx.x, n0 = blockIdx.x * HB;
+    const int IN = H + 4 * L;
+    for (int idx = tid; idx < HB * H; idx += 1024) { s_dh[idx] = 0.f; s_dcc[idx] = 0.f; }
+    __syncthreads();
+    for (int i = T - 1; i >= 0; --i) {
+        const float alpha = -((float)(i + 2) / (float)(T + 1)) / (float)B;
+        // 1. scaled posterior gradients of iteration i + 1
+        for (int idx = tid; idx < HB * L; idx += 1024) {
+            const int r = idx / L, l = idx % L, n = min(n0 + r, N - 1);
+            const float a = alpha * g_pm[((size_t)(i + 1) * N + n) * L + l], b = alpha * g_plv[((size_t)(i + 1) * N + n) * L + l];
+            s_dd[r * 2 * L + l] = a; s_dd[r * 2 * L + L + l] = b;
+            if (n0 + r < N) { ddm_o[((size_t)i * N + n) * L + l] = a; ddv_o[((size_t)i * N + n) * L + l] = b; }
+        }
+        __syncthreads();
+        // 2. read-out layers: dc1 = ddm . Wm (+) ddv . Wv, the two products summed in that order like the two SGEMM calls it replaces
+        {
+            const float* const W0[1] = {Wm}; const float* const W1[1] = {Wv};
+            const int ld0[1] = {H};
+            float* const o0[1] = {s_dc1}; float* const o1[1] = {s_dc1b};
+            head_matvec<1>(W0, ld0, L, H, s_dd, 2 * L, o0, H, s_part);
+            head_matvec<1>(W1, ld0, L, H, s_dd + L, 2 * L, o1, H, s_part);
+        }
+        __syncthreads();
+        // 3. LSTM cell backward (pointwise)
+        for (int idx = tid; idx < HB * H; idx += 1024) {
+            const int r = idx / H, j = idx % H, n = min(n0 + r, N - 1);
+            const float* g = gates + ((size_t)i * N + n) * 4 * H;
+            const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
+            const float c0v = cst[((size_t)i * N + n) * H + j], tc = tanhf(cst[((size_t)(i + 1) * N + n) * H + j]);
+            const float dh = s_dh[idx];
+            float dc = (s_dc1[idx] + s_dc1b[idx]) + s_dcc[idx];
+            dc += dh * go * (1.f - tc * tc);
+            const float d0 = dc * gg * gi * (1.f - gi), d1 = dc * c0v * gf * (1.f - gf), d2 = dc * gi * (1.f - gg * gg),
+                        d3 = dh * tc * go * (1.f - go);
+            float* sg = s_dg + r * 4 * H;
+            sg[j] = d0; sg[H + j] = d1; sg[2 * H + j] = d2; sg[3 * H + j] = d3;
+            if (n0 + r < N) {
+                float* og = dgates_o + ((size_t)i * N + n) * 4 * H;
+                og[j] = d0; og[H + j] = d1; og[2 * H + j] = d2; og[3 * H + j] = d3;
+            }
+            s_dcc[idx] = dc * gf;                                           // carry dc for iteration i - 1 (own element: no hazard)
+        }
+        __syncthreads();
+        // 4. + 5. dh0 = dgates . Whh (carry), dxin = dgates . Wih[:, :H]: one pass over k for both
+        {
+            const float* const W[2] = {Whh, Wih};
+            const int ld[2] = {H, IN};
+            float* const out[2] = {s_dhn, s_dx};
+            head_matvec<2>(W, ld, 4 * H, H, s_dg, 4 * H, out, H, s_part);
+        }
+        __syncthreads();
+        // 6. double-ELU MLP backward (pointwise); the new dh carry moves into place
+        for (int idx = tid; idx < HB * H; idx += 1024) {
+            const int r = idx / H, j = idx % H, n = min(n0 + r, N - 1);
+            const float sv = u[((size_t)i * N + n) * H + j];
+            const float y = elu1(sv);
+            const float g1 = sv > 0.f ? 1.f : y + 1.f, g2 = y > 0.f ? 1.f : expf(y);
+            const float d = s_dx[idx] * g1 * g2;
+            s_dx[idx] = d;
+            if (n0 + r < N) ds_o[((size_t)i * N + n) * H + j] = d;
+            s_dh[idx] = s_dhn[idx];
+        }
+        __syncthreads();
+        // 7. average-pool input gradient: dpooled = ds . Wmlp  (written straight to global: s_dc1 is free, used as staging)
+        {
+            const float* const W[1] = {Wmlp};
+            const int ld[1] = {Cr};
+            float* const out[1] = {s_dc1};
+            head_matvec<1>(W, ld, H, Cr, s_dx, H, out, H, s_part);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < HB * Cr; idx += 1024) {
+            const int r = idx / Cr, c = idx % Cr;
+            if (n0 + r < N) dpooled_o[((size_t)i * N + n0 + r) * Cr + c] = s_dc1[r * H + c];
+        }
+        __syncthreads();
+    }
+}
+
+// does the fused kernel's LDS footprint fit (it does for every shipped configuration; MLP_UNITS >= 512 falls back to the launch sequence)
+static size_t head_bptt_lds(int L, int H) { return ((size_t)HB * (2 * L + 10 * H) + (size_t)HKG * 2 * HB * 256) * sizeof(float); }
+bool head_bptt_fits(int L, int H, int Cr) { return Cr <= H && head_bptt_lds(L, H) <= 160 * 1024; }
+
+hipError_t launch_head_bptt(hipStream_t st, const float* g_pm, const float* g_plv, const float* gates, const float* cst, const float* u,
+                            const float* Wm, const float* Wv, const float* Whh, const float* Wih, const float* Wmlp, float* ddm,
+                            float* ddv, float* dgates, float* ds, float* dpooled, int T, int N, int B, int L, int H, int Cr)
+{
+    IOD_XSKIP(2);
+    if (Cr > H) return hipErrorInvalidValue;                                // (the pool gradient is staged in an [HB][H] buffer)
+    const size_t lds = head_bptt_lds(L, H);
+    static std::atomic<unsigned> attr_devs{0};
+    if (hipError_t e = iod_set_max_lds((const void*)head_bptt_kernel, 160 * 1024, attr_devs); e != hipSuccess) return e;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(head_bptt_kernel, dim3((N + HB - 1) / HB), dim3(256 * HKG), lds, st, g_pm, g_plv, gates, cst, u, Wm, Wv, Whh, Wih, Wmlp,
+                       ddm, ddv, dgates, ds, dpooled, T, N, B, L, H, Cr);
+    return hipGetLastError();
+}
+
 // avg-pool backward fused with the ELU derivative of the last refinement conv layer
 __global__ void pool_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ act, float* __restrict__ dpre,
                                 int PL, int C, size_t total)
