@@ -6,6 +6,10 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd $REPO
+# PMC passes FIRST: bench.py quotes roofline.traffic / roofline_hbm.traffic from profiles/<tag>_pmc.json only while its source digest
+# matches the tree, so the record of THIS tree has to be in place before the bench lines are taken
+bash tools/pmc_traffic.sh $TAG > $OUT/${TAG}_pmc.log 2>&1
+cp $OUT/${TAG}_pmc.json $REPO/profiles/${TAG}_pmc.json
 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
 python bench.py --mode infer --no-exact-fp32 --no-sustain > $OUT/${TAG}_bench_infer.json 2> /dev/null
 for g in 0 1; do
@@ -21,5 +25,4 @@ done
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_ds -- python $REPO/bench.py --config dsprites --steps 10 --warmup 2 --no-cpu-baseline --no-exact-fp32 --no-extra-configs --no-sustain > $OUT/${TAG}_prof_ds.log 2>&1
 python $REPO/tools/rocpd_summary.py $(ls $OUT/${TAG}_prof_ds/*/*.db | head -1) > $OUT/${TAG}_dsprites_train_kernel_stats.md
 cd $REPO
-bash tools/pmc_traffic.sh $TAG > $OUT/${TAG}_pmc.log 2>&1      # mandatory: roofline.traffic / roofline_hbm.traffic come from it
 ls $OUT | grep $TAG
