@@ -188,3 +188,14 @@ def test_generic_path_configurations(what):
     arch = dataclasses.replace(O.tiny_arch(slots=3, iters=2, img_size=32 if what == 'dec5_ref3' else 16), **kw)
     params, x, eps = _case(arch, 2, seed=11)
     _step_vs_oracle(arch, params, x, eps)
+
+
+def test_reference_default_arch():
+    """lib/config/defaults.py:35-100 verbatim - ITERS 5, SLOTS 7, SIGMA 0.13, DIM_LATENT 128, IMG_SIZE 32, REF 32 x 3 (k 3, stride 2),
+    MLP 256, DEC 64 x 5 with KERNEL_SIZE 5, ENCODING without 'coordinate': the configuration a user of the reference gets without a
+    yaml file constructs and runs (generic path for the decoder's 5 x 5 kernels), against the oracle"""
+    arch = O.Arch(dim_latent=128, iters=5, slots=7, sigma=0.13, img_size=32, ref_chan=32, ref_layers=3, ref_mlp=256, ref_kernel=3,
+                  dec_chan=64, dec_layers=5, dec_kernel=5, encoding=O.DEFAULT_ENCODING)
+    params, x, eps = _case(arch, 2, seed=21)
+    m = _step_vs_oracle(arch, params, x, eps)
+    assert m.get_input_size() == (15, 512) and tuple(m.decoder.conv.weight.shape) == (4, 64, 5, 5)
