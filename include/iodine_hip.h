@@ -56,7 +56,7 @@ typedef struct iodine_config {
     int dim_latent;        /* ARCH.DIM_LATENT  */
     int iters;             /* ARCH.ITERS       */
     int slots;             /* ARCH.SLOTS       */
-    int img_size;          /* ARCH.IMG_SIZE    (multiple of 16) */
+    int img_size;          /* ARCH.IMG_SIZE    (multiples of 16: tuned kernels; other sizes >= 8: generic fallback path) */
     int img_channels;      /* ARCH.IMG_CHANNELS (3) */
     double sigma;          /* ARCH.SIGMA       */
     int layernorm;         /* ARCH.LAYERNORM   */

@@ -264,7 +264,7 @@ std::string validate(const iodine_config& c)
     for (int k : {c.dec_kernel_size, c.ref_kernel_size})
         if (k != 3 && k != 5 && k != 7) return "KERNEL_SIZE must be 3, 5 or 7 (odd: the reference pads with KERNEL_SIZE // 2, iodine.py:419,580)";
     if (c.ref_stride != 2) return "only REF.STRIDE 2 is implemented";
-    if (c.img_size < 16 || c.img_size % 16 != 0) return "ARCH.IMG_SIZE must be a positive multiple of 16";
+    if (c.img_size < 8 || c.img_size > 1024) return "ARCH.IMG_SIZE must be in 8..1024 (multiples of 16 run on the tuned kernels, other sizes on the generic path)";
     if (c.dec_conv_chan < 8 || c.dec_conv_chan > 256 || c.dec_conv_chan % 4 != 0) return "DEC.CONV_CHAN must be a multiple of 4 in 8..256";
     if (c.ref_conv_chan < 4 || c.ref_conv_chan > 256 || 256 % c.ref_conv_chan != 0) return "REF.CONV_CHAN must divide 256 (4 ... 256)";
     if (9 * c.dec_conv_chan < c.dim_latent) return "DIM_LATENT must not exceed 9 * DEC.CONV_CHAN";
@@ -784,7 +784,7 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     h->Cd = cfg->dec_conv_chan; h->Dd = cfg->dec_conv_layers; h->Cr = cfg->ref_conv_chan; h->Dr = cfg->ref_conv_layers;
     h->H = cfg->ref_mlp_units;
     h->kd = cfg->dec_kernel_size; h->kr = cfg->ref_kernel_size;
-    h->generic = h->kd != 3 || h->kr != 3 || (h->Cd != 32 && h->Cd != 64) || (h->Cr != 32 && h->Cr != 64);
+    h->generic = h->kd != 3 || h->kr != 3 || (h->Cd != 32 && h->Cd != 64) || (h->Cr != 32 && h->Cr != 64) || h->S % 16 != 0;
     {
         // image-shaped entries in CODE order (iodine.py:277-340) with their channel counts
         static const struct { unsigned bit; int first, count; } ent[10] = {
