@@ -25,12 +25,14 @@ from oracle import iodine_oracle as O  # noqa: E402
 RUNS = {   # name: (family, K, T, B, steps, checkpoints, lr)
     'teacher_tiny': ('tiny', 3, 2, 4, 100, (10, 30, 60, 100), 2e-3),
     'teacher_cfg1': ('dsprites', 4, 3, 4, 40, (20, 40), 1e-3),
+    # the headline architecture (CLEVR6: 128 x 128, 64 channels, K = 7, T = 5), one image: a dozen steps are what the CPU affords
+    'teacher_cfg3': ('clevr', 7, 5, 1, 12, (12,), 1e-3),
 }
 SEED_W, SEED_X, SEED_E = 11, 12, 1000
 
 
 def run(name, fam, K, T, B, steps, ckpts, lr):
-    arch = {'tiny': O.tiny_arch, 'dsprites': O.dsprites_arch}[fam](slots=K, iters=T)
+    arch = {'tiny': O.tiny_arch, 'dsprites': O.dsprites_arch, 'clevr': O.clevr_arch}[fam](slots=K, iters=T)
     pn = synth.make_params(O.param_shapes(arch), seed=SEED_W)
     params = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in pn.items()}
     imgs, _ = synth.make_images(B, arch.img_size, seed=SEED_X, kind='blobs')
@@ -59,4 +61,6 @@ def run(name, fam, K, T, B, steps, ckpts, lr):
 if __name__ == '__main__':
     torch.set_num_threads(8)
     for name, cfg in RUNS.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         run(name, *cfg)

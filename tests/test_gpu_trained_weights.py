@@ -14,14 +14,15 @@ from util import load_golden, make_hip_model, rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-CASES = [('teacher_tiny', c, k) for c in (10, 30, 60, 100) for k in (1.0, 8.0)] + [('teacher_cfg1', c, k) for c in (20, 40) for k in (1.0, 8.0)]
+CASES = ([('teacher_tiny', c, k) for c in (10, 30, 60, 100) for k in (1.0, 8.0)] + [('teacher_cfg1', c, k) for c in (20, 40) for k in (1.0, 8.0)]
+         + [('teacher_cfg3', 12, k) for k in (1.0, 8.0)])       # the headline architecture: 128 x 128, 64 channels, K = 7, T = 5
 
 
 @pytest.mark.parametrize('name,ckpt,sharpen', CASES)
 def test_training_step_on_trained_weights(name, ckpt, sharpen):
     t = load_golden(name)
     fam, K, T, B = str(t['meta_family']), int(t['meta_K']), int(t['meta_T']), int(t['meta_B'])
-    arch = {'tiny': O.tiny_arch, 'dsprites': O.dsprites_arch}[fam](slots=K, iters=T)
+    arch = {'tiny': O.tiny_arch, 'dsprites': O.dsprites_arch, 'clevr': O.clevr_arch}[fam](slots=K, iters=T)
     sw, sx, se = (int(v) for v in t['meta_seeds'])
     params = {k: torch.from_numpy(t[f'ckpt{ckpt}.param.{k}']).clone() for k in O.param_shapes(arch)}
     if sharpen != 1.0:
