@@ -779,41 +779,42 @@ hipError_t launch_mlp_bwd_pointwise(hipStream_t st, const float* du, int ldu, co
 //   ds   = dxin * ELU'(ELU(s)) * ELU'(s)       dpooled = ds . Wmlp
 // It replaces 9 launches per iteration (2 scale, 4 + 1 SGEMM, 2 pointwise: 45 launches, ~0.45 ms per cfg3 step - each of them
 // tens of microseconds of latency for a few MFLOP) by one.  The row vectors sit in LDS, a weight element is read once per block and used
-// for all HB rows; the k loop is latency-bound, so 1024 threads split it four ways with eight loads in flight each (head_matvec).
+// for all HB rows; the k loop is bound by that L2 stream, so the sixteen waves of a block split it and load 16 bytes per lane (head_matvec).
 // =========================================================================================
-constexpr int HB = 4;      // rows per block
-constexpr int HKG = 4;     // k groups: 1024 threads = HKG x 256 column threads (a latency-bound loop: loads in flight are what counts)
+constexpr int HB = 2;      // rows per block
+constexpr int HKG = 16;    // k groups = waves of the 1024-thread block; a lane owns four adjacent output columns (16-byte weight loads)
 
-// vout[w][r][j] = sum_k vin[r][k] * W[w][k * ldw[w] + j]   for r < HB, j < J; vin / vout / s_part in LDS.  Thread (kg, jj) sums the
-// k range of group kg for the columns jj, jj + 256, ... in ascending k; the HKG partial sums are added in group order (deterministic).
+// vout[w][r][j] = sum_k vin[r][k] * W[w][k * ldw[w] + j]   for r < HB, j < J (J, ldw multiples of 4); vin / vout / s_part in LDS.
+// The loop streams the weights once per block from L2 and is bound by that stream: wave g sums the k range of group g for the
+// column quads lane, lane + 64, ... in ascending k with eight 16-byte loads in flight; the HKG partial sums are added in group order.
 template <int NW>
 IOD_DEVINL void head_matvec(const float* const (&W)[NW], const int (&ldw)[NW], int K, int J, const float* __restrict__ vin, int ldv,
                             float* const (&vout)[NW], int ldo, float* __restrict__ s_part)
 {
-    const int jj = threadIdx.x & 255, kg = threadIdx.x >> 8;
+    const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
     const int kq = (K + HKG - 1) / HKG, k0 = kg * kq, k1 = min(K, k0 + kq);
     for (int jb = 0; jb < J; jb += 256) {
-        const int j = jb + jj;
-        float acc[NW][HB];
+        const int j = jb + 4 * lane;
+        f32x4 acc[NW][HB];
 #pragma unroll
         for (int w = 0; w < NW; ++w)
 #pragma unroll
-            for (int r = 0; r < HB; ++r) acc[w][r] = 0.f;
+            for (int r = 0; r < HB; ++r) acc[w][r] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (j < J) {
             int k = k0;
             for (; k + 7 < k1; k += 8) {
-                float wv[NW][8];
+                f32x4 wv[NW][8];
 #pragma unroll
                 for (int w = 0; w < NW; ++w)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) wv[w][u] = W[w][(size_t)(k + u) * ldw[w] + j];
+                    for (int u = 0; u < 8; ++u) wv[w][u] = *reinterpret_cast<const f32x4*>(W[w] + (size_t)(k + u) * ldw[w] + j);
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
 #pragma unroll
                     for (int r = 0; r < HB; ++r) {
                         const float x = vin[r * ldv + k + u];
 #pragma unroll
-                        for (int w = 0; w < NW; ++w) acc[w][r] = fmaf(x, wv[w][u], acc[w][r]);
+                        for (int w = 0; w < NW; ++w) acc[w][r] += x * wv[w][u];
                     }
             }
             for (; k < k1; ++k)
@@ -821,23 +822,22 @@ IOD_DEVINL void head_matvec(const float* const (&W)[NW], const int (&ldw)[NW], i
                 for (int r = 0; r < HB; ++r) {
                     const float x = vin[r * ldv + k];
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) acc[w][r] = fmaf(x, W[w][(size_t)k * ldw[w] + j], acc[w][r]);
+                    for (int w = 0; w < NW; ++w) acc[w][r] += x * *reinterpret_cast<const f32x4*>(W[w] + (size_t)k * ldw[w] + j);
                 }
 #pragma unroll
             for (int w = 0; w < NW; ++w)
 #pragma unroll
-                for (int r = 0; r < HB; ++r) s_part[((kg * NW + w) * HB + r) * 256 + jj] = acc[w][r];
+                for (int r = 0; r < HB; ++r) *reinterpret_cast<f32x4*>(s_part + ((kg * NW + w) * HB + r) * 256 + 4 * lane) = acc[w][r];
         }
         __syncthreads();
-        // fixed-order sum over the k groups: thread (kg, jj) finishes (w, r) pairs kg, kg + HKG, ...
-        if (j < J) {
-            for (int q = kg; q < NW * HB; q += HKG) {
-                const int w = q / HB, r = q % HB;
-                float sum = s_part[((0 * NW + w) * HB + r) * 256 + jj];
+        // fixed-order sum over the k groups
+        const int ncol = min(256, J - jb);
+        for (int o = threadIdx.x; o < NW * HB * ncol; o += blockDim.x) {
+            const int c = o % ncol, wr = o / ncol;
+            float sum = s_part[(0 * NW * HB + wr) * 256 + c];
 #pragma unroll
-                for (int g = 1; g < HKG; ++g) sum += s_part[((g * NW + w) * HB + r) * 256 + jj];
-                vout[w][r * ldo + j] = sum;
-            }
+            for (int g = 1; g < HKG; ++g) sum += s_part[(g * NW * HB + wr) * 256 + c];
+            vout[wr / HB][(wr % HB) * ldo + jb + c] = sum;
         }
         __syncthreads();
     }
@@ -851,7 +851,7 @@ void head_bptt_kernel(const float* __restrict__ g_pm, const float* __restrict__ 
                       float* __restrict__ dgates_o, float* __restrict__ ds_o, float* __restrict__ dpooled_o, int T, int N, int B,
                       int L, int H, int Cr)
 {
-    extern __shared__ float s_hb[];
+    extern __shared__ __attribute__((aligned(16))) float s_hb[];
     float* s_dd = s_hb;                              // [HB][2L]   ddm | ddv
     float* s_dc1 = s_dd + HB * 2 * L;                // [HB][H]    (two halves summed: see below)
     float* s_dc1b = s_dc1 + HB * H;                  // [HB][H]
@@ -860,7 +860,7 @@ void head_bptt_kernel(const float* __restrict__ g_pm, const float* __restrict__ 
     float* s_dcc = s_dh + HB * H;                    // [HB][H]    carry dc
     float* s_dx = s_dcc + HB * H;                    // [HB][H]    dxin, then ds
     float* s_dhn = s_dx + HB * H;                    // [HB][H]    new carry dh
-    float* s_part = s_dhn + HB * H;                  // [HKG][2][HB][256] partial sums of head_matvec
+    float* s_part = s_dhn + HB * H;                  // [HKG][2][HB][256] partial sums of head_matvec (16-byte aligned: all sizes are multiples of 4)
     const int tid = threadIdx.x, n0 = blockIdx.x * HB;
     const int IN = H + 4 * L;
     for (int idx = tid; idx < HB * H; idx += 1024) { s_dh[idx] = 0.f; s_dcc[idx] = 0.f; }
@@ -954,7 +954,7 @@ hipError_t launch_head_bptt(hipStream_t st, const float* g_pm, const float* g_pl
     static std::atomic<unsigned> attr_devs{0};
     if (hipError_t e = iod_set_max_lds((const void*)head_bptt_kernel, 160 * 1024, attr_devs); e != hipSuccess) return e;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(head_bptt_kernel, dim3((N + HB - 1) / HB), dim3(256 * HKG), lds, st, g_pm, g_plv, gates, cst, u, Wm, Wv, Whh, Wih, Wmlp,
+    hipLaunchKernelGGL(head_bptt_kernel, dim3((N + HB - 1) / HB), dim3(64 * HKG), lds, st, g_pm, g_plv, gates, cst, u, Wm, Wv, Whh, Wih, Wmlp,
                        ddm, ddv, dgates, ds, dpooled, T, N, B, L, H, Cr);
     return hipGetLastError();
 }
