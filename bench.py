@@ -44,6 +44,12 @@ import os
 import sys
 import time
 
+# one process per GPU over RCCL: the host driver only supports dmabuf IPC.  Under the driver's own
+# `python -m torch.distributed.run ... bench.py --gpus N` nothing else sets this (iodine_amd/launch.py does for the self-spawn
+# path), and it has to be in the environment before the HIP runtime is loaded by `import torch`.
+if int(os.environ.get('WORLD_SIZE', '1')) > 1 or '--gpus' in sys.argv:
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -56,7 +62,7 @@ SPLIT_PASSES = 3                   # fp32 product = a_hi*w_hi + a_hi*w_lo + a_lo
 PUBLISHED_TRAIN_ITERS_PER_S = 94.0  # 1.7 s / 32-image T=5 training step on 4 unknown GPUs (log.md:3)
 DOMINANT = ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad')
 CATS = DOMINANT + ('dec_out', 'dec_out_dgrad', 'dec_out_wgrad', 'dec_out_bwd', 'dec_l0', 'l0_reduce', 'l0_slot_sum', 'pixel_pass1',
-                   'pixel_pass2', 'refine_conv', 'refine_l0', 'refine_head', 'refine_wgrad', 'refine_dgrad', 'refine_bias_grad', 'head_bwd')
+                   'pixel_pass2', 'refine_conv', 'refine_l0', 'refine_head', 'refine_wgrad', 'refine_dgrad', 'refine_bwd01', 'refine_bias_grad', 'head_bwd')
 
 
 def parse():
@@ -206,9 +212,18 @@ def hbm_algorithmic_bytes(arch, B, mode):
     if Dr > 1:
         b['refine_conv'] = sum(i + o for i, o in per_layer[1:]) / (Dr - 1)
     if mode == 'train':                                      # one batch of T * N slot-images per layer
-        b['refine_wgrad'] = T * sum(i + o for i, o in per_layer) / Dr
-        if Dr > 1:
-            b['refine_dgrad'] = T * sum(2 * i + o for i, o in per_layer[1:]) / (Dr - 1)   # read d(out) + saved act, write d(in)
+        # round 4: the data gradient of layer 1 and the weight gradient of layer 0 are one launch (refine_bwd01: reads d(out 1), the
+        # saved activation 0 and the encoding; d(pre-activation 0) is not stored) - the other layers as before
+        fused01 = Dr > 1 and Cr == 64 and S % 64 == 0
+        if fused01:
+            b['refine_bwd01'] = T * (per_layer[0][0] + per_layer[0][1] + per_layer[1][1])
+            b['refine_wgrad'] = T * sum(i + o for i, o in per_layer[1:]) / (Dr - 1)
+            if Dr > 2:
+                b['refine_dgrad'] = T * sum(2 * i + o for i, o in per_layer[2:]) / (Dr - 2)
+        else:
+            b['refine_wgrad'] = T * sum(i + o for i, o in per_layer) / Dr
+            if Dr > 1:
+                b['refine_dgrad'] = T * sum(2 * i + o for i, o in per_layer[1:]) / (Dr - 1)   # read d(out) + saved act, write d(in)
     return b
 
 
@@ -226,12 +241,21 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world:
+    def fail_line(code, msg, **extra):
+        """Every failure path of the N > 1 start-up leaves a diagnosable record on rank 0: the message on stderr AND a JSON
+        object with the rccl block (world size, backend, rendezvous) on stdout, so that a hang or a refusal can be read off the tail."""
         if rank == 0:
-            print(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); start it as '
-                  f'`python bench.py --gpus {args.gpus}` or under torch.distributed.run --nproc-per-node {args.gpus}',
-                  file=sys.stderr, flush=True)
-        sys.exit(2)
+            print(f'bench.py: {msg}', file=sys.stderr, flush=True)
+            print(json.dumps(dict(error=msg, exit_code=code, n_gpus=world,
+                                  rccl=dict(world_size=world, rank=rank, local_rank=local,
+                                            backend=('gloo' if os.environ.get('IODINE_BENCH_SHARE_DEVICE') == '1' else 'nccl'),
+                                            master=f"{os.environ.get('MASTER_ADDR', '127.0.0.1')}:{os.environ.get('MASTER_PORT', '?')}",
+                                            hsa_ipc_mode_legacy=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'), **extra))), flush=True)
+        sys.exit(code)
+
+    if args.gpus != world:
+        fail_line(2, f'--gpus {args.gpus} but the launcher started {world} rank(s); start it as '
+                     f'`python bench.py --gpus {args.gpus}` or under torch.distributed.run --nproc-per-node {args.gpus}')
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
     # test hook (tests/test_gpu_multirank.py on a 1-GPU box): IODINE_BENCH_SHARE_DEVICE=1 puts every rank on device 0 and runs the
     # collectives over gloo - RCCL refuses two ranks on one device.  Everything else of the N > 1 path is the code that ships.
@@ -239,18 +263,25 @@ def main():
     if share:
         local = 0
     if ndev < (1 if share else max(world, 1)) or local >= ndev:
-        if rank == 0:
-            print(f'bench.py: --gpus {world} needs {world} visible ROCm devices on this node, found {ndev} '
-                  f'(rank {rank} of {world}, LOCAL_RANK {local})', file=sys.stderr, flush=True)
-        sys.exit(3)
+        fail_line(3, f'--gpus {world} needs {world} visible ROCm devices on this node, found {ndev} '
+                     f'(rank {rank} of {world}, LOCAL_RANK {local})', visible_devices=ndev)
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)                 # before the process group: RCCL binds the communicator to this device
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if share:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-        else:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        import datetime
+        try:
+            if share:
+                dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+            else:
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device,
+                                        timeout=datetime.timedelta(seconds=300))
+                # the first collective builds the RCCL communicator (xGMI rings): do it here, where a failure is attributable
+                t0c = torch.zeros(1, device=device)
+                dist.all_reduce(t0c)
+                torch.cuda.synchronize()
+        except Exception as e:                      # noqa: BLE001 - whatever RCCL / the rendezvous raised goes on the record
+            fail_line(4, f'process group start-up failed on rank {rank}: {type(e).__name__}: {e}', visible_devices=ndev)
 
     model, arch, params = build_model(args.config, args.slots, args.iters, device)
     B, T, K, S = args.batch, arch.ITERS, arch.SLOTS, arch.IMG_SIZE
@@ -445,6 +476,9 @@ def main():
                dtype=('f32 (3xf16-split MFMA convs, f32 accumulate)' if args.conv_precision == 1 else 'f32'), data='synthetic',
                config=dict(workload=f'{cfg_name}, K={K}, T={T}, batch {B}/GPU, {args.mode} step ({what})',
                            step=args.mode, global_batch=B * world, slots=K, iters=T, img_size=S, hip_graph=bool(args.graph),
+                           conv_path=('split_fp16x3: fp32 tensors, conv operands split on the fly into fp16 hi+lo, three f16 MFMAs, fp32 '
+                                      'accumulate (library default; `exact_fp32` on this line is the same step on fp32 MFMA)'
+                                      if args.conv_precision == 1 else 'exact_fp32: v_mfma_f32_32x32x2_f32 (option conv_precision=0)'),
                            parallelism=f'dp{world} (images sharded over ranks; '
                                        f'{"one RCCL all-reduce of the flat gradient buffer per step" if args.mode == "train" else "no data-path collective"})'),
                batch_iters_per_s=round(T / (dt / args.steps), 3), roofline=roofline, roofline_hbm=roofline_hbm, kernels=prof)
@@ -468,26 +502,55 @@ def main():
         torch.cuda.synchronize()
         us = max_over_ranks(e0.elapsed_time(e1) / 20 * 1e3)
         replicas_after = parallel.replicas_identical(model.parameters())
+        # north_star: "all-reduce of the per-image ELBO / gradient terms" - the (T+1, 3) {ELBO, KL, LL} batch means of the last step,
+        # averaged over the ranks' equal shards (= the global-batch means; DataParallel's gather + loss.mean(), train.py:61)
+        terms = parallel.allreduce_mean(model.elbo_terms.detach().float().contiguous(), world)
         out['rccl'] = dict(world_size=dist.get_world_size(), backend=dist.get_backend(), allreduce_bytes=nflat * 4,
                            allreduce_us=round(us, 1), per_step=1 if args.mode == 'train' else 0,
                            replicas_identical=bool(replicas_before and replicas_after),
                            replicas_identical_before_first_step=bool(replicas_before),
-                           replicas_identical_after_last_step=bool(replicas_after))
+                           replicas_identical_after_last_step=bool(replicas_after),
+                           hsa_ipc_mode_legacy=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'),
+                           elbo_terms_global_mean=[[round(float(v), 4) for v in row] for row in terms.cpu().tolist()],
+                           elbo_terms_columns=['elbo', 'kl', 'log_likelihood'])
+        if share:
+            # test hook: all ranks drive ONE device and the collectives ran over gloo - this line is NOT a multi-GPU measurement
+            out['shared_device'] = True
+            out['n_devices'] = 1
+            out['scaling'] = 'none (ranks share one device: test hook IODINE_BENCH_SHARE_DEVICE=1)'
 
     if rank == 0 and world == 1 and args.mode == 'train' and not args.no_exact_fp32 and args.conv_precision == 1:
-        # the precision trade on the record: the same step on the exact fp32-MFMA path (v_mfma_f32_32x32x2_f32)
+        # The strict-precision number, first class: the same step with every conv on the exact fp32-MFMA path
+        # (v_mfma_f32_32x32x2_f32; SURVEY 6c's primary plan), --steps timed steps (>= 8), its own value and roofline object with the
+        # dominant launches bracketed by HIP events inside ITS timed region, priced against the 157.3 TF/s fp32 matrix peak.
         model.set_option('conv_precision', 0)
         step()
+        nx = max(args.steps, 8)
         model.set_option('profile', 1)
-        dtx = timed(step, 2) / 2
+        dtx = timed(step, nx) / nx
         model.set_option('profile', 0)
         px = read_prof()
         xm = sum(px[c]['ms_total'] for c in DOMINANT if c in px)
         xn = sum(px[c]['launches'] for c in DOMINANT if c in px)
         xa = flops_per_launch / (xm / xn * 1e-3) / 1e12 if xn else 0.0
-        out['exact_fp32'] = dict(ms_per_step=round(dtx * 1e3, 3), steps=2, dominant_avg_launch_ms=round(xm / max(xn, 1), 4),
-                                 achieved_tflops=round(xa, 2), frac_of_157_3=round(xa / PEAK_F32_MFMA_TFLOPS, 4),
-                                 speedup_of_default_path=round(dtx * 1e3 / ms_per_step, 2))
+        out['exact_fp32'] = dict(
+            metric='refinement_iters_per_s', value=round(world * B * T / dtx, 2), unit='image-refinement-iters/s',
+            ms_per_step=round(dtx * 1e3, 3), steps=nx, dtype='f32 (v_mfma_f32_32x32x2_f32, IEEE fp32 products, fp32 accumulate)',
+            vs_baseline=round(world * B * T / dtx / PUBLISHED_TRAIN_ITERS_PER_S, 3) if args.config == 'clevr6' else None,
+            roofline=dict(bound='mfma',
+                          kernel=f'conv3x3_tile_kernel<{C_},{C_}> + conv3x3_wgrad_tile_kernel<{C_},{C_}> (decoder 3x3 conv {C_}->{C_}: fwd, '
+                                 f'dgrad, wgrad launches; exact fp32 MFMA)',
+                          achieved=round(xa, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=round(xa / PEAK_F32_MFMA_TFLOPS, 4),
+                          traffic=None, flops_per_launch=flops_per_launch, avg_launch_ms=round(xm / max(xn, 1), 4), launches=xn,
+                          events_in_timed_region=True,
+                          kernel_time_share=round(xm / max(nx, 1) / (dtx * 1e3), 4),
+                          per_form={c: dict(ms_avg=px[c]['ms_avg'],
+                                            tflops=round(flops_per_launch / (px[c]['ms_avg'] * 1e-3) / 1e12, 1),
+                                            frac=round(flops_per_launch / (px[c]['ms_avg'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+                                    for c in DOMINANT if c in px}),
+            speedup_of_default_path=round(dtx * 1e3 / ms_per_step, 2),
+            note='option conv_precision=0 (--conv-precision 0 makes it the headline line): every conv of the step on fp32 MFMA; the '
+                 'default line above keeps fp32 tensors and splits conv operands into fp16 hi+lo (3 f16 MFMAs, fp32 accumulate)')
         model.set_option('conv_precision', 1)
 
     if rank == 0 and world == 1 and not args.no_extra_configs and args.config == 'clevr6' and args.conv_precision == 1 \

@@ -316,6 +316,11 @@ hipError_t launch_conv3x3_s2_dgrad_f16x3(hipStream_t st, const float* d, const v
 hipError_t launch_conv3x3_s2_wgrad_f16x3(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
                                          int S, int ci_real, int nco, int* nparts, int* cipad, int* nbias_parts,
                                          const float* a2 = nullptr, int kdiv = 0);
+// kernels_refbwd.hip: data gradient of refinement layer 1 + weight / bias gradient of layer 0 in one pass (dpre0 never stored)
+bool refine_bwd01_ok(int S, int c);
+hipError_t launch_refine_bwd01(hipStream_t st, const float* rd1, const void* wpk, const float* wmeta, const float* act0, const float* enck,
+                               const float* encs, float* part, float* part_b, int NT, int S, int c, int kdiv, int* nparts, int* cipad,
+                               int* nbias_parts);
 hipError_t launch_dec_out_wgrad_gemm_f16x3(hipStream_t st, const float* a, const float* g, float* part, float* part_b, int N,
                                            int S, int c, int* nparts, int* nbias_parts);
 hipError_t launch_dec_out_bwd_fused_f16x3(hipStream_t st, const float* a, const float* g, const void* wpk, const float* wmeta,

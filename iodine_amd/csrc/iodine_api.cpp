@@ -93,6 +93,8 @@ struct iodine_handle {
     int fuse_l0 = 1;                            // inference: layer-1 data gradient reduces straight to the layer-0 row sums
     int refine_split = 1;                       // first refinement layer split into a per-slot and a per-image part (split-fp16 path)
     int head_fused = 1;                         // training backward: the head's BPTT recurrence as ONE launch (0 = 9 launches per iteration)
+    int refine_bwd_fused = 1;                   // training backward: data gradient of refinement layer 1 + weight gradient of layer 0 in one
+                                                // launch, d(pre-activation 0) never stored (kernels_refbwd.hip; 0 = the two launches)
     bool fwd_split = false;                     // the form the saved training forward used
     int variant = 6;                            // split-fp16 stride-1 conv: 6 = weight-stationary persistent kernel (power-of-two image sizes;
                                                 // other sizes use 1), 1 = LDS-tiled 16x16 tiles (2 blocks/CU)
@@ -108,6 +110,7 @@ struct iodine_handle {
     float *ref_wk = nullptr, *ref_wsh = nullptr;           // split first layer: weights in the internal channel order [Cr][12][9], [Cr][8][9]
     float *ref_wk16 = nullptr, *ref_wsh16 = nullptr, *ref_wkmeta = nullptr, *ref_wshmeta = nullptr;   // and their packs
     float* ref_g20 = nullptr;                              // [Cr][20][9] weight gradient in the internal order
+    float *ref_w1ws = nullptr, *ref_w1ws_meta = nullptr;   // layer 1's weights in the register layout of the fused layer-1/0 backward
     // ARCH.ENCODING subsets: reference input channel j of the first refinement layer = internal channel enc_map[j] (code order of
     // iodine.py:277-340); n_in < 17 -> weights expanded to / gradients gathered from the 17 internal channels
     int n_in = 17;
@@ -272,8 +275,9 @@ std::string validate(const iodine_config& c)
     if (c.ref_conv_layers < 1 || (c.img_size >> c.ref_conv_layers) < 1) return "REF.CONV_LAYERS out of range for IMG_SIZE";
     if (c.slots < 1 || c.slots > 12) return "ARCH.SLOTS must be in 1..12";
     if (c.iters < 1) return "ARCH.ITERS must be >= 1";
-    if (c.dim_latent < 2 || c.dim_latent > 256) return "ARCH.DIM_LATENT must be in 2..256";
-    if (c.ref_mlp_units < 1 || c.ref_mlp_units > 1024) return "REF.MLP_UNITS must be in 1..1024";
+    // (the refinement head reads its weight rows as 16-byte vectors: refine_head_kernel / head_bptt_kernel)
+    if (c.dim_latent < 4 || c.dim_latent > 256 || c.dim_latent % 4 != 0) return "ARCH.DIM_LATENT must be a multiple of 4 in 4..256";
+    if (c.ref_mlp_units < 4 || c.ref_mlp_units > 1024 || c.ref_mlp_units % 4 != 0) return "REF.MLP_UNITS must be a multiple of 4 in 4..1024";
     if (!(c.sigma > 0)) { snprintf(m, sizeof m, "ARCH.SIGMA must be > 0 (got %g)", c.sigma); return m; }
     return "";
 }
@@ -758,7 +762,7 @@ int run_graphed(iodine_handle* h, hipStream_t st, const std::vector<uintptr_t>& 
 std::vector<uintptr_t> graph_key(const iodine_handle* h, int entry, int batch, std::initializer_list<const void*> ptrs)
 {
     std::vector<uintptr_t> k = {(uintptr_t)entry, (uintptr_t)batch, (uintptr_t)h->stop_after, (uintptr_t)h->precision,
-                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)h->head_fused,
+                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)(h->head_fused | (h->refine_bwd_fused << 1)),
                                 (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
     for (const void* p : ptrs) k.push_back((uintptr_t)p);
     return k;
@@ -849,6 +853,7 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     }
     // split first layer: one 16-channel chunk each for the per-slot (12 real) and the per-image (8 real) channels
     ALLOC(h->ref_wk, (size_t)Cr * 12 * 9); ALLOC(h->ref_wsh, (size_t)Cr * 8 * 9); ALLOC(h->ref_g20, (size_t)Cr * 20 * 9);
+    if (Cr % 32 == 0) { ALLOC(h->ref_w1ws, conv_ws_wpk_bytes(Cr) / 4); ALLOC(h->ref_w1ws_meta, (size_t)4); }
     ALLOC(h->ref_w17, (size_t)Cr * 17 * h->kr * h->kr); ALLOC(h->ref_g17, (size_t)Cr * 17 * h->kr * h->kr);
     if (h->generic) {
         const int kkd = h->kd * h->kd, kkr = h->kr * h->kr;
@@ -994,6 +999,8 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         HIPCHK(h, launch_ref_split_weights(st, w0, Cr, h->ref_wk, h->ref_wsh));
         HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wk, Cr, 12, 16, Cr, 0, h->ref_wkmeta, h->ref_wk16));
         HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wsh, Cr, 8, 16, Cr, 0, h->ref_wshmeta, h->ref_wsh16));
+        if (h->Dr >= 2 && refine_bwd01_ok(h->S, Cr))           // fused layer-1 / layer-0 backward: W1 as the transposed conv's A operand
+            HIPCHK(h, launch_pack_conv_weights_ws(st, P("refine.mlc.layers.1.weight"), Cr, 1, h->ref_w1ws_meta, h->ref_w1ws));
     }
     }   // !generic
     auto copy_raw = [&](float* dst, const std::string& name) {
@@ -1053,6 +1060,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "fuse_l0")) { h->fuse_l0 = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_split")) { h->refine_split = value != 0; return IODINE_OK; }
     if (!strcmp(key, "head_fused")) { h->head_fused = value != 0; return IODINE_OK; }
+    if (!strcmp(key, "refine_bwd_fused")) { h->refine_bwd_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {
         if (value != 1 && value != 6) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1 (LDS-tiled) or 6 (weight-stationary)");
         if (((int)value == 6) != (h->variant == 6)) h->params_set = false;   // the other kernel's weight packs are not kept up to date
@@ -1327,6 +1335,10 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
         for (int l = 0; l < h->Dr; ++l) sz[l + 1] = ref_out_size(sz[l]);
         const int sl = sz[h->Dr];
         HIPCHK(h, launch_pool_bwd(st, b.dpooled, b.ract[0][h->Dr - 1], b.rdpre[h->Dr - 1], NT, sl * sl, Cr));
+        // round 4: the data gradient of layer 1 and the weight / bias gradient of layer 0 in ONE launch - d(pre-activation 0), the
+        // largest tensor of this backward (T * N x 64 x 64 x 64 floats at cfg3), is produced and consumed on chip
+        const bool fuse01 = h->refine_bwd_fused && h->fwd_split && !h->generic && h->precision == 1 && refine_f16_ok(h) && h->Dr >= 2 &&
+                            refine_bwd01_ok(h->S, Cr);
         for (int l = h->Dr - 1; l >= 0; --l) {
             const float* in = l == 0 ? b.enc[0] : b.ract[0][l - 1];
             const int cip = l == 0 ? 20 : Cr, ireal = l == 0 ? 17 : Cr;
@@ -1340,6 +1352,14 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
             if (h->generic) {
                 PROF(h, st, "gen_conv", launch_gen_conv_wgrad(st, in, b.rdpre[l], b.gen_scr, NT, sz[l], ireal, cip, ireal, Cr, h->kr, 2, 1.f,
                                                               gw_dst, G(base + ".bias")));
+            } else if (l == 0 && fuse01) {
+                int nb = 0;
+                PROF(h, st, "refine_bwd01", launch_refine_bwd01(st, b.rdpre[1], h->ref_w1ws, h->ref_w1ws_meta, b.ract[0][0], b.enck[0], b.encs[0],
+                                                                b.wg_part, b.wg_part_b, NT, sz[0], Cr, h->K, &nparts, &cipad, &nb));
+                HIPCHK(h, hipMemsetAsync(h->ref_g20, 0, (size_t)Cr * 20 * 9 * sizeof(float), st));
+                HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, 20, 20, 1.f, h->ref_g20, b.wg_fold,
+                                              b.wg_part_b, nb, G(base + ".bias")));
+                HIPCHK(h, launch_ref_unsplit_grad(st, h->ref_g20, Cr, gw_dst));
             } else if (l == 0 && h->fwd_split) {
                 // split first layer: 12 per-slot + 8 per-image channels from two tensors, gradient in the internal channel
                 // order, then added to the reference layout
@@ -1364,7 +1384,7 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
                                                                    G(base + ".bias"), b.wg_part_b, (size_t)512 * 64));
             }
             if (gather0) HIPCHK(h, launch_enc_gather_grad(st, h->ref_g17, Cr, h->n_in, h->enc_map, G(base + ".weight"), h->kr * h->kr));
-            if (l > 0) {
+            if (l > 0 && !(l == 1 && fuse01)) {
                 if (h->generic)
                     PROF(h, st, "gen_conv", launch_gen_conv_dgrad(st, b.rdpre[l], h->gen_wref[l], b.ract[0][l - 1], b.rdpre[l - 1], NT, sz[l],
                                                                   Cr, Cr, Cr, h->kr, 2));

@@ -38,7 +38,7 @@ __host__ __device__ constexpr int s2_fwd_sb(int i) { return 3 - i; }
 template <int CIN_REAL, int CIN, int COUT, int MODE, int SBT>
 IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
                              const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
-                             int Sc, int tiles, int kdiv, unsigned char* smem_b)
+                             int Sc, int tiles, int kdiv, unsigned char* smem_b, int bid)
 {
     constexpr int NC16 = CIN / 16;
     constexpr int NSTAGE = MODE == 0 ? 4 * NC16 : NC16;
@@ -60,7 +60,6 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
     const int prow = li >> 4, pcol = li & 15;
     const int Sf = 2 * Sc;
 
-    int bid = blockIdx.x;
     const int tx = bid % tiles; bid /= tiles;
     const int ty = bid % tiles;
     const int n = bid / tiles;
@@ -313,13 +312,18 @@ void conv3x3_s2_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s2[];
     if (MODE == 0) {
-        conv_s2_body<CIN_REAL, CIN, COUT, 0, 0>(in, wpk, wmeta, bias, aux, out, Sc, tiles, kdiv, smem_s2);
+        conv_s2_body<CIN_REAL, CIN, COUT, 0, 0>(in, wpk, wmeta, bias, aux, out, Sc, tiles, kdiv, smem_s2, (int)blockIdx.x);
     } else {
-        switch (3 - (int)blockIdx.y) {                       // heaviest class (4 taps) is dispatched first
-        case 0: conv_s2_body<CIN_REAL, CIN, COUT, 1, 0>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2); break;
-        case 1: conv_s2_body<CIN_REAL, CIN, COUT, 1, 1>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2); break;
-        case 2: conv_s2_body<CIN_REAL, CIN, COUT, 1, 2>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2); break;
-        default: conv_s2_body<CIN_REAL, CIN, COUT, 1, 3>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2); break;
+        // The four parity classes of a coarse tile read the SAME staged input: their blocks are made neighbours in dispatch order ON
+        // ONE XCD (block b runs on XCD b % 8, observed; speed only), so that three of the four reads hit that XCD's L2 instead of
+        // coming from HBM at different times (round 3: 1.42x the algorithmic bytes).  b = 8 (4 q + class) + xcd, tile = 8 q + xcd.
+        const int b = (int)blockIdx.x, xcd = b & 7, r = b >> 3, tile = (r >> 2) * 8 + xcd;
+        if (tile >= kdiv) return;                            // (kdiv carries the tile count in this mode; block-uniform)
+        switch (r & 3) {                                     // heaviest class (4 taps) first
+        case 3: conv_s2_body<CIN_REAL, CIN, COUT, 1, 0>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2, tile); break;
+        case 2: conv_s2_body<CIN_REAL, CIN, COUT, 1, 1>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2, tile); break;
+        case 1: conv_s2_body<CIN_REAL, CIN, COUT, 1, 2>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2, tile); break;
+        default: conv_s2_body<CIN_REAL, CIN, COUT, 1, 3>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2, tile); break;
         }
     }
 }
@@ -332,7 +336,9 @@ hipError_t launch_s2_inst(hipStream_t st, const float* in, const void* wpk, cons
     static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
     if (hipError_t e = iod_set_max_lds((const void*)conv3x3_s2_f16x3_kernel<CIN_REAL, CIN, COUT, MODE>, (int)lds, attr_devs); e != hipSuccess) return e;
     const int tiles = (Sc + 15) / 16;
-    hipLaunchKernelGGL((conv3x3_s2_f16x3_kernel<CIN_REAL, CIN, COUT, MODE>), dim3(N * tiles * tiles, MODE == 0 ? 1 : 4),
+    const int ntiles = N * tiles * tiles;
+    if (MODE == 1) kdiv = ntiles;                                          // data gradient: 1-D grid, see the kernel
+    hipLaunchKernelGGL((conv3x3_s2_f16x3_kernel<CIN_REAL, CIN, COUT, MODE>), dim3(MODE == 0 ? ntiles : ((ntiles + 7) / 8) * 32),
                        dim3(256), lds, st, in, reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, Sc, tiles, kdiv);
     return hipGetLastError();
 }

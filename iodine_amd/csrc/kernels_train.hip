@@ -297,6 +297,62 @@ void wgrad_fold_kernel(const float4* __restrict__ part, int nparts, int per, int
     fold[(size_t)f * total4 + e] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
 }
 
+// Round 4: both stages in ONE launch (the two-launch form cost 28 x (7.7 + 5.4 us + a kernel boundary) per cfg3 training step).
+// A block owns 64 consecutive elements of the [tap][ci][co] tile: thread (g = tid / 16, q = tid % 16) sums float4 column q of the
+// parts g, g + 16, g + 32, ... (eight independent 16-byte loads in flight), the 16 group sums meet in LDS and are added in fixed order
+// by the first 64 threads, which also do the layout change into OIHW.  Blocks behind the weight blocks sum the bias partial rows.
+__global__ __launch_bounds__(256)
+void wgrad_reduce_fused_kernel(const float4* __restrict__ part, int nparts, int ci_pad, int co_pad, int O_real, int I_real, int I_dst,
+                               float alpha, float* __restrict__ dst, const float* __restrict__ part_b, int nb, float* __restrict__ dst_b)
+{
+    const int total = 9 * ci_pad * co_pad, total4 = total / 4, nblk_w = total / 64;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= nblk_w) {
+        __shared__ float s_red[256];
+        const int c = blockIdx.x - nblk_w;
+        float s = 0.f;
+        for (int r = tid; r < nb; r += 256) s += part_b[(size_t)r * O_real + c];
+        s_red[tid] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) s_red[tid] += s_red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) dst_b[c] += alpha * s_red[0];
+        return;
+    }
+    __shared__ float4 s_g[16][16];
+    const int g = tid >> 4, q = tid & 15;
+    const float4* col = part + (size_t)blockIdx.x * 16 + q;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    int b = g;
+    for (; b + 7 * 16 < nparts; b += 8 * 16) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = col[(size_t)(b + 16 * j) * total4];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            s0.x += v[j].x; s0.y += v[j].y; s0.z += v[j].z; s0.w += v[j].w;
+            s1.x += v[j + 1].x; s1.y += v[j + 1].y; s1.z += v[j + 1].z; s1.w += v[j + 1].w;
+        }
+    }
+    for (; b < nparts; b += 16) { const float4 v = col[(size_t)b * total4]; s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w; }
+    s_g[g][q] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (tid < 64) {
+        const float* sf = reinterpret_cast<const float*>(&s_g[0][0]);
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) { t0 += sf[j * 64 + tid]; t1 += sf[(j + 1) * 64 + tid]; }
+        const int e = blockIdx.x * 64 + tid;
+        const int co = e % co_pad, ci = (e / co_pad) % ci_pad, tap = e / (co_pad * ci_pad);
+        if (co < O_real && ci < I_real) {
+            float* o = dst + ((size_t)co * I_dst + ci) * 9 + tap;
+            *o += alpha * (t0 + t1);
+        }
+    }
+}
+
 // part_b / dst_b (optional): nb bias partial rows [nb][O_real] of the same launch, summed into dst_b with the same alpha
 hipError_t launch_wgrad_reduce(hipStream_t st, const float* part, int nparts, int ci_pad, int co_pad, int O_real,
                                int I_real, int I_dst, float alpha, float* dst, float* fold, const float* part_b, int nb,
@@ -305,6 +361,12 @@ hipError_t launch_wgrad_reduce(hipStream_t st, const float* part, int nparts, in
     IOD_XSKIP(1);
     if (nparts <= 0) return hipSuccess;
     const int total = 9 * ci_pad * co_pad;
+    const bool with_b = part_b && dst_b && nb > 0;
+    if (nparts >= 16 && total % 64 == 0) {
+        hipLaunchKernelGGL(wgrad_reduce_fused_kernel, dim3(total / 64 + (with_b ? O_real : 0)), dim3(256), 0, st, (const float4*)part, nparts,
+                           ci_pad, co_pad, O_real, I_real, I_dst, alpha, dst, part_b, nb, dst_b);
+        return hipGetLastError();
+    }
     if (fold && nparts >= 4 * WGRAD_FOLD && total % 4 == 0) {
         const int per = (nparts + WGRAD_FOLD - 1) / WGRAD_FOLD, nf = (nparts + per - 1) / per;
         hipLaunchKernelGGL(wgrad_fold_kernel, dim3((total / 4 + 255) / 256, nf), dim3(256), 0, st, (const float4*)part,
@@ -312,7 +374,6 @@ hipError_t launch_wgrad_reduce(hipStream_t st, const float* part, int nparts, in
         part = fold;
         nparts = nf;
     }
-    const bool with_b = part_b && dst_b && nb > 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256 + (with_b ? O_real : 0)), dim3(256), 0, st, part, nparts,
                        ci_pad, co_pad, O_real, I_real, I_dst, alpha, dst, part_b, nb, dst_b);
     return hipGetLastError();
@@ -942,7 +1003,8 @@ void head_bptt_kernel(const float* __restrict__ g_pm, const float* __restrict__ 
 
 // does the fused kernel's LDS footprint fit (it does for every shipped configuration; MLP_UNITS >= 512 falls back to the launch sequence)
 static size_t head_bptt_lds(int L, int H) { return ((size_t)HB * (2 * L + 10 * H) + (size_t)HKG * 2 * HB * 256) * sizeof(float); }
-bool head_bptt_fits(int L, int H, int Cr) { return Cr <= H && head_bptt_lds(L, H) <= 160 * 1024; }
+// (head_matvec reads the weights as 16-byte f32x4 rows: every row length / leading dimension - H, H + 4L, Cr, L - must be a multiple of 4)
+bool head_bptt_fits(int L, int H, int Cr) { return Cr <= H && H % 4 == 0 && Cr % 4 == 0 && L % 4 == 0 && head_bptt_lds(L, H) <= 160 * 1024; }
 
 hipError_t launch_head_bptt(hipStream_t st, const float* g_pm, const float* g_plv, const float* gates, const float* cst, const float* u,
                             const float* Wm, const float* Wv, const float* Whh, const float* Wih, const float* Wmlp, float* ddm,

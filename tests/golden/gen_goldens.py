@@ -53,6 +53,10 @@ CASES = {
     # stacks) together with its default ENCODING: the generic fallback path of the library (round 3)
     'tiny_k5': ('tiny', 3, 2, 2, 'uniform'),
 }
+# Round 4 (VERDICT r03, next #3c): FULL gradient tensors of the headline-architecture cases, so that reference <-> oracle <-> HIP are
+# compared element by element there too (the base fixtures keep sum / sumsq / 16 samples per tensor).  Own files: the base fixtures
+# stay byte-identical.  Values: the reference's fp64 run, stored as float32 (rounding 6e-8, the gate is 1e-3).
+GRAD_CASES = {'cfg3_clevr_k7_t5_b1_grads': 'cfg3_clevr_k7_t5_b1', 'cfg5_clevr_k11_t7_b1_grads': 'cfg5_clevr_k11_t7_b1'}
 CASE_KERNEL = {'tiny_k5': (5, 5)}          # (REF.KERNEL_SIZE, DEC.KERNEL_SIZE)
 # encoding list per case (default: the full 12-entry list of the shipped IODINE configs)
 CASE_ENCODING = {c: [e for e in ENCODING if e != 'coordinate'] for c in ('tiny_default_enc', 'cfg1_default_enc', 'tiny_k5')}
@@ -191,6 +195,44 @@ def run_case(case):
     return out
 
 
+def run_grad_case(case):
+    """One training step (lib/engine/train.py:60-63) of the unmodified reference in fp64 on the inputs of the base case: every
+    parameter gradient in full (float32 storage), the loss and the ELBO trajectory (float64)."""
+    base = GRAD_CASES[case]
+    fam, K, T, B, kind = CASES[base]
+    S, L = ARCHS[fam]['S'], ARCHS[fam]['L']
+    imgs = synth.make_images(B, S, seed=SEED_X, kind=kind)
+    imgs = imgs[0] if kind == 'blobs' else imgs
+    eps = synth.make_eps(T, B, K, L, seed=SEED_E)
+    out = dict(meta_base=base, meta_K=K, meta_T=T, meta_B=B, meta_S=S, meta_L=L, meta_kind=kind, meta_family=fam,
+               meta_seeds=np.array([SEED_W, SEED_X, SEED_E]))
+    model, _ = build_reference(fam, K, T, torch.float64)
+    x, e = torch.from_numpy(imgs).double(), torch.from_numpy(eps).double()
+    model.train()
+    elbo_log = []
+    orig_elbo = model.elbo
+
+    def spy(xx):
+        v = orig_elbo(xx)
+        elbo_log.append(v.detach().clone())
+        return v
+    model.elbo = spy
+    with EpsReplay(e) as rp:
+        loss = model(x)
+        assert rp.i == T + 1
+    loss = loss.mean()
+    model.zero_grad()
+    loss.backward()
+    model.elbo = orig_elbo
+    out['f64.train.loss'] = np.float64(loss.item())
+    out['f64.train.elbos'] = torch.stack(elbo_log).double().numpy().copy()
+    for n, prm in model.named_parameters():
+        g = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+        out[f'f64.train.grad.{n}'] = g.detach().double().numpy().astype(np.float32)
+    print(f'  [{case}] fp64 train loss {loss.item():.6f}')
+    return out
+
+
 def dump_stages(model, x, e, out):
     """Capture the tensors the reference keeps on ``self`` after each elbo() /
     get_input_encoding() call (iodine.py:36-52,171-216,243-343) during ``encode``."""
@@ -282,10 +324,11 @@ def ari_known_answer():
 
 def main():
     torch.set_num_threads(8)
-    want = sys.argv[1:] or (list(CASES) + ['ari', 'tiny_logger'])
+    want = sys.argv[1:] or (list(CASES) + ['ari', 'tiny_logger'] + list(GRAD_CASES))
     for case in want:
         t0 = time.time()
-        out = ari_known_answer() if case == 'ari' else run_logger_case() if case == 'tiny_logger' else run_case(case)
+        out = (ari_known_answer() if case == 'ari' else run_logger_case() if case == 'tiny_logger'
+               else run_grad_case(case) if case in GRAD_CASES else run_case(case))
         path = os.path.join(HERE, case + '.npz')
         np.savez_compressed(path, **out)
         print(f'{case}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB, {time.time() - t0:.1f}s)')

@@ -28,6 +28,11 @@ RUNS = {   # name: (family, K, T, B, steps, checkpoints, lr)
     # the headline architecture (CLEVR6: 128 x 128, 64 channels, K = 7, T = 5), one image: a dozen steps are what the CPU affords
     'teacher_cfg3': ('clevr', 7, 5, 1, 12, (12,), 1e-3),
 }
+# Round 4 (VERDICT r03, next #3a): the SAME oracle loop run LONG on cfg1 - until the masks are (nearly) binary, the regime of a converged
+# IODINE: sharpness logged every 50 steps, parameters kept at the checkpoints listed + the first step whose mean max-mask reaches 0.98
+LONG_RUNS = {   # name: (family, K, T, B, max steps, keep-at, lr, stop-at sharpness)
+    'teacher_cfg1_long': ('dsprites', 4, 3, 4, 3000, (250, 500, 1000, 1500, 2000, 3000), 1e-3, 0.98),
+}
 SEED_W, SEED_X, SEED_E = 11, 12, 1000
 
 
@@ -58,8 +63,49 @@ def run(name, fam, K, T, B, steps, ckpts, lr):
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
 
 
+def run_long(name, fam, K, T, B, max_steps, keep, lr, stop_sharp):
+    arch = {'tiny': O.tiny_arch, 'dsprites': O.dsprites_arch, 'clevr': O.clevr_arch}[fam](slots=K, iters=T)
+    pn = synth.make_params(O.param_shapes(arch), seed=SEED_W)
+    params = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in pn.items()}
+    imgs, _ = synth.make_images(B, arch.img_size, seed=SEED_X, kind='blobs')
+    x = torch.from_numpy(imgs)
+    opt = torch.optim.Adam(list(params.values()), lr=lr)
+    out = dict(meta_family=fam, meta_K=K, meta_T=T, meta_B=B, meta_lr=lr, meta_seeds=np.array([SEED_W, SEED_X, SEED_E]))
+    losses, sharp_log, ckpts = [], [], []
+
+    def keep_ckpt(s, sharp):
+        ckpts.append(s)
+        out[f'ckpt{s}.mask_sharpness'] = sharp
+        for k, v in params.items():
+            out[f'ckpt{s}.param.{k}'] = v.detach().numpy().copy()
+
+    for s in range(1, max_steps + 1):
+        eps = torch.from_numpy(synth.make_eps(T, B, K, arch.dim_latent, seed=SEED_E + s))
+        res = O.train_forward(x, eps, params, arch)
+        opt.zero_grad()
+        res['loss'].backward()
+        opt.step()
+        losses.append(float(res['loss'].detach()))
+        sharp = float(res['final_mask'].detach().max(dim=1).values.mean())
+        if s % 50 == 0:
+            sharp_log.append((s, sharp))
+            print(f'  [{name}] step {s}: loss {losses[-1]:.3f}, mean max-mask {sharp:.4f}', flush=True)
+        done = sharp >= stop_sharp
+        if s in keep or done:
+            keep_ckpt(s, sharp)
+            np.savez_compressed(os.path.join(HERE, name + '.npz'), losses=np.array(losses), sharpness_log=np.array(sharp_log),
+                                meta_ckpts=np.array(ckpts), meta_steps=s, **out)
+        if done:
+            print(f'  [{name}] step {s}: mean max-mask {sharp:.4f} >= {stop_sharp} - stop', flush=True)
+            break
+
+
 if __name__ == '__main__':
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get('TEACHER_THREADS', '8')))
+    for name, cfg in LONG_RUNS.items():
+        if name in sys.argv[1:]:
+            run_long(name, *cfg)
+            sys.exit(0)
     for name, cfg in RUNS.items():
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue

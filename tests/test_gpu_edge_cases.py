@@ -10,7 +10,7 @@ import torch
 
 from iodine_amd import synth
 from oracle import iodine_oracle as O
-from util import golden_setup, load_golden, make_hip_model, rel_err, rel_l2
+from util import golden_setup, grad_views, load_golden, make_hip_model, rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -71,6 +71,12 @@ def test_unsupported_configurations_fail_loudly():
         IODINE(arch_namespace(8, 2, 3, 16, (48, 2, 32), (48, 2))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
     with pytest.raises((RuntimeError, ValueError)):                          # even kernel size
         IODINE(arch_namespace(8, 2, 3, 16, (32, 2, 32), (32, 2), kernels=(3, 4))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
+    # the refinement head reads weight rows as 16-byte vectors: DIM_LATENT / MLP_UNITS that are not multiples of 4 are refused WHEN
+    # THE HANDLE IS CREATED, with a readable message (round 4; they used to surface as a bare HIP error at the first call)
+    with pytest.raises((RuntimeError, ValueError), match='DIM_LATENT must be a multiple of 4'):
+        IODINE(arch_namespace(6, 2, 3, 16, (32, 2, 32), (32, 2))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
+    with pytest.raises((RuntimeError, ValueError), match='MLP_UNITS must be a multiple of 4'):
+        IODINE(arch_namespace(8, 2, 3, 16, (32, 2, 30), (32, 2))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
     m = IODINE(ok).to(DEV)
     with pytest.raises((RuntimeError, ValueError)):                          # wrong image size for this ARCH
         m.reconstruct(torch.rand(1, 3, 32, 32, device=DEV))
@@ -104,13 +110,13 @@ def test_default_encoding_without_coordinate(case, opt):
     assert abs(loss.item() - float(g['f32.train.loss'])) <= 1e-4 * abs(float(g['f32.train.loss']))
     assert rel_err(m.elbo_terms[:, 0].cpu(), g['f32.train.elbos']) < 1e-4
     out, rg = O.train_step_grads(x, eps, params, arch)
-    bad = [(n, rel_l2(p.grad.cpu().numpy(), rg[n].numpy())) for n, p in m.named_parameters()
-           if n != 'decoder.conv.bias' and not rel_l2(p.grad.cpu().numpy(), rg[n].numpy()) < 2e-3]
+    bad = [(n, rel_l2(*grad_views(n, p.grad.cpu().numpy(), rg[n].numpy()))) for n, p in m.named_parameters()
+           if not rel_l2(*grad_views(n, p.grad.cpu().numpy(), rg[n].numpy())) < 2e-3]
     assert not bad, bad
     assert tuple(m.refine.mlc.layers[0].weight.grad.shape) == (arch.ref_chan, 15, 3, 3)
     if case.startswith('tiny'):
         for n, p in m.named_parameters():
-            assert rel_l2(p.grad.cpu().numpy(), g['f64.train.grad.' + n]) < 2e-3 or n == 'decoder.conv.bias', n
+            assert rel_l2(*grad_views(n, p.grad.cpu().numpy(), g['f64.train.grad.' + n])) < 2e-3, n
     pred, mask, mean = m.reconstruct(xd, ed)
     assert rel_err(m.elbo_terms[:, 0].cpu(), g['f32.recon.elbos']) < 1e-4
     ref = O.reconstruct(x, eps, params, arch)
@@ -131,8 +137,8 @@ def test_encoding_subset_in_the_middle_of_the_list():
     loss.backward()
     out, rg = O.train_step_grads(x, eps, params, arch)
     assert abs(loss.item() - float(out['loss'])) <= 1e-4 * abs(float(out['loss']))
-    bad = [(n, rel_l2(p.grad.cpu().numpy(), rg[n].numpy())) for n, p in m.named_parameters()
-           if n != 'decoder.conv.bias' and not rel_l2(p.grad.cpu().numpy(), rg[n].numpy()) < 2e-3]
+    bad = [(n, rel_l2(*grad_views(n, p.grad.cpu().numpy(), rg[n].numpy()))) for n, p in m.named_parameters()
+           if not rel_l2(*grad_views(n, p.grad.cpu().numpy(), rg[n].numpy())) < 2e-3]
     assert not bad, bad
     arch.encoding = tuple(e for e in O.FULL_ENCODING if e != 'posterior')
     with pytest.raises(RuntimeError, match='grad_post'):
@@ -149,8 +155,8 @@ def _step_vs_oracle(arch, params, x, eps, tol_grad=2e-3):
     out, rg = O.train_step_grads(x, eps, params, arch)
     assert abs(loss.item() - float(out['loss'])) <= 1e-4 * abs(float(out['loss']))
     assert rel_err(m.elbo_terms[:, 0].cpu(), out['elbos']) < 1e-4
-    bad = [(n, rel_l2(p.grad.cpu().numpy(), rg[n].numpy())) for n, p in m.named_parameters()
-           if n != 'decoder.conv.bias' and not rel_l2(p.grad.cpu().numpy(), rg[n].numpy()) < tol_grad]
+    bad = [(n, rel_l2(*grad_views(n, p.grad.cpu().numpy(), rg[n].numpy()))) for n, p in m.named_parameters()
+           if not rel_l2(*grad_views(n, p.grad.cpu().numpy(), rg[n].numpy())) < tol_grad]
     assert not bad, bad
     for n, p in m.named_parameters():
         assert tuple(p.grad.shape) == tuple(params[n].shape), n
@@ -175,7 +181,7 @@ def test_kernel_size_5_matches_the_reference_golden():
     assert abs(loss.item() - float(g['f32.train.loss'])) <= 1e-4 * abs(float(g['f32.train.loss']))
     assert rel_err(m.elbo_terms[:, 0].cpu(), g['f32.train.elbos']) < 1e-4
     for n, p in m.named_parameters():
-        assert rel_l2(p.grad.cpu().numpy(), g['f64.train.grad.' + n]) < 2e-3 or n == 'decoder.conv.bias', n
+        assert rel_l2(*grad_views(n, p.grad.cpu().numpy(), g['f64.train.grad.' + n])) < 2e-3, n
     pred, mask, mean = m.reconstruct(x.to(DEV), eps.to(DEV))
     assert rel_err(pred.cpu(), g['f32.recon.pred']) < 2e-4 and rel_err(mean.cpu(), g['f32.recon.mean']) < 2e-4
 

@@ -60,8 +60,14 @@ def test_two_ranks_sharing_one_device_bench_path():
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_json(r.stdout)
     assert out['n_gpus'] == 2 and out['rccl']['world_size'] == 2 and out['rccl']['backend'] == 'gloo'
-    assert out['config']['global_batch'] == 16 and out['scaling'] == 'weak'
+    assert out['config']['global_batch'] == 16
+    # the hook is visible on the line: two ranks on ONE device are not a multi-GPU measurement
+    assert out['shared_device'] is True and out['n_devices'] == 1 and out['scaling'].startswith('none')
     assert out['rccl']['replicas_identical'] is True          # after Adam steps on all-reduced gradients the replicas still agree bitwise
+    # the (T+1, 3) ELBO / KL / LL batch means of the last step, all-reduced over the ranks (north_star: "all-reduce of the per-image
+    # ELBO / gradient terms"): ELBO = LL - KL row by row
+    terms = out['rccl']['elbo_terms_global_mean']
+    assert len(terms) in (5, 6) and all(abs(t[0] - (t[2] - t[1])) <= 1e-4 * abs(t[0]) for t in terms)   # (T elbo calls if the last step was a reconstruct, T + 1 after a training step)
     assert out['value'] > 0 and out['ms_per_step'] > 0 and out['roofline']['frac'] > 0
 
 

@@ -1,7 +1,8 @@
 """Parity on weights AFTER training: tests/golden/teacher_*.npz hold parameters the CPU oracle reached after
 10 ... 100 Adam steps on blob scenes (tests/golden/gen_teacher.py).  Each checkpoint is loaded into the HIP module and into the oracle;
-one training step on the same images / noise must agree: loss and ELBO trajectory to 1e-4, every parameter gradient to 1e-3 rel-L2
-(the north_star gate), and reconstruct's ELBOs / masks likewise.  A second pass SHARPENS the masks artificially (mask-logit row of the
+one training step on the same images / noise must agree: loss and ELBO trajectory to 1e-4, the gradient as a whole to 1e-3 rel-L2 (the
+north_star gate) and every single parameter tensor to 5e-3 rel-L2 (all of them; of decoder.conv.bias the three rgb entries - the mask-logit
+bias has a zero gradient), and reconstruct's ELBOs / masks likewise.  A second pass SHARPENS the masks artificially (mask-logit row of the
 output conv x 8: the softmax over slots saturates, r -> 0 / 1, and the inner gradients r (x - mu) / sigma^2 inside one 8 x 16 cell
 spread over many orders of magnitude) - the regime where a per-cell scale for the fp16 split is weakest."""
 import numpy as np
@@ -10,7 +11,7 @@ import torch
 
 from iodine_amd import synth
 from oracle import iodine_oracle as O
-from util import load_golden, make_hip_model, rel_err, rel_l2
+from util import grad_views, load_golden, make_hip_model, rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -45,8 +46,9 @@ def test_training_step_on_trained_weights(name, ckpt, sharpen):
     num = sum(float(((p.grad.double().cpu() - rg[n].double()) ** 2).sum()) for n, p in m.named_parameters())
     den = sum(float((rg[n].double() ** 2).sum()) for n, _ in m.named_parameters())
     e_grad = (num / den) ** 0.5
-    worst = max(((rel_l2(p.grad.cpu().numpy(), rg[n].numpy()), n) for n, p in m.named_parameters()
-                 if n != 'decoder.conv.bias' and float(rg[n].abs().max()) > 0), default=(0.0, ''))
+    # per tensor: everything but the mask-logit bias (decoder.conv.bias[3], zero gradient + rounding noise) - the rgb biases are checked
+    worst = max(((rel_l2(*grad_views(n, p.grad.cpu().numpy(), rg[n].numpy())), n) for n, p in m.named_parameters()
+                 if float(rg[n].abs().max()) > 0), default=(0.0, ''))
     print(f'[trained weights] {name} step {ckpt} sharpen x{sharpen:g}: mean max-mask {sharp:.3f}, loss {e_loss:.1e}, ELBOs {e_elbo:.1e}, '
           f'grad rel-L2 {e_grad:.1e}, worst tensor {worst[1]} {worst[0]:.1e}')
     assert np.isfinite(ref_loss)
