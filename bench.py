@@ -575,6 +575,45 @@ def main():
             side[tag] = rec
             del m2, x2
             torch.cuda.empty_cache()
+        # The reference's DEFAULT decoder kernel size (lib/config/defaults.py:100, configs/test.yaml:40,44: DEC.KERNEL_SIZE 5) at the
+        # CLEVR shapes: runs on the library's generic fallback path (kernels_generic.hip: plain fp32 convs, one thread per output, the
+        # spatial broadcast materialised).  On the record so that the cost of that path is a number, not a guess; no roofline claim.
+        try:
+            from iodine_amd import IODINE
+            from iodine_amd.model import arch_namespace
+            a5 = arch_namespace(64, 5, 7, 128, (64, 4, 256), (64, 4), kernels=(3, 5))
+            m5 = IODINE(a5)
+            sh5 = {k: tuple(v.shape) for k, v in m5.state_dict().items()}
+            m5.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(sh5, seed=0).items()})
+            m5 = m5.to(device)
+            m5.manual_seed(7)
+            b5 = 4
+            x5 = torch.from_numpy(synth.make_images(b5, 128, seed=0)).to(device)
+            rec = dict(workload=f'CLEVR6 128x128 shapes with DEC.KERNEL_SIZE 5 (64 channels), K=7, T=5, batch {b5}, 1 GPU', steps=2,
+                       path='generic fallback (kernels_generic.hip): correctness path, not tuned')
+            for md in ('train', 'infer'):
+                st5, _ = make_step(m5, x5, md)
+                st5()
+                d5 = timed(st5, 2) / 2
+                rec[f'{md}_ms'] = round(d5 * 1e3, 3)
+                rec[f'{md}_iters_per_s'] = round(b5 * 5 / d5, 1)
+                del st5
+            # the same batch on the tuned path (KERNEL_SIZE 3): what the fallback costs relative to the MFMA kernels
+            m3, _, _ = build_model('clevr6', 7, 5, device)
+            m3.manual_seed(7)
+            for md in ('train', 'infer'):
+                st3, _ = make_step(m3, x5, md)
+                st3()
+                d3 = timed(st3, 2) / 2
+                rec[f'{md}_ms_kernel_size_3_same_batch'] = round(d3 * 1e3, 3)
+                del st3
+            rec['slowdown_vs_kernel_size_3'] = dict(train=round(rec['train_ms'] / rec['train_ms_kernel_size_3_same_batch'], 1),
+                                                    infer=round(rec['infer_ms'] / rec['infer_ms_kernel_size_3_same_batch'], 1))
+            side['default_dec_kernel5'] = rec
+            del m5, m3, x5
+            torch.cuda.empty_cache()
+        except Exception as e:                      # noqa: BLE001 - a side measurement must not break the bench line
+            side['default_dec_kernel5'] = dict(error=f'{type(e).__name__}: {e}')
         out['configs'] = side
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -180,7 +180,7 @@ hipError_t launch_pixel_pass1(hipStream_t st, const float* x4, const float* dec,
 hipError_t launch_pixel_finalize(hipStream_t st, const double* part, int B, int K, int P, int use_ln,
                                  float* lnstat, float* ll_img);
 hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec, const float* lnstat,
-                              const float* lin, float* enc, int B, int K, int S, float sigma, float* enc_sh = nullptr);
+                              const float* lin, float* enc, int B, int K, int S, float sigma, float* enc_sh = nullptr, unsigned chmask = 0x1ffffu);
 hipError_t launch_final_out(hipStream_t st, const float* dec, float* pred, float* mask, float* mean, float* logits,
                             int B, int K, int P);
 // kernels_misc.hip

@@ -115,6 +115,7 @@ struct iodine_handle {
     // iodine.py:277-340); n_in < 17 -> weights expanded to / gradients gathered from the 17 internal channels
     int n_in = 17;
     int enc_map[17];
+    unsigned enc_chmask = 0x1ffffu;                        // bit c: internal channel c is part of the encoding (absent ones are written as 0)
     float *ref_w17 = nullptr, *ref_g17 = nullptr;          // [Cr][17][kr * kr]
     // GENERIC fallback path (kernels_generic.hip): KERNEL_SIZE other than 3 or CONV_CHAN other than 32 / 64.  Weights re-packed to
     // [tap][ci][co]; the broadcast layer is materialised; nothing of the tuned conv kernels runs.
@@ -672,7 +673,7 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
     const bool split = refine_split_on(h);     // (training: iodine_train_forward records the form in h->fwd_split - host state must
                                                //  not be written here, a hipGraph replay does not execute this body)
     PROF(h, st, "pixel_pass2", launch_pixel_pass2(st, b.x4, b.dec_out, b.lnstat, h->lin, split ? b.enck[i] : b.enc[i], B, h->K, h->S,
-                                                  (float)h->cfg.sigma, split ? b.encs[i] : nullptr));
+                                                  (float)h->cfg.sigma, split ? b.encs[i] : nullptr, h->enc_chmask));
     int s = h->S;
     const float* in = b.enc[i];
     for (int l = 0; l < h->Dr; ++l) {
@@ -799,6 +800,8 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
         for (const auto& e : ent)
             if (cfg->encoding & e.bit) for (int q = 0; q < e.count; ++q) h->enc_map[h->n_in++] = e.first + q;
         for (int j = h->n_in; j < 17; ++j) h->enc_map[j] = -1;
+        h->enc_chmask = 0;
+        for (int j = 0; j < h->n_in; ++j) h->enc_chmask |= 1u << h->enc_map[j];
     }
     build_param_table(h);
 

@@ -243,8 +243,12 @@ template <int K, bool SPLIT>
 __global__ __launch_bounds__(PIX_BLOCK)
 void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict__ dec,
                         const float* __restrict__ lnstat, const float* __restrict__ lin, float* __restrict__ enc,
-                        float* __restrict__ enc_sh, int P, int S, int ppb, float inv2s2, float invs2, float lconst)
+                        float* __restrict__ enc_sh, int P, int S, int ppb, float inv2s2, float invs2, float lconst, unsigned chmask)
 {
+    // ARCH.ENCODING subsets: bit c of chmask = internal channel c (code order of iodine.py:277-340) is part of the encoding.  An absent
+    // channel is written as 0 - its weights are zero too (enc_expand_weights), but 0 * Inf would still be NaN, and the reference never
+    // computes such a channel (e.g. the leave-one-out likelihood, a cancellation divided by 1e-5).
+    auto on = [&](int c, float v) { return (chmask >> c) & 1u ? v : 0.f; };
     const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
     const float4* dec_b = dec + (size_t)b * K * P;
     __shared__ float s_ln[K * 8];
@@ -270,8 +274,8 @@ void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict_
         const float cx = lin[p % S], cy = lin[p / S];
         if constexpr (SPLIT) {
             float4* tw8 = reinterpret_cast<float4*>(s_tr[wv] + lane * 8);
-            tw8[0] = make_float4(xv.x, xv.y, xv.z, (t.like - s_ln[6]) * s_ln[7]);      // LN statistics of slot 0: the same for every slot
-            tw8[1] = make_float4(cx, cy, 0.f, 0.f);
+            tw8[0] = make_float4(on(0, xv.x), on(1, xv.y), on(2, xv.z), on(13, (t.like - s_ln[6]) * s_ln[7]));   // LN statistics of slot 0: the same for every slot
+            tw8[1] = make_float4(on(15, cx), on(16, cy), 0.f, 0.f);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -289,9 +293,9 @@ void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict_
                 const float* ln = s_ln + k * 8;
                 const float loo = t.loo[k];
                 float4* tw12 = reinterpret_cast<float4*>(s_tr[wv] + lane * 12);
-                tw12[0] = make_float4(t.mu[k][0], t.mu[k][1], t.mu[k][2], t.m[k]);
-                tw12[1] = make_float4(t.logit[k], t.pk[k] / psum, (t.g1[k][0] - ln[0]) * ln[1], (t.g1[k][1] - ln[0]) * ln[1]);
-                tw12[2] = make_float4((t.g1[k][2] - ln[0]) * ln[1], (t.g2[k] - ln[2]) * ln[3], (loo - ln[4]) * ln[5], 0.f);
+                tw12[0] = make_float4(on(3, t.mu[k][0]), on(4, t.mu[k][1]), on(5, t.mu[k][2]), on(6, t.m[k]));
+                tw12[1] = make_float4(on(7, t.logit[k]), on(8, t.pk[k] / psum), on(9, (t.g1[k][0] - ln[0]) * ln[1]), on(10, (t.g1[k][1] - ln[0]) * ln[1]));
+                tw12[2] = make_float4(on(11, (t.g1[k][2] - ln[0]) * ln[1]), on(12, (t.g2[k] - ln[2]) * ln[3]), on(14, (loo - ln[4]) * ln[5]), 0.f);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -311,12 +315,12 @@ void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict_
         for (int k = 0; k < K; ++k) {
             const float* ln = s_ln + k * 8;
             const float loo = t.loo[k];
-            tw[0] = make_float4(xv.x, xv.y, xv.z, t.mu[k][0]);
-            tw[1] = make_float4(t.mu[k][1], t.mu[k][2], t.m[k], t.logit[k]);
-            tw[2] = make_float4(t.pk[k] / psum, (t.g1[k][0] - ln[0]) * ln[1], (t.g1[k][1] - ln[0]) * ln[1],
-                                (t.g1[k][2] - ln[0]) * ln[1]);
-            tw[3] = make_float4((t.g2[k] - ln[2]) * ln[3], (t.like - ln[6]) * ln[7], (loo - ln[4]) * ln[5], cx);
-            tw[4] = make_float4(cy, 0.f, 0.f, 0.f);
+            tw[0] = make_float4(on(0, xv.x), on(1, xv.y), on(2, xv.z), on(3, t.mu[k][0]));
+            tw[1] = make_float4(on(4, t.mu[k][1]), on(5, t.mu[k][2]), on(6, t.m[k]), on(7, t.logit[k]));
+            tw[2] = make_float4(on(8, t.pk[k] / psum), on(9, (t.g1[k][0] - ln[0]) * ln[1]), on(10, (t.g1[k][1] - ln[0]) * ln[1]),
+                                on(11, (t.g1[k][2] - ln[0]) * ln[1]));
+            tw[3] = make_float4(on(12, (t.g2[k] - ln[2]) * ln[3]), on(13, (t.like - ln[6]) * ln[7]), on(14, (loo - ln[4]) * ln[5]), on(15, cx));
+            tw[4] = make_float4(on(16, cy), 0.f, 0.f, 0.f);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -402,7 +406,7 @@ hipError_t launch_pixel_finalize(hipStream_t st, const double* part, int B, int 
 }
 
 hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec, const float* lnstat,
-                              const float* lin, float* enc, int B, int K, int S, float sigma, float* enc_sh)
+                              const float* lin, float* enc, int B, int K, int S, float sigma, float* enc_sh, unsigned chmask)
 {
     IOD_XSKIP(8);
     const int P = S * S;
@@ -412,9 +416,9 @@ hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec,
     switch (K) {
 #define CASE(KK) case KK: \
         if (enc_sh) hipLaunchKernelGGL((pixel_pass2_kernel<KK, true>), dim3(nblk, B), dim3(PIX_BLOCK), 0, st, \
-            (const float4*)x4, (const float4*)dec, lnstat, lin, enc, enc_sh, P, S, ppb, inv2s2, invs2, lconst); \
+            (const float4*)x4, (const float4*)dec, lnstat, lin, enc, enc_sh, P, S, ppb, inv2s2, invs2, lconst, chmask); \
         else hipLaunchKernelGGL((pixel_pass2_kernel<KK, false>), dim3(nblk, B), dim3(PIX_BLOCK), 0, st, \
-            (const float4*)x4, (const float4*)dec, lnstat, lin, enc, enc_sh, P, S, ppb, inv2s2, invs2, lconst); \
+            (const float4*)x4, (const float4*)dec, lnstat, lin, enc, enc_sh, P, S, ppb, inv2s2, invs2, lconst, chmask); \
         break;
         FOR_EACH_K(CASE)
 #undef CASE

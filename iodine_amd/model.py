@@ -14,7 +14,9 @@ Extensions over the reference: every entry point takes an optional ``eps`` tenso
 (T+1, B, K, L) replacing the ``torch.randn_like`` draws of ``Gaussian.sample``
 (iodine.py:632) in call order, so that results can be compared with the CPU oracle.  Without
 ``eps`` the draws come from the library's own counter-based generator (Philox4x32-10,
-``iodine_randn``; seed with ``model.manual_seed``) - no ATen kernel runs on the product path.
+``iodine_randn``; seed with ``model.manual_seed``) - no ATen COMPUTE kernel runs on the product path (what a kernel trace
+still shows from ATen are autograd's own fills: ``loss.backward()`` seeds the scalar loss gradient with ``ones_like`` and
+``zero_grad`` / the flat gradient buffer are fills - a handful of 5-us launches per training step, none of them arithmetic of the model).
 """
 from __future__ import annotations
 

@@ -84,10 +84,13 @@ def main():
     tag = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith('-') else 'r03'
     cfg = 'dsprites' if 'dsprites' in sys.argv[2:] else 'clevr6'
     from iodine_amd.build import source_digest
-    try:
-        commit = subprocess.run(['git', 'rev-parse', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip() or 'unknown'
-    except Exception:
-        commit = 'unknown'
+    # the GPU box has no .git: the commit is handed over in the environment (tools/round_profiles.sh, IODINE_COMMIT=$(git rev-parse HEAD))
+    commit = os.environ.get('IODINE_COMMIT', '').strip()
+    if not commit:
+        try:
+            commit = subprocess.run(['git', 'rev-parse', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip() or 'unknown'
+        except Exception:
+            commit = 'unknown'
     fetch, names = per_launch(outdir, 'FETCH_SIZE')
     write, _ = per_launch(outdir, 'WRITE_SIZE')
     mfma, _ = per_launch(outdir, 'SQ_VALU_MFMA_BUSY_CYCLES')

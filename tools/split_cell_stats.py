@@ -12,8 +12,11 @@ range: r (x - mu) / sigma^2 under a saturated softmax), on trained and artificia
   * the histogram of log2 r over all elements,
   * per OUTPUT element of the consuming data-gradient conv: the share of its magnitude sum_k |w_k| |x_k| that comes from input elements
     with r < 2^-10 and with r < 2^-15,
-  * the resulting bound on the output's error relative to that magnitude, sum |w| |x| e(r) / sum |w| |x| with
-    e(r) = max(2^-22, 2^-37 / r) (+ 2^-22 for the weights' own split) - what the per-cell scale can cost in the worst case.
+  * the resulting bound on the output's error, sum |w| |x| e(r) with e(r) = max(2^-22, 2^-37 / r) (+ 2^-22 for the weights' own split),
+    (a) relative to the output's own magnitude sum |w| |x| (meaningless where the output is itself far below its surroundings) and
+    (b) relative to the LARGEST such magnitude in the 3 x 3 cells around the output - the scale every consumer of the tensor works at
+    (the next conv takes its tile scale from exactly that neighbourhood; weight gradients, class sums and the ELBO add the
+    neighbourhood's small and large values up in fp32, where anything below 2^-24 of the running sum is lost in the reference too).
 
 usage: python tools/split_cell_stats.py [fixture:ckpt:sharpen ...]     (default: the trained-weights cases of tests/test_gpu_trained_weights.py)
 """
@@ -68,7 +71,7 @@ def analyse(name, ckpt, sharpen):
     post = [(tr['post_mean'].detach(), tr['post_logvar'].detach()) for tr in trace]
     hist = np.zeros(len(BINS) - 1)
     n_elem = 0
-    share10, share15, bound = [], [], []
+    share10, share15, bound, bound_cell = [], [], [], []
     sharp = []
     for i, (pm, plv) in enumerate(post):
         z = O.sample(pm, plv, eps[i])
@@ -104,13 +107,20 @@ def analyse(name, ckpt, sharpen):
             share10.append((s10[ok] / tot[ok]).flatten())
             share15.append((s15[ok] / tot[ok]).flatten())
             bound.append((eb[ok] / tot[ok] + 2.0 ** -22).flatten())
-    s10, s15, bd = torch.cat(share10), torch.cat(share15), torch.cat(bound)
+            N_, C_, S_, _ = tot.shape
+            ch, cw = min(CELL_H, S_), min(CELL_W, S_)
+            tmax = tot.reshape(N_, C_, S_ // ch, ch, S_ // cw, cw).amax(dim=(1, 3, 5))                 # (N, cells y, cells x)
+            tmax = F.max_pool2d(tmax[:, None], 3, stride=1, padding=1)[:, 0]                          # 3 x 3 cells around: the kernel's tile scale
+            tmax = tmax[:, None, :, None, :, None].expand(N_, C_, S_ // ch, ch, S_ // cw, cw).reshape(N_, C_, S_, S_)
+            okc = tmax > 0
+            bound_cell.append((eb[okc] / tmax[okc] + 2.0 ** -22).flatten())
+    s10, s15, bd, bc = torch.cat(share10), torch.cat(share15), torch.cat(bound), torch.cat(bound_cell)
 
     def q(v, f):
         return float(torch.quantile(v[:: max(1, v.numel() // 2_000_000)], f))
     row = dict(case=f'{name} ckpt {ckpt} x{sharpen:g}', sharp=float(np.mean(sharp[-1:])), hist=hist / n_elem,
                s10=(q(s10, 0.5), q(s10, 0.999), float(s10.max())), s15=(q(s15, 0.5), q(s15, 0.999), float(s15.max())),
-               bound=(q(bd, 0.5), q(bd, 0.999), float(bd.max())))
+               bound=(q(bd, 0.5), q(bd, 0.999), float(bd.max())), bound_cell=(q(bc, 0.5), q(bc, 0.999), float(bc.max())))
     return row
 
 
@@ -127,11 +137,11 @@ def main():
         print(f"| {r['case']} | {r['sharp']:.3f} | " + ' | '.join(f'{v:.2e}' if 0 < v < 1e-3 else f'{v:.4f}' for v in r['hist']) + ' |')
     print()
     print('| case | share of an output from r < 2^-10: median / 99.9 % / max | from r < 2^-15: median / 99.9 % / max | error bound relative to '
-          'sum of magnitudes: median / 99.9 % / max |')
-    print('|---|---|---|---|')
+          'the output\'s own sum of magnitudes: median / 99.9 % / max | error bound relative to the largest sum of magnitudes in the 3 x 3 cells around the output: median / 99.9 % / max |')
+    print('|---|---|---|---|---|')
     for r in rows:
         print(f"| {r['case']} | " + ' / '.join(f'{v:.1e}' for v in r['s10']) + ' | ' + ' / '.join(f'{v:.1e}' for v in r['s15']) + ' | '
-              + ' / '.join(f'{v:.1e}' for v in r['bound']) + ' |')
+              + ' / '.join(f'{v:.1e}' for v in r['bound']) + ' | ' + ' / '.join(f'{v:.1e}' for v in r['bound_cell']) + ' |')
 
 
 if __name__ == '__main__':
