@@ -576,8 +576,9 @@ def main():
             del m2, x2
             torch.cuda.empty_cache()
         # The reference's DEFAULT decoder kernel size (lib/config/defaults.py:100, configs/test.yaml:40,44: DEC.KERNEL_SIZE 5) at the
-        # CLEVR shapes: runs on the library's generic fallback path (kernels_generic.hip: plain fp32 convs, one thread per output, the
-        # spatial broadcast materialised).  On the record so that the cost of that path is a number, not a guess; no roofline claim.
+        # CLEVR shapes: runs on the library's generic path (kernels_generic.hip: exact-fp32 MFMA convs with an LDS-resident weight slice
+        # for the stride-1 decoder since round 4, scalar kernels for the stride-2 refinement stack, the spatial broadcast
+        # materialised).  On the record so that the cost of that path is a number, not a guess; no roofline claim.
         try:
             from iodine_amd import IODINE
             from iodine_amd.model import arch_namespace
@@ -590,7 +591,7 @@ def main():
             b5 = 4
             x5 = torch.from_numpy(synth.make_images(b5, 128, seed=0)).to(device)
             rec = dict(workload=f'CLEVR6 128x128 shapes with DEC.KERNEL_SIZE 5 (64 channels), K=7, T=5, batch {b5}, 1 GPU', steps=2,
-                       path='generic fallback (kernels_generic.hip): correctness path, not tuned')
+                       path='generic path (kernels_generic.hip): exact-fp32 MFMA decoder convs (16x16x4 / 32x32x2), scalar stride-2 refinement convs')
             for md in ('train', 'infer'):
                 st5, _ = make_step(m5, x5, md)
                 st5()

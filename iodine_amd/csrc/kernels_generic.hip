@@ -3,10 +3,14 @@
 // lib/config/defaults.py:100; configs/test.yaml:40,44) and CONV_CHAN other than 32 / 64.  Reference call sites: nn.Conv2d + F.elu of
 // MultiLayerConv (iodine.py:570-594), the output conv (iodine.py:422,435), SpatialBroadcast (iodine.py:505-540) and their autograd.
 //
-// These kernels are written for correctness, not speed: one thread per output element, plain fp32 FMAs in a fixed order
-// (deterministic), no MFMA, no LDS tiling.  The spatial-broadcast layer is MATERIALISED here ([N][P][L+2]) and convolved like any
+// Two tiers.  Stride-1 convs (the decoder: ~96 % of the FLOPs) run on exact-fp32 MFMA kernels since round 4 (further down: LDS-resident
+// weight slice per 16 output channels, 16 x 16 pixel tiles, v_mfma_f32_16x16x4_f32; weight gradient on v_mfma_f32_32x32x2_f32) whenever
+// the weight slice fits LDS - 5 x 5 x 64 channels does, 7 x 7 up to 32 channels.  Everything else (stride 2 = the refinement stack,
+// larger slices) runs on the scalar kernels right below: one thread per output element, plain fp32 FMAs in a fixed order, written for
+// correctness.  All of it is deterministic.  The spatial-broadcast layer is MATERIALISED here ([N][P][L+2]) and convolved like any
 // other layer; its gradient wrt z is the pixel sum of the data gradient.  Every shipped / benchmarked configuration stays on the
-// tuned path (iodine_api.cpp: `generic` is false for KERNEL_SIZE 3 with 32 / 64 channels).
+// tuned path (iodine_api.cpp: `generic` is false for KERNEL_SIZE 3 with 32 / 64 channels).  Measured (MI355X, CLEVR shapes with
+// DEC.KERNEL_SIZE 5, batch 4): training step 4977 -> 206 ms, reconstruct 2317 -> 96 ms against the scalar tier.
 //
 // Layouts: activations NHWC with a channel stride `ldc` >= Ci (the 17-of-20 refinement input); weights re-packed at set_params to
 // [tap = ky * k + kx][ci][co] (co fastest: coalesced over the threads of a pixel); stride s in {1, 2}, padding k / 2.
@@ -161,7 +165,198 @@ __global__ void gen_identity_kernel(float* __restrict__ m, int rows, int L)
     m[idx] = (idx / L) == (idx % L) ? 1.f : 0.f;
 }
 
+
+// =====================================================================================================================================
+// Round 4: fp32-MFMA forms of the stride-1 generic convs (the decoder with the reference's DEFAULT DEC.KERNEL_SIZE 5,
+// lib/config/defaults.py:100): exact fp32 products (v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32 = fmaf chains, 157 TF/s peak), any
+// odd kernel size whose weight slice fits LDS, any channel counts and image sizes (bounds are checked per element).  The scalar kernels
+// above stay for stride 2 (refinement stack, 3.6 % of the FLOPs) and for slices that do not fit (KERNEL_SIZE 7 with >= 36 channels).
+//
+// Forward / data gradient (one kernel): implicit GEMM, M = 16 pixels of a tile row, N = 16 output channels, K = 4 channels of one tap.
+// A persistent block owns ONE group of 16 output channels and keeps its whole weight slice [tap][reduction channel][16] in LDS
+// (KS^2 x C x 64 B: 102 KB for 5 x 5 x 64) for all the tiles it processes - the weights are what a 5 x 5 conv re-reads most; the input
+// halo of a 16 x 16 tile is staged per 4-channel chunk (double-buffered, one barrier per chunk = per 100 MFMAs of a wave).
+//   W(tap, k, n) = wt[tapidx * sT + k * sK + n * sN]:  forward tapidx = tap, (sT, sK, sN) = (Ci Co, Co, 1) on the pack [tap][ci][co];
+//   data gradient: the correlation with the flipped kernel, tapidx = KS^2 - 1 - tap, reduction over co, (sT, sK, sN) = (ldi Co, 1, Co).
+// =====================================================================================================================================
+template <int KS>
+__global__ __launch_bounds__(256)
+void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+                          const float* __restrict__ aux, float* __restrict__ out, int S, int Ck, int ldin, int Cn, int ldout,
+                          int flip, int sT, int sK, int sN, int elu, int ncg, int tiles, int ntiles)
+{
+    constexpr int KK = KS * KS, PAD = KS / 2, TW = 16 + KS - 1, NPX = TW * TW;
+    constexpr int NLD = (NPX * 4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem_g[];
+    const int Ckp = (Ck + 3) & ~3, nchunk = Ckp >> 2;
+    float* s_w = smem_g;                                      // [KK][Ckp][16]
+    float* s_in = smem_g + (size_t)KK * Ckp * 16;             // [2][NPX][4]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cg = blockIdx.x % ncg, pb = blockIdx.x / ncg, nb = gridDim.x / ncg;
+    if (pb >= nb) return;                                     // (grid = ncg * nb exactly; defensive)
+    // ---- this block's weight slice -> LDS, once ----
+    for (int e = tid; e < KK * Ckp * 16; e += 256) {
+        const int n = e & 15, k = (e >> 4) % Ckp, tap = (e >> 4) / Ckp;
+        const int co = cg * 16 + n;
+        float v = 0.f;
+        if (k < Ck && co < Cn) v = wt[(size_t)(flip ? KK - 1 - tap : tap) * sT + (size_t)k * sK + (size_t)co * sN];
+        s_w[e] = v;
+    }
+    const int m = lane & 15, kq = lane >> 4;
+    float rin[NLD];
+    for (int t = pb; t < ntiles; t += nb) {
+        const int tx = t % tiles, ty = (t / tiles) % tiles, n = t / (tiles * tiles);
+        const float* in_n = in + (size_t)n * S * S * ldin;
+        auto fetch = [&](int c) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int e = tid + 256 * i;
+                const int px = e >> 2, k = e & 3;
+                const int gy = ty * 16 - PAD + px / TW, gx = tx * 16 - PAD + px % TW, ch = c * 4 + k;
+                const bool ok = e < NPX * 4 && (unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S && ch < Ck;
+                rin[i] = ok ? in_n[((size_t)gy * S + gx) * ldin + ch] : 0.f;
+            }
+        };
+        auto commit = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int e = tid + 256 * i;
+                if (e < NPX * 4) s_in[buf * NPX * 4 + e] = rin[i];
+            }
+        };
+        f32x4 acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                                      // weights staged / previous tile's last chunk consumed
+        fetch(0);
+        commit(0);
+        __syncthreads();
+        for (int c = 0; c < nchunk; ++c) {
+            if (c + 1 < nchunk) fetch(c + 1);                 // in flight under this chunk's MFMAs
+            const float* si = s_in + (c & 1) * NPX * 4;
+            const float* sw = s_w + (size_t)(c * 4 + kq) * 16 + m;
+            for (int tap = 0; tap < KK; ++tap) {
+                const int ky = tap / KS, kx = tap % KS;
+                const float b = sw[(size_t)tap * Ckp * 16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = si[((4 * wv + r + ky) * TW + m + kx) * 4 + kq];
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[r], 0, 0, 0);
+                }
+            }
+            if (c + 1 < nchunk) commit((c + 1) & 1);
+            __syncthreads();
+        }
+        // D[pixel column 4 kq + i][channel m] of tile row 4 wv + r
+        const int co = cg * 16 + m;
+        if (co < Cn) {
+            const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = ty * 16 + 4 * wv + r;
+                if (y >= S) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int x = tx * 16 + 4 * kq + i;
+                    if (x >= S) continue;
+                    const size_t o = (((size_t)n * S + y) * S + x) * ldout + co;
+                    float v = acc[r][i] + bv;
+                    if (elu) v = gen_elu(v);
+                    if (aux) { const float a = aux[o]; v *= a > 0.f ? 1.f : a + 1.f; }
+                    out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// Weight gradient, stride 1: dW[tap][ci][co] = sum_px in[px + tap][ci] * dout[px][co] as D[32 ci x 32 co] += A[32 x 2 px] B[2 px x 32]
+// (v_mfma_f32_32x32x2_f32); a block owns ONE tap and one of GEN_WGRAD_SLICES row ranges, its four waves the (ci tile, co tile) pairs;
+// both operands are read straight from global memory (4-byte loads, coalesced over the channels, sixteen in flight per lane).  Partial
+// tiles in the layout of gen_conv_wgrad_reduce_kernel; the bias partial comes from the blocks of tap 0.
+template <int KS>
+__global__ __launch_bounds__(256)
+void gen_wgrad_mfma_kernel(const float* __restrict__ in, const float* __restrict__ dout, float* __restrict__ part, int N, int S, int Ci,
+                           int ldc, int Co, int nslice)
+{
+    constexpr int KK = KS * KS, PAD = KS / 2;
+    const int tap = blockIdx.x % KK, slice = (blockIdx.x / KK) % nslice, pgrp = blockIdx.x / (KK * nslice);
+    const int ky = tap / KS, kx = tap % KS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, kh = lane >> 5;
+    const int nct = (Co + 31) / 32, npair = ((Ci + 31) / 32) * nct;
+    const int pair = pgrp * 4 + wv;
+    const int per = KK * Ci * Co + Co;
+    if (pair >= npair) return;
+    const int cit = pair / nct, cot = pair % nct;
+    const int ci = cit * 32 + li, co = cot * 32 + li;
+    const bool civ = ci < Ci, cov = co < Co;
+    const long long R = (long long)N * S;
+    const long long r0 = R * slice / nslice, r1 = R * (slice + 1) / nslice;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    float bsum = 0.f;
+    for (long long row = r0; row < r1; ++row) {
+        const int y = (int)(row % S);
+        const long long n = row / S;
+        const int iy = y + ky - PAD;
+        const bool rowv = (unsigned)iy < (unsigned)S;
+        const float* ip = in + ((size_t)n * S + (rowv ? iy : 0)) * S * (size_t)ldc + ci;
+        const float* dp = dout + ((size_t)n * S + y) * S * (size_t)Co + co;
+        for (int x0 = 0; x0 < S; x0 += 16) {
+            float a[8], b[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int x = x0 + 2 * j + kh, ix = x + kx - PAD;
+                a[j] = (civ && rowv && x < S && (unsigned)ix < (unsigned)S) ? ip[(size_t)ix * ldc] : 0.f;
+                b[j] = (cov && x < S) ? dp[(size_t)x * Co] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+                bsum += b[j];
+            }
+        }
+    }
+    float* pw = part + (size_t)slice * per;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int cr = cit * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+        if (cr < Ci && cov) pw[((size_t)tap * Ci + cr) * Co + co] = acc[q];
+    }
+    if (tap == 0 && cit == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (kh == 0 && cov) pw[(size_t)KK * Ci * Co + co] = bsum;
+    }
+}
+
 inline unsigned gen_blocks(size_t total) { return (unsigned)((total + 255) / 256); }
+
+// LDS bytes of the MFMA form: weight slice + two halo chunks; 0 = does not apply (stride 2, or the slice does not fit)
+inline size_t gen_mfma_lds(int k, int Ck, int s)
+{
+    if (s != 1 || (k != 3 && k != 5 && k != 7)) return 0;
+    const int Ckp = (Ck + 3) & ~3, TW = 16 + k - 1;
+    const size_t b = ((size_t)k * k * Ckp * 16 + (size_t)2 * TW * TW * 4) * sizeof(float);
+    return b <= 160 * 1024 ? b : 0;
+}
+
+template <int KS>
+hipError_t gen_mfma_launch(hipStream_t st, const float* in, const float* wt, const float* bias, const float* aux, float* out, int N, int S,
+                           int Ck, int ldin, int Cn, int ldout, int flip, int sT, int sK, int sN, int elu, size_t lds)
+{
+    static std::atomic<unsigned> attr_devs{0};
+    if (hipError_t e = iod_set_max_lds((const void*)gen_conv_mfma_kernel<KS>, 160 * 1024, attr_devs); e != hipSuccess) return e;
+    int n_cu = 0;
+    if (hipError_t e = iod_cu_count(&n_cu); e != hipSuccess) return e;
+    const int ncg = (Cn + 15) / 16, tiles = (S + 15) / 16, ntiles = N * tiles * tiles;
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int nb = std::max(1, std::min(ntiles, per_cu * n_cu / ncg));
+    hipLaunchKernelGGL((gen_conv_mfma_kernel<KS>), dim3(ncg * nb), dim3(256), lds, st, in, wt, bias, aux, out, S, Ck, ldin, Cn, ldout, flip,
+                       sT, sK, sN, elu, ncg, tiles, ntiles);
+    return hipGetLastError();
+}
+
 
 }  // namespace
 
@@ -181,6 +376,12 @@ hipError_t launch_gen_broadcast(hipStream_t st, const float* z, const float* lin
 hipError_t launch_gen_conv_fwd(hipStream_t st, const float* in, const float* wt, const float* bias, float* out, int N, int Si, int Ci,
                                int ldc, int Co, int k, int s, int elu)
 {
+    if (const size_t lds = gen_mfma_lds(k, Ci, s)) {
+        // [tap][ci][co] pack: W(tap, k = ci, n = co)
+        if (k == 3) return gen_mfma_launch<3>(st, in, wt, bias, nullptr, out, N, Si, Ci, ldc, Co, Co, 0, Ci * Co, Co, 1, elu, lds);
+        if (k == 5) return gen_mfma_launch<5>(st, in, wt, bias, nullptr, out, N, Si, Ci, ldc, Co, Co, 0, Ci * Co, Co, 1, elu, lds);
+        return gen_mfma_launch<7>(st, in, wt, bias, nullptr, out, N, Si, Ci, ldc, Co, Co, 0, Ci * Co, Co, 1, elu, lds);
+    }
     const int So = (Si - 1) / s + 1;
     const size_t total = (size_t)N * So * So * Co;
     hipLaunchKernelGGL(gen_conv_fwd_kernel, dim3(gen_blocks(total)), dim3(256), 0, st, in, wt, bias, out, Si, So, Ci, ldc, Co, k, s, elu, total);
@@ -190,6 +391,12 @@ hipError_t launch_gen_conv_fwd(hipStream_t st, const float* in, const float* wt,
 hipError_t launch_gen_conv_dgrad(hipStream_t st, const float* dout, const float* wt, const float* aux, float* din, int N, int Si, int Ci,
                                  int ldi, int Co, int k, int s)
 {
+    if (const size_t lds = gen_mfma_lds(k, Co, s)) {
+        // correlation of dout with the flipped kernel: reduction over co, W(tap, k = co, n = ci) = wt[(KK - 1 - tap)][ci][co]
+        if (k == 3) return gen_mfma_launch<3>(st, dout, wt, nullptr, aux, din, N, Si, Co, Co, Ci, ldi, 1, ldi * Co, 1, Co, 0, lds);
+        if (k == 5) return gen_mfma_launch<5>(st, dout, wt, nullptr, aux, din, N, Si, Co, Co, Ci, ldi, 1, ldi * Co, 1, Co, 0, lds);
+        return gen_mfma_launch<7>(st, dout, wt, nullptr, aux, din, N, Si, Co, Co, Ci, ldi, 1, ldi * Co, 1, Co, 0, lds);
+    }
     const int So = (Si - 1) / s + 1;
     const size_t total = (size_t)N * Si * Si * Ci;
     hipLaunchKernelGGL(gen_conv_dgrad_kernel, dim3(gen_blocks(total)), dim3(256), 0, st, dout, wt, aux, din, Si, So, Ci, ldi, Co, k, s, total);
@@ -203,6 +410,16 @@ hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* d
 {
     const int So = (Si - 1) / s + 1;
     const size_t per = (size_t)k * k * Ci * Co + Co;
+    if (s == 1 && (k == 3 || k == 5 || k == 7)) {
+        const int npair = ((Ci + 31) / 32) * ((Co + 31) / 32), ngrp = (npair + 3) / 4;
+        const dim3 grid((unsigned)(k * k * GEN_WGRAD_SLICES * ngrp));
+        if (k == 3) hipLaunchKernelGGL((gen_wgrad_mfma_kernel<3>), grid, dim3(256), 0, st, in, dout, scratch, N, Si, Ci, ldc, Co, GEN_WGRAD_SLICES);
+        else if (k == 5) hipLaunchKernelGGL((gen_wgrad_mfma_kernel<5>), grid, dim3(256), 0, st, in, dout, scratch, N, Si, Ci, ldc, Co, GEN_WGRAD_SLICES);
+        else hipLaunchKernelGGL((gen_wgrad_mfma_kernel<7>), grid, dim3(256), 0, st, in, dout, scratch, N, Si, Ci, ldc, Co, GEN_WGRAD_SLICES);
+        hipLaunchKernelGGL(gen_conv_wgrad_reduce_kernel, dim3(gen_blocks(per)), dim3(256), 0, st, scratch, GEN_WGRAD_SLICES, Ci, Ci_dst, Co,
+                           k * k, alpha, gw, gb);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(gen_conv_wgrad_partial_kernel, dim3(gen_blocks(per * GEN_WGRAD_SLICES)), dim3(256), 0, st, in, dout, scratch, N, Si,
                        So, Ci, ldc, Co, k, s, GEN_WGRAD_SLICES);
     hipLaunchKernelGGL(gen_conv_wgrad_reduce_kernel, dim3(gen_blocks(per)), dim3(256), 0, st, scratch, GEN_WGRAD_SLICES, Ci, Ci_dst, Co,
