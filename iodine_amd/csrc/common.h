@@ -316,6 +316,10 @@ hipError_t launch_conv3x3_s2_dgrad_f16x3(hipStream_t st, const float* d, const v
 hipError_t launch_conv3x3_s2_wgrad_f16x3(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
                                          int S, int ci_real, int nco, int* nparts, int* cipad, int* nbias_parts,
                                          const float* a2 = nullptr, int kdiv = 0);
+// kernels_refws.hip: weight-stationary stride-2 conv C -> C + bias + ELU (refinement layers 1 ..), wpk = launch_pack_conv_weights_ws(w, C, 0)
+bool conv3x3_s2ws_ok(int S, int c);
+hipError_t launch_conv3x3_s2ws_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias, float* out,
+                                     int N, int S, int c);
 // kernels_refbwd.hip: data gradient of refinement layer 1 + weight / bias gradient of layer 0 in one pass (dpre0 never stored)
 bool refine_bwd01_ok(int S, int c);
 hipError_t launch_refine_bwd01(hipStream_t st, const float* rd1, const void* wpk, const float* wmeta, const float* act0, const float* enck,

@@ -110,6 +110,8 @@ struct iodine_handle {
     float *ref_wk = nullptr, *ref_wsh = nullptr;           // split first layer: weights in the internal channel order [Cr][12][9], [Cr][8][9]
     float *ref_wk16 = nullptr, *ref_wsh16 = nullptr, *ref_wkmeta = nullptr, *ref_wshmeta = nullptr;   // and their packs
     float* ref_g20 = nullptr;                              // [Cr][20][9] weight gradient in the internal order
+    int refine_ws = 1;                                     // forward stride-2 convs of refinement layers 1 .. on the weight-stationary kernel (kernels_refws.hip)
+    std::vector<float*> ref_wsf, ref_wsf_meta;             // their weights in its register layout
     float *ref_w1ws = nullptr, *ref_w1ws_meta = nullptr;   // layer 1's weights in the register layout of the fused layer-1/0 backward
     // ARCH.ENCODING subsets: reference input channel j of the first refinement layer = internal channel enc_map[j] (code order of
     // iodine.py:277-340); n_in < 17 -> weights expanded to / gradients gathered from the 17 internal channels
@@ -685,6 +687,8 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
                                                              h->Cr));
             PROF(h, st, "refine_l0", launch_conv3x3_s2_f16x3(st, b.enck[i], h->ref_wk16, h->ref_wkmeta, h->ref_b[0], b.ract[i][0], N,
                                                              s, 12, h->Cr, b.rmap, h->K));
+        } else if (l > 0 && h->refine_ws && h->precision == 1 && refine_f16_ok(h) && conv3x3_s2ws_ok(s, h->Cr)) {
+            PROF(h, st, "refine_conv", launch_conv3x3_s2ws_f16x3(st, in, h->ref_wsf[l], h->ref_wsf_meta[l], h->ref_b[l], b.ract[i][l], N, s, h->Cr));
         } else if (h->precision == 1 && refine_f16_ok(h))
             PROF(h, st, l == 0 ? "refine_l0" : "refine_conv", launch_conv3x3_s2_f16x3(st, in, h->ref_wf16[l], h->ref_wmeta[l], h->ref_b[l],
                                                                b.ract[i][l], N, s, l == 0 ? 20 : h->Cr, h->Cr));
@@ -763,7 +767,7 @@ int run_graphed(iodine_handle* h, hipStream_t st, const std::vector<uintptr_t>& 
 std::vector<uintptr_t> graph_key(const iodine_handle* h, int entry, int batch, std::initializer_list<const void*> ptrs)
 {
     std::vector<uintptr_t> k = {(uintptr_t)entry, (uintptr_t)batch, (uintptr_t)h->stop_after, (uintptr_t)h->precision,
-                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)(h->head_fused | (h->refine_bwd_fused << 1)),
+                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)(h->head_fused | (h->refine_bwd_fused << 1) | (h->refine_ws << 2)),
                                 (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
     for (const void* p : ptrs) k.push_back((uintptr_t)p);
     return k;
@@ -857,6 +861,9 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     // split first layer: one 16-channel chunk each for the per-slot (12 real) and the per-image (8 real) channels
     ALLOC(h->ref_wk, (size_t)Cr * 12 * 9); ALLOC(h->ref_wsh, (size_t)Cr * 8 * 9); ALLOC(h->ref_g20, (size_t)Cr * 20 * 9);
     if (Cr % 32 == 0) { ALLOC(h->ref_w1ws, conv_ws_wpk_bytes(Cr) / 4); ALLOC(h->ref_w1ws_meta, (size_t)4); }
+    h->ref_wsf.assign(h->Dr, nullptr); h->ref_wsf_meta.assign(h->Dr, nullptr);
+    if (Cr == 64)
+        for (int l = 1; l < h->Dr; ++l) { ALLOC(h->ref_wsf[l], conv_ws_wpk_bytes(Cr) / 4); ALLOC(h->ref_wsf_meta[l], (size_t)4); }
     ALLOC(h->ref_w17, (size_t)Cr * 17 * h->kr * h->kr); ALLOC(h->ref_g17, (size_t)Cr * 17 * h->kr * h->kr);
     if (h->generic) {
         const int kkd = h->kd * h->kd, kkr = h->kr * h->kr;
@@ -1002,6 +1009,9 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         HIPCHK(h, launch_ref_split_weights(st, w0, Cr, h->ref_wk, h->ref_wsh));
         HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wk, Cr, 12, 16, Cr, 0, h->ref_wkmeta, h->ref_wk16));
         HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wsh, Cr, 8, 16, Cr, 0, h->ref_wshmeta, h->ref_wsh16));
+        if (Cr == 64)                                           // weight-stationary forward of layers 1 ..
+            for (int l = 1; l < h->Dr; ++l)
+                HIPCHK(h, launch_pack_conv_weights_ws(st, P("refine.mlc.layers." + std::to_string(l) + ".weight"), Cr, 0, h->ref_wsf_meta[l], h->ref_wsf[l]));
         if (h->Dr >= 2 && refine_bwd01_ok(h->S, Cr))           // fused layer-1 / layer-0 backward: W1 as the transposed conv's A operand
             HIPCHK(h, launch_pack_conv_weights_ws(st, P("refine.mlc.layers.1.weight"), Cr, 1, h->ref_w1ws_meta, h->ref_w1ws));
     }
@@ -1064,6 +1074,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "refine_split")) { h->refine_split = value != 0; return IODINE_OK; }
     if (!strcmp(key, "head_fused")) { h->head_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_bwd_fused")) { h->refine_bwd_fused = value != 0; return IODINE_OK; }
+    if (!strcmp(key, "refine_ws")) { h->refine_ws = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {
         if (value != 1 && value != 6) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1 (LDS-tiled) or 6 (weight-stationary)");
         if (((int)value == 6) != (h->variant == 6)) h->params_set = false;   // the other kernel's weight packs are not kept up to date
