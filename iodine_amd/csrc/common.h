@@ -316,6 +316,13 @@ hipError_t launch_conv3x3_s2_dgrad_f16x3(hipStream_t st, const float* d, const v
 hipError_t launch_conv3x3_s2_wgrad_f16x3(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
                                          int S, int ci_real, int nco, int* nparts, int* cipad, int* nbias_parts,
                                          const float* a2 = nullptr, int kdiv = 0);
+// kernels_refl0.hip: encoding (pixel_pass2's channels) + first refinement layer (conv k3 s2 17 -> 64, ELU) for all slots of an image
+size_t refine_l0_wpk_bytes(int O);
+hipError_t launch_refine_l0_pack(hipStream_t st, const float* w, int O, int cinw, float* meta, void* dst);
+bool refine_l0_fused_ok(int S, int c, int K);
+hipError_t launch_refine_l0_fused(hipStream_t st, const float* x4, const float* dec, const float* lnstat, const float* lin, const void* wk,
+                                  const float* wkmeta, const void* ws, const float* wsmeta, const float* bias, float* out, float* enck,
+                                  float* encs, int B, int K, int S, int c, float sigma, unsigned chmask);
 // kernels_refws.hip: weight-stationary stride-2 conv C -> C + bias + ELU (refinement layers 1 ..), wpk = launch_pack_conv_weights_ws(w, C, 0)
 bool conv3x3_s2ws_ok(int S, int c);
 hipError_t launch_conv3x3_s2ws_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias, float* out,

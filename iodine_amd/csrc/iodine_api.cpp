@@ -110,6 +110,8 @@ struct iodine_handle {
     float *ref_wk = nullptr, *ref_wsh = nullptr;           // split first layer: weights in the internal channel order [Cr][12][9], [Cr][8][9]
     float *ref_wk16 = nullptr, *ref_wsh16 = nullptr, *ref_wkmeta = nullptr, *ref_wshmeta = nullptr;   // and their packs
     float* ref_g20 = nullptr;                              // [Cr][20][9] weight gradient in the internal order
+    int refine_l0_fused = 1;                               // encoding + first refinement layer in one kernel (kernels_refl0.hip); 0: pixel_pass2 + two convs
+    void *ref_l0k = nullptr, *ref_l0s = nullptr; float *ref_l0kmeta = nullptr, *ref_l0smeta = nullptr;     // its weight packs
     int refine_ws = 1;                                     // forward stride-2 convs of refinement layers 1 .. on the weight-stationary kernel (kernels_refws.hip)
     std::vector<float*> ref_wsf, ref_wsf_meta;             // their weights in its register layout
     float *ref_w1ws = nullptr, *ref_w1ws_meta = nullptr;   // layer 1's weights in the register layout of the fused layer-1/0 backward
@@ -674,14 +676,24 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
     // split first layer: the channels every slot of an image shares are written and convolved once per image
     const bool split = refine_split_on(h);     // (training: iodine_train_forward records the form in h->fwd_split - host state must
                                                //  not be written here, a hipGraph replay does not execute this body)
-    PROF(h, st, "pixel_pass2", launch_pixel_pass2(st, b.x4, b.dec_out, b.lnstat, h->lin, split ? b.enck[i] : b.enc[i], B, h->K, h->S,
-                                                  (float)h->cfg.sigma, split ? b.encs[i] : nullptr, h->enc_chmask));
+    // ... and with refine_l0_fused the encoding is not written at all (inference): one kernel from the decoder output to layer 0's output
+    const bool l0f = split && h->refine_l0_fused && refine_l0_fused_ok(h->S, h->Cr, h->K);
+    const bool keep_enc = save || h->stop_after >= 0;     // the backward / iodine_debug_copy("enc") read it
+    if (l0f)
+        PROF(h, st, "refine_l0f", launch_refine_l0_fused(st, b.x4, b.dec_out, b.lnstat, h->lin, h->ref_l0k, h->ref_l0kmeta, h->ref_l0s,
+                                                         h->ref_l0smeta, h->ref_b[0], b.ract[i][0], keep_enc ? b.enck[i] : nullptr,
+                                                         keep_enc ? b.encs[i] : nullptr, B, h->K, h->S, h->Cr, (float)h->cfg.sigma,
+                                                         h->enc_chmask));
+    else
+        PROF(h, st, "pixel_pass2", launch_pixel_pass2(st, b.x4, b.dec_out, b.lnstat, h->lin, split ? b.enck[i] : b.enc[i], B, h->K, h->S,
+                                                      (float)h->cfg.sigma, split ? b.encs[i] : nullptr, h->enc_chmask));
     int s = h->S;
     const float* in = b.enc[i];
     for (int l = 0; l < h->Dr; ++l) {
         if (h->generic) {
             PROF(h, st, "gen_conv", launch_gen_conv_fwd(st, in, h->gen_wref[l], h->ref_b[l], b.ract[i][l], N, s, l == 0 ? 17 : h->Cr,
                                                         l == 0 ? 20 : h->Cr, h->Cr, h->kr, 2, 1));
+        } else if (l == 0 && l0f) {
         } else if (l == 0 && split) {
             PROF(h, st, "refine_l0", launch_conv3x3_s2_f16x3(st, b.encs[i], h->ref_wsh16, h->ref_wshmeta, nullptr, b.rmap, B, s, 8,
                                                              h->Cr));
@@ -767,7 +779,7 @@ int run_graphed(iodine_handle* h, hipStream_t st, const std::vector<uintptr_t>& 
 std::vector<uintptr_t> graph_key(const iodine_handle* h, int entry, int batch, std::initializer_list<const void*> ptrs)
 {
     std::vector<uintptr_t> k = {(uintptr_t)entry, (uintptr_t)batch, (uintptr_t)h->stop_after, (uintptr_t)h->precision,
-                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)(h->head_fused | (h->refine_bwd_fused << 1) | (h->refine_ws << 2)),
+                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)(h->head_fused | (h->refine_bwd_fused << 1) | (h->refine_ws << 2) | (h->refine_l0_fused << 3)),
                                 (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
     for (const void* p : ptrs) k.push_back((uintptr_t)p);
     return k;
@@ -874,6 +886,12 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     }
     ALLOC(h->ref_wk16, (size_t)9 * 2 * 2 * Cr * 4); ALLOC(h->ref_wsh16, (size_t)9 * 2 * 2 * Cr * 4);
     ALLOC(h->ref_wkmeta, (size_t)4); ALLOC(h->ref_wshmeta, (size_t)4);
+    if (Cr % 16 == 0) {
+        float *pk = nullptr, *ps = nullptr;
+        ALLOC(pk, refine_l0_wpk_bytes(Cr) / 4); ALLOC(ps, refine_l0_wpk_bytes(Cr) / 4);
+        h->ref_l0k = pk; h->ref_l0s = ps;
+        ALLOC(h->ref_l0kmeta, (size_t)4); ALLOC(h->ref_l0smeta, (size_t)4);
+    }
     // gradient accumulators: ONE buffer, parameters back to back in named_parameters() order (the layout the wrapper's
     // flat gradient buffer has too), so that zeroing and the final scale-and-add are one launch each
     h->gacc.assign(h->params.size(), nullptr);
@@ -1009,6 +1027,10 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         HIPCHK(h, launch_ref_split_weights(st, w0, Cr, h->ref_wk, h->ref_wsh));
         HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wk, Cr, 12, 16, Cr, 0, h->ref_wkmeta, h->ref_wk16));
         HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wsh, Cr, 8, 16, Cr, 0, h->ref_wshmeta, h->ref_wsh16));
+        if (h->ref_l0k) {                                      // fused encoding + layer 0: both parts as K = 16 MFMA operands
+            HIPCHK(h, launch_refine_l0_pack(st, h->ref_wk, Cr, 12, h->ref_l0kmeta, h->ref_l0k));
+            HIPCHK(h, launch_refine_l0_pack(st, h->ref_wsh, Cr, 8, h->ref_l0smeta, h->ref_l0s));
+        }
         if (Cr == 64)                                           // weight-stationary forward of layers 1 ..
             for (int l = 1; l < h->Dr; ++l)
                 HIPCHK(h, launch_pack_conv_weights_ws(st, P("refine.mlc.layers." + std::to_string(l) + ".weight"), Cr, 0, h->ref_wsf_meta[l], h->ref_wsf[l]));
@@ -1074,6 +1096,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "refine_split")) { h->refine_split = value != 0; return IODINE_OK; }
     if (!strcmp(key, "head_fused")) { h->head_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_bwd_fused")) { h->refine_bwd_fused = value != 0; return IODINE_OK; }
+    if (!strcmp(key, "refine_l0_fused")) { h->refine_l0_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_ws")) { h->refine_ws = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {
         if (value != 1 && value != 6) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1 (LDS-tiled) or 6 (weight-stationary)");

@@ -11,97 +11,7 @@
 
 #define PIX_BLOCK 256
 
-template <int K>
-struct PixelTerms {
-    float mu[K][3];       // sigmoid(rgb)
-    float m[K];           // mask = softmax_k(logit)
-    float logit[K];
-    float g1[K][3];       // d(B*ELBO)/d mean
-    float g2[K];          // d(B*ELBO)/d mask
-    float pk[K];          // exp(sum_c l_kc)  (un-stabilised, as the reference)
-    float ll_sum;         // sum_c logsumexp_k(log(m_k + 1e-12) + l_kc)
-    float like;           // exp(ll_sum)
-    float mix;            // sum_k m_k * pk_k
-    float loo[K];         // leave-one-out likelihood (iodine.py:321-328), see pixel_terms
-};
-
-template <int K>
-IOD_DEVINL void pixel_terms(const float4 xv, const float4* __restrict__ dec, size_t slot_stride, size_t p,
-                            float inv2s2, float invs2, float lconst, PixelTerms<K>& t)
-{
-    // No fp contraction in here: pass 1 (layer-norm statistics) and pass 2 (the values that get normalised) inline this function
-    // separately, and hipcc's default -ffp-contract=fast fuses multiplies into adds differently per instantiation.  A 1-ulp
-    // difference upstream is harmless everywhere except in the leave-one-out channel below, whose value at a saturated mask is
-    // rounding noise x 1e5: a noise spike that pass 2 sees but pass 1's statistics do not contain is normalised to 100 sigma
-    // instead of being absorbed by the standard deviation (as in the reference, which computes the channel once).
-#pragma clang fp contract(off)
-    const float xs[3] = {xv.x, xv.y, xv.z};
-    float mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const float4 d = dec[(size_t)k * slot_stride + p];
-        t.mu[k][0] = sigmoidf_(d.x); t.mu[k][1] = sigmoidf_(d.y); t.mu[k][2] = sigmoidf_(d.z);
-        t.logit[k] = d.w;
-        mx = fmaxf(mx, d.w);
-    }
-    float den = 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) { t.m[k] = expf(t.logit[k] - mx); den += t.m[k]; }
-    const float rden = 1.f / den;
-    float lm[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) { t.m[k] *= rden; lm[k] = logf(t.m[k] + 1e-12f); t.g2[k] = 0.f; }
-    float lsum[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) lsum[k] = 0.f;
-    t.ll_sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float a[K];
-        float amax = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float d = xs[c] - t.mu[k][c];
-            const float l = -(d * d) * inv2s2 + lconst;
-            lsum[k] += l;
-            a[k] = lm[k] + l;
-            amax = fmaxf(amax, a[k]);
-        }
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < K; ++k) { a[k] = expf(a[k] - amax); s += a[k]; }
-        t.ll_sum += amax + logf(s);
-        const float rs = 1.f / s;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float r = a[k] * rs;                         // responsibility of slot k for channel c
-            t.g1[k][c] = r * (xs[c] - t.mu[k][c]) * invs2;
-            t.g2[k] += r / (t.m[k] + 1e-12f);
-        }
-    }
-    t.like = expf(t.ll_sum);
-    // Leave-one-out likelihood, iodine.py:321-328: (sum_j m_j p_j - m_k p_k) / (1 - m_k + 1e-5).  Where a mask saturates
-    // (m_k -> 1) this is a cancellation divided by 1e-5: the value IS rounding noise amplified 1e5 x, in the reference too.  The
-    // only defensible target is the reference's own sequence of rounded fp32 operations - product, sequential sum over the
-    // slots (torch.sum over dim 1), difference with the SAME rounded product, denominator (1 - m) + 1e-5.  hipcc's default fp
-    // contraction fuses m_k * p_k into the sum / the difference (an EXACT product where the reference has a rounded one: the
-    // numerator then goes negative by an ulp where the reference's is exactly 0, i.e. -0.2 instead of 0 after the division) and
-    // does so differently in the three kernels that inline this function.  HIP's __fmul_rn / __fadd_rn do NOT help: they are
-    // plain operators in a header compiled with contraction on, and LLVM fuses them after inlining.  What helps is the
-    // `fp contract(off)` pragma at the top of this function with the arithmetic written as plain operators HERE.  Found by
-    // tests/test_gpu_trained_weights.py (sharpened masks): pass 2 of the split first refinement layer computed -101 sigma at a
-    // pixel where pass 1's statistics had seen 0, and the ELBO of the following iterations was off by 8e-4 relative.
-    float prod[K];
-    t.mix = 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        t.pk[k] = expf(lsum[k]);
-        prod[k] = t.m[k] * t.pk[k];
-        t.mix = k == 0 ? prod[0] : t.mix + prod[k];
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) t.loo[k] = (t.mix - prod[k]) / ((1.f - t.m[k]) + 1e-5f);
-}
+#include "pixel_terms.h"
 
 // sum of a double over the wave (valid in every lane).  Lane swaps / DPP in the VALU on the two 32-bit halves: __shfl_down on a
 // double is two ds_bpermute per step, and the pass-1 kernel reduces 6K + 3 statistics per wave for only two pixels per thread.
@@ -177,18 +87,27 @@ void pixel_pass1_kernel(const float4* __restrict__ x4, const float4* __restrict_
         st[2] += t.like * t.like;
     }
 
-    __shared__ double s_red[PIX_BLOCK / 64][NST];
-    const int lane = tid & 63, wv = tid >> 6;
+    // Block sum of the NST statistics in fp64.  Through LDS, not DPP: 6 K + 3 wave reductions in fp64 were ~1800 instructions per wave, more
+    // than one pixel_terms; here thread (statistic i, wave w) adds the 64 per-thread fp32 partials of that wave (row stride 257 and a start
+    // rotated by 16 w: conflict-free), then NST threads add the four wave sums.  A fixed order: deterministic.
+    __shared__ float s_part[NST][PIX_BLOCK + 1];
+    __shared__ double s_red[NST][PIX_BLOCK / 64];
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
-        const double v = wave_sum_d((double)st[i]);
-        if (lane == 0) s_red[wv][i] = v;
+    for (int i = 0; i < NST; ++i) s_part[i][tid] = st[i];
+    __syncthreads();
+    for (int q = tid; q < NST * (PIX_BLOCK / 64); q += PIX_BLOCK) {
+        const int i = q / (PIX_BLOCK / 64), w = q % (PIX_BLOCK / 64);
+        const float* row = s_part[i] + w * 64;
+        double v = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) v += (double)row[(j + 16 * w) & 63];
+        s_red[i][w] = v;
     }
     __syncthreads();
     if (tid < NST) {
         double v = 0.0;
 #pragma unroll
-        for (int w = 0; w < PIX_BLOCK / 64; ++w) v += s_red[w][tid];
+        for (int w = 0; w < PIX_BLOCK / 64; ++w) v += s_red[tid][w];
         part[((size_t)b * nblk + blk) * NST + tid] = v;
     }
 }

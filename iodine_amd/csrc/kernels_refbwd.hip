@@ -241,7 +241,7 @@ void refine_bwd01_kernel(const float* __restrict__ rd1, const uint4* __restrict_
                 int nimg, ty, tx;
                 tile_of(it + 2, nimg, ty, tx);
                 const long long org = (long long)(8 * ty - 1) * Sf + 32 * tx - 4;       // halo origin pixel (may lie before the image: masked)
-                const int nim2 = (int)__umulhi((unsigned)nimg, kdiv_magic);              // nimg / K (the launcher validated the multiplier)
+                const int nim2 = kdiv_magic ? (int)__umulhi((unsigned)nimg, kdiv_magic) : nimg;   // nimg / K (the launcher validated the multiplier; 0: K = 1)
                 const __amdgpu_buffer_rsrc_t rs_k = rb_rsrc(enck + ((long long)nimg * Sf * Sf + org) * 12);
                 const __amdgpu_buffer_rsrc_t rs_s = rb_rsrc(encs + ((long long)nim2 * Sf * Sf + org) * 8);
                 const bool top = ty == 0, left = tx == 0;
@@ -508,8 +508,8 @@ hipError_t launch_refine_bwd01(hipStream_t st, const float* rd1, const void* wpk
     int lgSm = 0;
     while ((1 << lgSm) < Sm) ++lgSm;
     // n / kdiv as a multiply-high: validated for every slot-image index of this launch
-    const unsigned magic = (unsigned)((((unsigned long long)1 << 32) + kdiv - 1) / kdiv);
-    for (int i = 0; i < NT; ++i)
+    const unsigned magic = kdiv == 1 ? 0u : (unsigned)((((unsigned long long)1 << 32) + kdiv - 1) / kdiv);     // (2^32 does not fit: 0 = "one slot")
+    for (int i = 0; i < NT && kdiv > 1; ++i)
         if ((unsigned)(((unsigned long long)i * magic) >> 32) != (unsigned)(i / kdiv)) return hipErrorInvalidValue;
     const int per_xcd = (ntiles + 7) / 8;
     const int bpx = std::min(per_xcd, std::max(1, n_cu / 8));

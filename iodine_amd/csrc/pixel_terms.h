@@ -1,0 +1,107 @@
+// Per-pixel mixture terms shared by the pixel kernels (kernels_pixel.hip) and the fused first refinement layer (kernels_refl0.hip):
+// ONE definition, so that every kernel that needs the 17-channel encoding computes bit-identical values (the function switches fp
+// contraction off for exactly that reason - see the comments inside).  Reference: lib/modeling/iodine.py:185-216, 277-331.
+#pragma once
+#include "common.h"
+
+template <int K>
+struct PixelTerms {
+    float mu[K][3];       // sigmoid(rgb)
+    float m[K];           // mask = softmax_k(logit)
+    float logit[K];
+    float g1[K][3];       // d(B*ELBO)/d mean
+    float g2[K];          // d(B*ELBO)/d mask
+    float pk[K];          // exp(sum_c l_kc)  (un-stabilised, as the reference)
+    float ll_sum;         // sum_c logsumexp_k(log(m_k + 1e-12) + l_kc)
+    float like;           // exp(ll_sum)
+    float mix;            // sum_k m_k * pk_k
+    float loo[K];         // leave-one-out likelihood (iodine.py:321-328), see pixel_terms
+};
+
+// dv[k] = decoder output (rgb logits, mask logit) of slot k at this pixel
+template <int K>
+IOD_DEVINL void pixel_terms_core(const float4 xv, const float4 (&dv)[K], float inv2s2, float invs2, float lconst, PixelTerms<K>& t)
+{
+    // No fp contraction in here: pass 1 (layer-norm statistics) and pass 2 (the values that get normalised) inline this function
+    // separately, and hipcc's default -ffp-contract=fast fuses multiplies into adds differently per instantiation.  A 1-ulp
+    // difference upstream is harmless everywhere except in the leave-one-out channel below, whose value at a saturated mask is
+    // rounding noise x 1e5: a noise spike that pass 2 sees but pass 1's statistics do not contain is normalised to 100 sigma
+    // instead of being absorbed by the standard deviation (as in the reference, which computes the channel once).
+#pragma clang fp contract(off)
+    const float xs[3] = {xv.x, xv.y, xv.z};
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float4 d = dv[k];
+        t.mu[k][0] = sigmoidf_(d.x); t.mu[k][1] = sigmoidf_(d.y); t.mu[k][2] = sigmoidf_(d.z);
+        t.logit[k] = d.w;
+        mx = fmaxf(mx, d.w);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { t.m[k] = expf(t.logit[k] - mx); den += t.m[k]; }
+    const float rden = 1.f / den;
+    float lm[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { t.m[k] *= rden; lm[k] = logf(t.m[k] + 1e-12f); t.g2[k] = 0.f; }
+    float lsum[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) lsum[k] = 0.f;
+    t.ll_sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float a[K];
+        float amax = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float d = xs[c] - t.mu[k][c];
+            const float l = -(d * d) * inv2s2 + lconst;
+            lsum[k] += l;
+            a[k] = lm[k] + l;
+            amax = fmaxf(amax, a[k]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { a[k] = expf(a[k] - amax); s += a[k]; }
+        t.ll_sum += amax + logf(s);
+        const float rs = 1.f / s;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float r = a[k] * rs;                         // responsibility of slot k for channel c
+            t.g1[k][c] = r * (xs[c] - t.mu[k][c]) * invs2;
+            t.g2[k] += r / (t.m[k] + 1e-12f);
+        }
+    }
+    t.like = expf(t.ll_sum);
+    // Leave-one-out likelihood, iodine.py:321-328: (sum_j m_j p_j - m_k p_k) / (1 - m_k + 1e-5).  Where a mask saturates
+    // (m_k -> 1) this is a cancellation divided by 1e-5: the value IS rounding noise amplified 1e5 x, in the reference too.  The
+    // only defensible target is the reference's own sequence of rounded fp32 operations - product, sequential sum over the
+    // slots (torch.sum over dim 1), difference with the SAME rounded product, denominator (1 - m) + 1e-5.  hipcc's default fp
+    // contraction fuses m_k * p_k into the sum / the difference (an EXACT product where the reference has a rounded one: the
+    // numerator then goes negative by an ulp where the reference's is exactly 0, i.e. -0.2 instead of 0 after the division) and
+    // does so differently in the three kernels that inline this function.  HIP's __fmul_rn / __fadd_rn do NOT help: they are
+    // plain operators in a header compiled with contraction on, and LLVM fuses them after inlining.  What helps is the
+    // `fp contract(off)` pragma at the top of this function with the arithmetic written as plain operators HERE.  Found by
+    // tests/test_gpu_trained_weights.py (sharpened masks): pass 2 of the split first refinement layer computed -101 sigma at a
+    // pixel where pass 1's statistics had seen 0, and the ELBO of the following iterations was off by 8e-4 relative.
+    float prod[K];
+    t.mix = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        t.pk[k] = expf(lsum[k]);
+        prod[k] = t.m[k] * t.pk[k];
+        t.mix = k == 0 ? prod[0] : t.mix + prod[k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) t.loo[k] = (t.mix - prod[k]) / ((1.f - t.m[k]) + 1e-5f);
+}
+
+template <int K>
+IOD_DEVINL void pixel_terms(const float4 xv, const float4* __restrict__ dec, size_t slot_stride, size_t p,
+                            float inv2s2, float invs2, float lconst, PixelTerms<K>& t)
+{
+    float4 dv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) dv[k] = dec[(size_t)k * slot_stride + p];
+    pixel_terms_core<K>(xv, dv, inv2s2, invs2, lconst, t);
+}

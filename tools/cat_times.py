@@ -36,7 +36,7 @@ torch.cuda.synchronize()
 m.set_option('profile', 0)
 tot = 0.0
 for cat in ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad', 'dec_out', 'dec_out_dgrad', 'dec_out_wgrad', 'dec_out_bwd', 'dec_l0',
-            'l0_reduce', 'l0_slot_sum', 'pixel_pass1', 'pixel_pass2', 'refine_conv', 'refine_head', 'refine_wgrad',
+            'l0_reduce', 'l0_slot_sum', 'pixel_pass1', 'pixel_pass2', 'refine_l0', 'refine_l0f', 'refine_conv', 'refine_head', 'refine_wgrad',
             'refine_dgrad', 'refine_bwd01', 'refine_bias_grad'):
     ms, cnt = m.profile_read(cat)
     if cnt:
