@@ -61,6 +61,7 @@ SUSTAIN_S = 6.0                    # minimum length of the continuous step loop 
 SPLIT_PASSES = 3                   # fp32 product = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, three f16 MFMAs, fp32 accumulate
 PUBLISHED_TRAIN_ITERS_PER_S = 94.0  # 1.7 s / 32-image T=5 training step on 4 unknown GPUs (log.md:3)
 DOMINANT = ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad')
+PROFILE_STRIDE = 7                 # timed region: every 7th launch of each dominant form is bracketed with HIP events (library option profile_stride)
 CATS = DOMINANT + ('dec_out', 'dec_out_dgrad', 'dec_out_wgrad', 'dec_out_bwd', 'dec_l0', 'l0_reduce', 'l0_slot_sum', 'pixel_pass1',
                    'pixel_pass2', 'refine_conv', 'refine_l0', 'refine_head', 'refine_wgrad', 'refine_dgrad', 'refine_bwd01', 'refine_bias_grad', 'head_bwd')
 
@@ -86,6 +87,8 @@ def parse():
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the cfg2 / cfg5-shard side measurements')
     ap.add_argument('--no-sustain', action='store_true', help='do not continue a short timed region to 6 s of GPU work')
     ap.add_argument('--cpu-batch', type=int, default=None)
+    ap.add_argument('--option', action='append', default=[], metavar='KEY=VALUE',
+                    help='library option for the timed model (A/B of kernel selections, e.g. refine_l0_fused=0); recorded in config.options')
     return ap.parse_args()
 
 
@@ -336,14 +339,19 @@ def main():
         out = {}
         for cat in CATS:
             tot, cnt = (m or model).profile_read(cat)
+            _, seen = (m or model).profile_read('seen:' + cat)              # every launch of the category, bracketed or not
             if cnt:
-                out[cat] = dict(ms_total=round(tot, 3), launches=cnt, ms_avg=round(tot / cnt, 4))
+                out[cat] = dict(ms_total=round(tot, 3), launches=cnt, ms_avg=round(tot / cnt, 4), **({'launches_seen': seen} if seen else {}))
         return out
 
     model.set_option('conv_precision', args.conv_precision)
     model.set_option('graph', args.graph)
+    for kv in args.option:
+        k, v = kv.split('=')
+        model.set_option(k, float(v))
     for _ in range(args.warmup):
         step()
+    model.set_option('profile_stride', PROFILE_STRIDE)
     model.set_option('profile', 0 if args.graph else 1)
     dt = timed(step, args.steps)                                          # ---- THE timed region: exactly --steps steps ----
     ms_per_step = dt / args.steps * 1e3
@@ -373,6 +381,7 @@ def main():
     def mfma_roofline(pr, steps_counted, step_ms, in_timed):
         dom_ms = sum(pr[c]['ms_total'] for c in DOMINANT if c in pr)
         dom_n = sum(pr[c]['launches'] for c in DOMINANT if c in pr)
+        dom_all = sum(pr[c].get('launches_seen', pr[c]['launches']) for c in DOMINANT if c in pr)      # bracketed: every PROFILE_STRIDE-th
         achieved = flops_per_launch / (dom_ms / dom_n * 1e-3) / 1e12 if dom_n else 0.0
         if args.conv_precision == 1:
             # the kernel executes SPLIT_PASSES f16 MFMAs per algorithmic (fp32-class) multiply-add: the peak for ALGORITHMIC
@@ -385,7 +394,7 @@ def main():
         traffic = None
         if per_kernel_traffic and dom_n:
             # launch-weighted mean over the forward / data-gradient / weight-gradient launches, like `achieved`
-            w = {c: pr[c]['launches'] for c in DOMINANT if c in pr}
+            w = {c: pr[c].get('launches_seen', pr[c]['launches']) for c in DOMINANT if c in pr}
             if all(c in per_kernel_traffic for c in w):
                 traffic = sum(per_kernel_traffic[c] * n for c, n in w.items()) / sum(w.values())
         per_form = {c: dict(ms_avg=pr[c]['ms_avg'], tflops=round(flops_per_launch / (pr[c]['ms_avg'] * 1e-3) / 1e12, 1),
@@ -397,8 +406,12 @@ def main():
                     traffic_per_kernel=({c: per_kernel_traffic[c] for c in DOMINANT if c in per_kernel_traffic}
                                         if per_kernel_traffic else None),
                     matrix_pipe_pmc=pmc_pipe, flops_per_launch=flops_per_launch, avg_launch_ms=round(avg_ms, 4),
-                    launches=dom_n, events_in_timed_region=in_timed, per_form=per_form,
-                    kernel_time_share=round(avg_ms * (dom_n / max(steps_counted, 1)) / step_ms, 4),
+                    launches=dom_all, launches_timed=dom_n, events_in_timed_region=in_timed,
+                    event_sampling=(f'every {PROFILE_STRIDE}th launch of each form is bracketed (a pair of event records idles the GPU for ~12 us: '
+                                    f'bracketing all {dom_all // max(steps_counted, 1)} launches of a step cost 0.8 ms of the step, tools/step_timeline.py); '
+                                    f'{PROFILE_STRIDE} is coprime to the layer count, every layer is sampled' if in_timed and dom_all != dom_n else None),
+                    per_form=per_form,
+                    kernel_time_share=round(avg_ms * (dom_all / max(steps_counted, 1)) / step_ms, 4),
                     executed_mfma_tflops=round(achieved * (SPLIT_PASSES if args.conv_precision == 1 else 1), 1),
                     algorithmic_hbm_bytes_per_launch=2.0 * B * K * S * S * C_ * 4,
                     hbm_gbps_algorithmic=round(2.0 * B * K * S * S * C_ * 4 / (avg_ms * 1e-3) / 1e9, 1) if dom_n else None)
@@ -476,6 +489,7 @@ def main():
                dtype=('f32 (3xf16-split MFMA convs, f32 accumulate)' if args.conv_precision == 1 else 'f32'), data='synthetic',
                config=dict(workload=f'{cfg_name}, K={K}, T={T}, batch {B}/GPU, {args.mode} step ({what})',
                            step=args.mode, global_batch=B * world, slots=K, iters=T, img_size=S, hip_graph=bool(args.graph),
+                           **({'options': args.option} if args.option else {}),
                            conv_path=('split_fp16x3: fp32 tensors, conv operands split on the fly into fp16 hi+lo, three f16 MFMAs, fp32 '
                                       'accumulate (library default; `exact_fp32` on this line is the same step on fp32 MFMA)'
                                       if args.conv_precision == 1 else 'exact_fp32: v_mfma_f32_32x32x2_f32 (option conv_precision=0)'),
@@ -532,6 +546,7 @@ def main():
         px = read_prof()
         xm = sum(px[c]['ms_total'] for c in DOMINANT if c in px)
         xn = sum(px[c]['launches'] for c in DOMINANT if c in px)
+        xall = sum(px[c].get('launches_seen', px[c]['launches']) for c in DOMINANT if c in px)
         xa = flops_per_launch / (xm / xn * 1e-3) / 1e12 if xn else 0.0
         out['exact_fp32'] = dict(
             metric='refinement_iters_per_s', value=round(world * B * T / dtx, 2), unit='image-refinement-iters/s',
@@ -541,9 +556,9 @@ def main():
                           kernel=f'conv3x3_tile_kernel<{C_},{C_}> + conv3x3_wgrad_tile_kernel<{C_},{C_}> (decoder 3x3 conv {C_}->{C_}: fwd, '
                                  f'dgrad, wgrad launches; exact fp32 MFMA)',
                           achieved=round(xa, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=round(xa / PEAK_F32_MFMA_TFLOPS, 4),
-                          traffic=None, flops_per_launch=flops_per_launch, avg_launch_ms=round(xm / max(xn, 1), 4), launches=xn,
-                          events_in_timed_region=True,
-                          kernel_time_share=round(xm / max(nx, 1) / (dtx * 1e3), 4),
+                          traffic=None, flops_per_launch=flops_per_launch, avg_launch_ms=round(xm / max(xn, 1), 4), launches=xall,
+                          launches_timed=xn, events_in_timed_region=True,
+                          kernel_time_share=round(xm / max(xn, 1) * xall / max(nx, 1) / (dtx * 1e3), 4),
                           per_form={c: dict(ms_avg=px[c]['ms_avg'],
                                             tflops=round(flops_per_launch / (px[c]['ms_avg'] * 1e-3) / 1e12, 1),
                                             frac=round(flops_per_launch / (px[c]['ms_avg'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))

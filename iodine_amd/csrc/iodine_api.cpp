@@ -64,7 +64,7 @@ struct Buffers {               // workspace carve-up for one batch size / mode
 
 // HIP-event profiler: when enabled every launch of a category is bracketed by two events on the
 // launch stream; totals are read back (after a sync) with iodine_profile_read.
-struct ProfCat { std::string name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; };
+struct ProfCat { std::string name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; unsigned long long seen = 0, seen_win = 0; };
 
 struct GraphEntry { std::vector<uintptr_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long long used = 0; };
 
@@ -72,6 +72,9 @@ struct iodine_handle {
     iodine_config cfg;
     std::string err;
     int profile = 0;                            // 0 off, 1 the dominant conv kernels ("conv_tile_*") only, 2 every category
+    int profile_stride = 1;                     // level 1: bracket every n-th launch of a category only - an event pair costs ~12 us of idle GPU
+                                                // (a barrier packet in front of the kernel and one behind it: tools/step_timeline.py), 54 pairs per cfg3
+                                                // training step = 0.8 ms of the step being measured; a stride coprime to the layer count samples every layer
     std::vector<ProfCat> prof;
     ProfCat* prof_cat(const char* name) {
         for (auto& c : prof) if (c.name == name) return &c;
@@ -171,8 +174,14 @@ hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, c
 #define PROF(h, st, cat, expr)                                                       \
     do {                                                                             \
         hipEvent_t e0_ = nullptr, e1_ = nullptr;                                     \
-        if ((h)->profile > 1 || ((h)->profile == 1 && !strncmp(cat, "conv_tile_", 10))) {    \
-            ProfCat* pc_ = (h)->prof_cat(cat);                                       \
+        ProfCat* pc_ = nullptr;                                                      \
+        if ((h)->profile > 1) pc_ = (h)->prof_cat(cat);                              \
+        else if ((h)->profile == 1 && !strncmp(cat, "conv_tile_", 10)) {             \
+            pc_ = (h)->prof_cat(cat);                                                \
+            pc_->seen_win++;                                                         \
+            if (pc_->seen++ % (unsigned long long)(h)->profile_stride) pc_ = nullptr;    \
+        }                                                                            \
+        if (pc_) {                                                                   \
             if (pc_->used == pc_->ev.size()) {                                       \
                 hipEvent_t a_, b_;                                                   \
                 HIPCHK(h, hipEventCreate(&a_)); HIPCHK(h, hipEventCreate(&b_));      \
@@ -1096,6 +1105,10 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "refine_split")) { h->refine_split = value != 0; return IODINE_OK; }
     if (!strcmp(key, "head_fused")) { h->head_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_bwd_fused")) { h->refine_bwd_fused = value != 0; return IODINE_OK; }
+    if (!strcmp(key, "profile_stride")) {
+        if (value < 1) return h->fail(IODINE_ERR_INVALID, "profile_stride must be >= 1");
+        h->profile_stride = (int)value; return IODINE_OK;
+    }
     if (!strcmp(key, "refine_l0_fused")) { h->refine_l0_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_ws")) { h->refine_ws = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {
@@ -1538,6 +1551,13 @@ int iodine_profile_read(iodine_handle* h, const char* category, double* total_ms
         if (total_ms) *total_ms = 0.0;
         if (launches) *launches = category[6] == 'c' ? h->graph_captures : h->graph_replays;
         if (reset) { if (category[6] == 'c') h->graph_captures = 0; else h->graph_replays = 0; }
+        return IODINE_OK;
+    }
+    if (!strncmp(category, "seen:", 5)) {               // launches of the category since the last reset, bracketed or not (profile_stride)
+        for (auto& c : h->prof)
+            if (c.name == category + 5) { cnt = (long long)c.seen_win; if (reset) c.seen_win = 0; }
+        if (total_ms) *total_ms = 0.0;
+        if (launches) *launches = cnt;
         return IODINE_OK;
     }
     for (auto& c : h->prof) {

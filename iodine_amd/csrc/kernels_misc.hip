@@ -97,14 +97,15 @@ hipError_t launch_dec_l0_prepare(hipStream_t st, const float* w, const float* bi
 }
 
 // z = mean + exp(logvar/2) * eps (Gaussian.sample, iodine.py:620-634), then V = z . Wcls.  One block per slot.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(1024)
 void dec_v_kernel(const float* __restrict__ pm, const float* __restrict__ plv, const float* __restrict__ eps,
                   const float* __restrict__ z_in, const float* __restrict__ wcls, float* __restrict__ z_out,
                   float* __restrict__ V, int L, int C)
 {
     extern __shared__ float s_z[];
     const int n = blockIdx.x, tid = threadIdx.x;
-    for (int l = tid; l < L; l += 256) {
+    const int nth = blockDim.x;
+    for (int l = tid; l < L; l += nth) {
         float z;
         if (z_in) z = z_in[(size_t)n * L + l];
         else z = pm[(size_t)n * L + l] + expf(0.5f * plv[(size_t)n * L + l]) * eps[(size_t)n * L + l];
@@ -112,24 +113,28 @@ void dec_v_kernel(const float* __restrict__ pm, const float* __restrict__ plv, c
         if (z_out) z_out[(size_t)n * L + l] = z;
     }
     __syncthreads();
-    for (int o = tid; o < 9 * C; o += 256) {
+    for (int o = tid; o < 9 * C; o += nth) {             // (one output per thread at C = 64: the loop is a chain of L2 load latencies)
         const int cls = o / C, co = o % C;
         const float* w = wcls + (size_t)cls * L * C + co;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;              // four partial sums: the loads of a chain overlap
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // eight partial sums: the loads of a chain overlap
         int ci = 0;
-        for (; ci + 3 < L; ci += 4) {
-            s0 = fmaf(s_z[ci], w[(size_t)ci * C], s0); s1 = fmaf(s_z[ci + 1], w[(size_t)(ci + 1) * C], s1);
-            s2 = fmaf(s_z[ci + 2], w[(size_t)(ci + 2) * C], s2); s3 = fmaf(s_z[ci + 3], w[(size_t)(ci + 3) * C], s3);
+        for (; ci + 7 < L; ci += 8) {
+            float wv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wv[q] = w[(size_t)(ci + q) * C];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = fmaf(s_z[ci + q], wv[q], a[q]);
         }
-        for (; ci < L; ++ci) s0 = fmaf(s_z[ci], w[(size_t)ci * C], s0);
-        V[(size_t)n * 9 * C + o] = (s0 + s1) + (s2 + s3);
+        for (; ci < L; ++ci) a[0] = fmaf(s_z[ci], w[(size_t)ci * C], a[0]);
+        V[(size_t)n * 9 * C + o] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
 }
 
 hipError_t launch_dec_v(hipStream_t st, const float* pm, const float* plv, const float* eps, const float* z_in,
                         const float* wcls, float* z_out, float* V, int N, int L, int C)
 {
-    hipLaunchKernelGGL(dec_v_kernel, dim3(N), dim3(256), L * sizeof(float), st, pm, plv, eps, z_in, wcls, z_out, V, L, C);
+    const int nth = std::min(1024, (9 * C + 63) / 64 * 64);
+    hipLaunchKernelGGL(dec_v_kernel, dim3(N), dim3(nth), L * sizeof(float), st, pm, plv, eps, z_in, wcls, z_out, V, L, C);
     return hipGetLastError();
 }
 
@@ -339,20 +344,30 @@ __global__ void l0_rows_combine_kernel(const float* __restrict__ part, const flo
     o[2 * 3 * C + t] = edge[((size_t)n * 2 + 1) * 3 * C + t];
 }
 
-// Rsum[i] = (first ? 0 : Rsum[i]) + alpha * sum_n rown[n][i], i < len: fixed order over the slot-images (four interleaved partial
+// Rsum[i] = (first ? 0 : Rsum[i]) + alpha * sum_n rown[n][i], i < len: fixed order over the slot-images (sixteen interleaved partial
 // sums), one thread per element
 __global__ void l0_rowsum_acc_kernel(const float* __restrict__ rown, int N, int len, float alpha, int first, float* __restrict__ Rsum)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
     const float* p = rown + i;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float a[16];                                             // sixteen loads in flight: the loop is a chain of memory latencies
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = 0.f;
     int n = 0;
-    for (; n + 3 < N; n += 4) {
-        a0 += p[(size_t)n * len]; a1 += p[(size_t)(n + 1) * len]; a2 += p[(size_t)(n + 2) * len]; a3 += p[(size_t)(n + 3) * len];
+    for (; n + 15 < N; n += 16) {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = p[(size_t)(n + q) * len];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] += v[q];
     }
-    for (; n < N; ++n) a0 += p[(size_t)n * len];
-    const float s = alpha * ((a0 + a1) + (a2 + a3));
+    for (; n < N; ++n) a[n & 15] += p[(size_t)n * len];
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+        for (int q = 0; q < w; ++q) a[q] += a[q + w];
+    const float s = alpha * a[0];
     Rsum[i] = first ? s : Rsum[i] + s;
 }
 
@@ -543,35 +558,40 @@ __global__ void dz_latent_kernel(const float* __restrict__ Rc, const float* __re
                                  const float* __restrict__ eps, int L, int C, int use_ln,
                                  float* __restrict__ g_pm, float* __restrict__ g_plv, float* __restrict__ latent)
 {
-    // blockDim = 4 * Lp (Lp = L rounded up to 64): the 9C-long contraction is cut into four slices (one per group of Lp
-    // threads), four independent partial sums each, combined in fixed order; slice 0 finishes the row.  (One thread per
-    // latent walked all 9C terms as a single dependent load + fma chain: 64 us per launch at cfg3.)
-    extern __shared__ float s_rc[];                     // 9*C, then 4*Lp partial sums
+    // blockDim = NS * Lp (Lp = L rounded up to 64, NS = 8 slices for L <= 64): the 9C-long contraction is cut into NS slices (one per group of
+    // Lp threads), eight independent partial sums each (eight L2 loads in flight per thread: the kernel is a chain of load latencies), combined
+    // in fixed order; slice 0 finishes the row.  (One thread per latent walked all 9C terms as a single dependent load + fma chain: 64 us per
+    // launch at cfg3; four slices x four partial sums: 21 us.)
+    extern __shared__ float s_rc[];                     // 9*C, then NS*Lp partial sums
     __shared__ float s_buf[8];
     const int n = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
-    const int Lp = nth / 4, l = tid % Lp, slice = tid / Lp, J = 9 * C;
+    const int Lp = (L + 63) / 64 * 64, NS = nth / Lp, l = tid % Lp, slice = tid / Lp, J = 9 * C;
     float* s_dz = s_rc + J;
     for (int i = tid; i < J; i += nth) s_rc[i] = Rc[(size_t)n * J + i];
     __syncthreads();
     {
-        const int per = (J + 3) / 4, j0 = slice * per, j1 = min(J, j0 + per);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const int per = (J + NS - 1) / NS, j0 = slice * per, j1 = min(J, j0 + per);
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (l < L) {
             const float* w = wclsT + l;
             int j = j0;
-            for (; j + 3 < j1; j += 4) {
-                a0 = fmaf(s_rc[j], w[(size_t)j * L], a0); a1 = fmaf(s_rc[j + 1], w[(size_t)(j + 1) * L], a1);
-                a2 = fmaf(s_rc[j + 2], w[(size_t)(j + 2) * L], a2); a3 = fmaf(s_rc[j + 3], w[(size_t)(j + 3) * L], a3);
+            for (; j + 7 < j1; j += 8) {
+                float wv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) wv[q] = w[(size_t)(j + q) * L];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[q] = fmaf(s_rc[j + q], wv[q], a[q]);
             }
-            for (; j < j1; ++j) a0 = fmaf(s_rc[j], w[(size_t)j * L], a0);
+            for (; j < j1; ++j) a[0] = fmaf(s_rc[j], w[(size_t)j * L], a[0]);
         }
-        s_dz[slice * Lp + l] = (a0 + a1) + (a2 + a3);
+        s_dz[slice * Lp + l] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     __syncthreads();
     const bool act = slice == 0 && l < L;
     float gm = 0.f, gl = 0.f, mu = 0.f, lv = 0.f;
     if (act) {
-        const float dz = (s_dz[l] + s_dz[Lp + l]) + (s_dz[2 * Lp + l] + s_dz[3 * Lp + l]);
+        float dz = 0.f;
+        for (int q = 0; q < NS; ++q) dz += s_dz[q * Lp + l];
         mu = pm[(size_t)n * L + tid]; lv = plv[(size_t)n * L + tid];
         const float e = eps[(size_t)n * L + tid];
         gm = dz - mu;
@@ -599,8 +619,9 @@ hipError_t launch_dz_latent(hipStream_t st, const float* Rc, const float* wclsT,
                             const float* eps, int N, int L, int C, int use_ln, float* g_pm, float* g_plv, float* latent)
 {
     IOD_XSKIP(32);
-    const int nth = 4 * ((L + 63) / 64) * 64;
-    if (nth > 512) return hipErrorInvalidValue;                  // block_sum_f: at most 8 waves
+    const int Lp = (L + 63) / 64 * 64;
+    if (Lp > 512) return hipErrorInvalidValue;                   // block_sum_f: at most 8 waves
+    const int nth = (512 / Lp) * Lp;                             // 8 slices for L <= 64, 4 for L <= 128, ...
     hipLaunchKernelGGL(dz_latent_kernel, dim3(N), dim3(nth), (9 * C + nth) * sizeof(float), st, Rc, wclsT, pm, plv, eps, L, C,
                        use_ln, g_pm, g_plv, latent);
     return hipGetLastError();
