@@ -179,6 +179,9 @@ hipError_t launch_pixel_pass1(hipStream_t st, const float* x4, const float* dec,
                               int K, int P, float sigma);
 hipError_t launch_pixel_finalize(hipStream_t st, const double* part, int B, int K, int P, int use_ln,
                                  float* lnstat, float* ll_img);
+// finalize + KL + batch means in one launch; counter: one zero-initialised device word per handle
+hipError_t launch_pixel_finalize_elbo(hipStream_t st, const double* part, int B, int K, int P, int use_ln, float* lnstat, float* ll_img,
+                                      const float* pm, const float* plv, int L, float* img_terms, float* scal, unsigned* counter);
 hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec, const float* lnstat,
                               const float* lin, float* enc, int B, int K, int S, float sigma, float* enc_sh = nullptr, unsigned chmask = 0x1ffffu);
 hipError_t launch_final_out(hipStream_t st, const float* dec, float* pred, float* mask, float* mean, float* logits,
@@ -236,6 +239,10 @@ hipError_t launch_colsum_tall(hipStream_t st, const float* src, int rows, int co
                               size_t tmp_elems);
 hipError_t launch_sgemm(hipStream_t st, int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
                         const float* B, int ldb, float beta, float* C, int ldc);
+// C = alpha * A^T . B + beta * C, A [K][M], B [K][N], on fp32 MFMA (M, N multiples of 32); mode 1: C through the broadcast layer's weight map
+bool sgemm_tn_mfma_ok(int M, int N, int K);
+hipError_t launch_sgemm_tn_mfma(hipStream_t st, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
+                                float beta, float* C, int ldc, int mode, int mode_c);
 hipError_t launch_l0_tap_sums(hipStream_t st, const float* Rc, float* RT, int N, int C);
 hipError_t launch_l0_scatter_z(hipStream_t st, const float* tmp, int L, int C, float alpha, float* gw);
 hipError_t launch_l0_coord_grads(hipStream_t st, const float* D, const float* lin, int S, int C, int L, float alpha,
@@ -274,6 +281,11 @@ hipError_t launch_dec_out_stream_f16x3(hipStream_t st, const float* in, const vo
 
 // kernels_convws.hip: weight-stationary split-fp16 3x3 conv C -> C (weights in registers, persistent blocks)
 hipError_t launch_pack_conv_weights_ws(hipStream_t st, const float* src, int C, int tflip, float* meta, void* dst);
+// kernels_pack.hip: the packs above for many tensors in two launches.  kind 0 = launch_pack_conv_weights_ws(src, C = p[0], tflip = p[1]),
+// kind 1 = launch_pack_conv_weights_f16(src, O = p[0], I = p[1], cin = p[2], cout = p[3], tflip = p[4]); meta / dst as there
+constexpr int PACK_BATCH_MAX = 48;
+struct PackJob { const float* src; void* dst; float* meta; int kind; int p[5]; };
+hipError_t launch_pack_batch(hipStream_t st, const PackJob* jobs, int n);
 hipError_t launch_cell_max(hipStream_t st, const float* x, float* tmax, int N, int S, int C);
 hipError_t launch_conv3x3_ws_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
                                    const float* aux, float* out, const float* tmax_in, float* tmax_out, int N, int S, int c,

@@ -113,6 +113,7 @@ struct iodine_handle {
     float *ref_wk = nullptr, *ref_wsh = nullptr;           // split first layer: weights in the internal channel order [Cr][12][9], [Cr][8][9]
     float *ref_wk16 = nullptr, *ref_wsh16 = nullptr, *ref_wkmeta = nullptr, *ref_wshmeta = nullptr;   // and their packs
     float* ref_g20 = nullptr;                              // [Cr][20][9] weight gradient in the internal order
+    unsigned* elbo_counter = nullptr;                      // ticket of pixel_finalize_elbo_kernel (zero between launches)
     int refine_l0_fused = 1;                               // encoding + first refinement layer in one kernel (kernels_refl0.hip); 0: pixel_pass2 + two convs
     void *ref_l0k = nullptr, *ref_l0s = nullptr; float *ref_l0kmeta = nullptr, *ref_l0smeta = nullptr;     // its weight packs
     int refine_ws = 1;                                     // forward stride-2 convs of refinement layers 1 .. on the weight-stationary kernel (kernels_refws.hip)
@@ -633,8 +634,12 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         // and bias from the slot-summed gradient map
         const int wi = param_index(h, "decoder.mlc.layers.0.weight"), bi = param_index(h, "decoder.mlc.layers.0.bias");
         HIPCHK(h, launch_l0_tap_sums(st, b.Rc, b.RT, N, Cd));
-        HIPCHK(h, launch_sgemm(st, 1, 0, h->L, 9 * Cd, N, 1.f, b.z[it], h->L, b.RT, 9 * Cd, 0.f, b.tmp_lz, 9 * Cd));
-        HIPCHK(h, launch_l0_scatter_z(st, b.tmp_lz, h->L, Cd, train_alpha, h->gacc[wi]));
+        if (sgemm_tn_mfma_ok(h->L, 9 * Cd, N))              // z^T . RT on fp32 MFMA, accumulated straight into gw[co][ci][tap]
+            HIPCHK(h, launch_sgemm_tn_mfma(st, h->L, 9 * Cd, N, train_alpha, b.z[it], h->L, b.RT, 9 * Cd, 1.f, h->gacc[wi], h->L + 2, 1, Cd));
+        else {
+            HIPCHK(h, launch_sgemm(st, 1, 0, h->L, 9 * Cd, N, 1.f, b.z[it], h->L, b.RT, 9 * Cd, 0.f, b.tmp_lz, 9 * Cd));
+            HIPCHK(h, launch_l0_scatter_z(st, b.tmp_lz, h->L, Cd, train_alpha, h->gacc[wi]));
+        }
         if (it == h->T) {
             if (fused_l0) HIPCHK(h, launch_l0_coord_grads_rows(st, b.Rsum, h->lin, h->S, Cd, h->L, 1.f, h->gacc[wi], h->gacc[bi]));
             else HIPCHK(h, launch_l0_coord_grads(st, b.Dsum, h->lin, h->S, Cd, h->L, 1.f, h->gacc[wi], h->gacc[bi], b.wg_part));
@@ -653,8 +658,8 @@ int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps
     int rc = decoder_forward(h, st, N, b.z[i]);
     if (rc) return rc;
     PROF(h, st, "pixel_pass1", launch_pixel_pass1(st, b.x4, b.dec_out, b.g, b.part, B, h->K, h->P, (float)h->cfg.sigma));
-    HIPCHK(h, launch_pixel_finalize(st, b.part, B, h->K, h->P, h->cfg.layernorm, b.lnstat, b.ll_img));
-    HIPCHK(h, launch_elbo(st, b.pm, b.plv, b.ll_img, B, h->K, h->L, b.img_terms + (size_t)i * B * 2, b.scal + 3 * i));
+    HIPCHK(h, launch_pixel_finalize_elbo(st, b.part, B, h->K, h->P, h->cfg.layernorm, b.lnstat, b.ll_img, b.pm, b.plv, h->L,
+                                         b.img_terms + (size_t)i * B * 2, b.scal + 3 * i, h->elbo_counter));
     h->last_elbo_iter = i; h->last_elbo_batch = B;
     if (!need_grads) return IODINE_OK;
     float* dpre0 = nullptr;
@@ -895,6 +900,12 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     }
     ALLOC(h->ref_wk16, (size_t)9 * 2 * 2 * Cr * 4); ALLOC(h->ref_wsh16, (size_t)9 * 2 * 2 * Cr * 4);
     ALLOC(h->ref_wkmeta, (size_t)4); ALLOC(h->ref_wshmeta, (size_t)4);
+    {
+        float* c_ = nullptr;
+        ALLOC(c_, (size_t)4);
+        h->elbo_counter = reinterpret_cast<unsigned*>(c_);
+        if (hipError_t e_ = hipMemset(c_, 0, 16); e_ != hipSuccess) return bail(e_, "hipMemset elbo_counter");
+    }
     if (Cr % 16 == 0) {
         float *pk = nullptr, *ps = nullptr;
         ALLOC(pk, refine_l0_wpk_bytes(Cr) / 4); ALLOC(ps, refine_l0_wpk_bytes(Cr) / 4);
@@ -963,6 +974,16 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         return hipSuccess;
     };
     const int L = h->L, Cd = h->Cd, Cr = h->Cr, H = h->H;
+    // split-fp16 packs (power-of-two scale + layout per tensor and direction) are collected and issued as two launches at the end
+    std::vector<PackJob> pj;
+    auto pack_ws = [&](const float* src, int C, int tflip, float* meta, void* dst) {
+        pj.push_back(PackJob{src, dst, meta, 0, {C, tflip, 0, 0, 0}});
+        return hipSuccess;
+    };
+    auto pack_f16 = [&](const float* src, int O, int I, int cin, int cout, int tflip, float* meta, void* dst) {
+        pj.push_back(PackJob{src, dst, meta, 1, {O, I, cin, cout, tflip}});
+        return hipSuccess;
+    };
     if (h->generic) {
         // fallback path: [tap][ci][co] packs of every conv, plain bias copies, the head below as on the tuned path
         for (int l = 0; l < h->Dd; ++l) {
@@ -995,11 +1016,11 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         }
         // only the selected kernel's packs are maintained (a change of conv_variant / conv_precision invalidates the parameters)
         if (conv_ws_ok(h)) {                                   // weight-stationary register layout
-            HIPCHK(h, launch_pack_conv_weights_ws(st, w, Cd, 0, h->dec_wmeta[l], h->dec_wsf[l]));
-            HIPCHK(h, launch_pack_conv_weights_ws(st, w, Cd, 1, h->dec_wmeta[l] + 2, h->dec_wsb[l]));
+            HIPCHK(h, pack_ws(w, Cd, 0, h->dec_wmeta[l], h->dec_wsf[l]));
+            HIPCHK(h, pack_ws(w, Cd, 1, h->dec_wmeta[l] + 2, h->dec_wsb[l]));
         } else {
-            HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cd, Cd, Cd, Cd, 0, h->dec_wmeta[l], h->dec_wf16[l]));
-            HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cd, Cd, Cd, Cd, 1, h->dec_wmeta[l] + 2, h->dec_wb16[l]));
+            HIPCHK(h, pack_f16(w, Cd, Cd, Cd, Cd, 0, h->dec_wmeta[l], h->dec_wf16[l]));
+            HIPCHK(h, pack_f16(w, Cd, Cd, Cd, Cd, 1, h->dec_wmeta[l] + 2, h->dec_wb16[l]));
         }
         HIPCHK(h, queue_copy(h->dec_b[l], P("decoder.mlc.layers." + std::to_string(l) + ".bias"), Cd));
     }
@@ -1027,24 +1048,24 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     if (refine_f16_ok(h)) {
         for (int l = 0; l < h->Dr; ++l) {
             const float* w = l == 0 ? w0 : P("refine.mlc.layers." + std::to_string(l) + ".weight");
-            HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cr, l == 0 ? 17 : Cr, l == 0 ? 32 : Cr, Cr, 0, h->ref_wmeta[l],
+            HIPCHK(h, pack_f16(w, Cr, l == 0 ? 17 : Cr, l == 0 ? 32 : Cr, Cr, 0, h->ref_wmeta[l],
                                                    h->ref_wf16[l]));
             if (l > 0)
-                HIPCHK(h, launch_pack_conv_weights_f16(st, w, Cr, Cr, Cr, Cr, 2, h->ref_wmeta[l] + 2, h->ref_wb16[l]));
+                HIPCHK(h, pack_f16(w, Cr, Cr, Cr, Cr, 2, h->ref_wmeta[l] + 2, h->ref_wb16[l]));
         }
         // split first layer (refine_split): the same weights in the internal channel order, packed as two 16-channel convs
         HIPCHK(h, launch_ref_split_weights(st, w0, Cr, h->ref_wk, h->ref_wsh));
-        HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wk, Cr, 12, 16, Cr, 0, h->ref_wkmeta, h->ref_wk16));
-        HIPCHK(h, launch_pack_conv_weights_f16(st, h->ref_wsh, Cr, 8, 16, Cr, 0, h->ref_wshmeta, h->ref_wsh16));
+        HIPCHK(h, pack_f16(h->ref_wk, Cr, 12, 16, Cr, 0, h->ref_wkmeta, h->ref_wk16));
+        HIPCHK(h, pack_f16(h->ref_wsh, Cr, 8, 16, Cr, 0, h->ref_wshmeta, h->ref_wsh16));
         if (h->ref_l0k) {                                      // fused encoding + layer 0: both parts as K = 16 MFMA operands
             HIPCHK(h, launch_refine_l0_pack(st, h->ref_wk, Cr, 12, h->ref_l0kmeta, h->ref_l0k));
             HIPCHK(h, launch_refine_l0_pack(st, h->ref_wsh, Cr, 8, h->ref_l0smeta, h->ref_l0s));
         }
         if (Cr == 64)                                           // weight-stationary forward of layers 1 ..
             for (int l = 1; l < h->Dr; ++l)
-                HIPCHK(h, launch_pack_conv_weights_ws(st, P("refine.mlc.layers." + std::to_string(l) + ".weight"), Cr, 0, h->ref_wsf_meta[l], h->ref_wsf[l]));
+                HIPCHK(h, pack_ws(P("refine.mlc.layers." + std::to_string(l) + ".weight"), Cr, 0, h->ref_wsf_meta[l], h->ref_wsf[l]));
         if (h->Dr >= 2 && refine_bwd01_ok(h->S, Cr))           // fused layer-1 / layer-0 backward: W1 as the transposed conv's A operand
-            HIPCHK(h, launch_pack_conv_weights_ws(st, P("refine.mlc.layers.1.weight"), Cr, 1, h->ref_w1ws_meta, h->ref_w1ws));
+            HIPCHK(h, pack_ws(P("refine.mlc.layers.1.weight"), Cr, 1, h->ref_w1ws_meta, h->ref_w1ws));
     }
     }   // !generic
     auto copy_raw = [&](float* dst, const std::string& name) {
@@ -1068,6 +1089,7 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     HIPCHK(h, queue_copy(h->init_mean, P("posterior.init_mean"), L));
     HIPCHK(h, queue_copy(h->init_logvar, P("posterior.init_logvar"), L));
     HIPCHK(h, launch_multi_copy(st, mc));
+    if (!pj.empty()) HIPCHK(h, launch_pack_batch(st, pj.data(), (int)pj.size()));      // (behind ref_split / enc_expand: stream order)
     h->params_set = true;
     h->fwd_done = false;
     return IODINE_OK;

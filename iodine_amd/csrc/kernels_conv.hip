@@ -6,6 +6,7 @@
 // v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain, so results differ from the CPU path only
 // by summation order.
 #include "common.h"
+#include "pack_bodies.h"
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
@@ -455,25 +456,10 @@ __global__ void pack_conv_weights_f16_kernel(const float* __restrict__ src, int 
                                              const float* __restrict__ meta, _Float16* __restrict__ dst)
 {
     const float scale = meta[0];
-    const size_t total = (size_t)(cin / 16) * 9 * 2 * 2 * cout * 8;
+    const size_t total = pack_f16_total(cin, cout);
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int e = idx & 7;
-        size_t r = idx >> 3;
-        const int co = r % cout; r /= cout;
-        const int kh = r & 1; r >>= 1;
-        const int term = r & 1; r >>= 1;
-        const int tap = r % 9;
-        const int chunk = r / 9;
-        const int ci = chunk * 16 + kh * 8 + e;
-        float v = 0.f;
-        if (!tflip) { if (ci < I && co < O) v = src[((size_t)co * I + ci) * 9 + tap]; }
-        else if (tflip == 1) { if (ci < O && co < I) v = src[((size_t)ci * I + co) * 9 + (8 - tap)]; }
-        else { if (ci < O && co < I) v = src[((size_t)ci * I + co) * 9 + tap]; }
-        v *= scale;
-        const _Float16 hi = (_Float16)v;
-        dst[idx] = term == 0 ? hi : (_Float16)(v - (float)hi);
-    }
+         idx += (size_t)gridDim.x * blockDim.x)
+        dst[idx] = pack_f16_element(src, O, I, cout, tflip, scale, idx);
 }
 
 hipError_t launch_pack_conv_weights_f16(hipStream_t st, const float* src, int O, int I, int cin, int cout, int tflip,

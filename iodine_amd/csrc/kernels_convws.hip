@@ -19,6 +19,7 @@
 //     reduces the max itself (one more barrier per chunk).
 // Output and ELU' operand move as one float4 (4 channels) per lane and row: 16 pixels x 64 contiguous bytes per instruction.
 #include "common.h"
+#include "pack_bodies.h"
 #include <cstdio>
 #include <vector>
 
@@ -30,42 +31,15 @@ __global__ void pack_conv_weights_ws_kernel(const float* __restrict__ src, int C
                                             _Float16* __restrict__ dst)
 {
     const float scale = meta[0];
-    const int nchunk = C / 32;
-    const size_t total = (size_t)(C / 16) * nchunk * 9 * 2 * 64 * 8;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int e = idx & 7;
-        size_t r = idx >> 3;
-        const int lane = r & 63; r >>= 6;
-        const int hl = r & 1; r >>= 1;
-        const int tap = r % 9; r /= 9;
-        const int c = r % nchunk;
-        const int cg = (int)(r / nchunk);
-        const int co = 16 * cg + (lane & 15), ci = 32 * c + 8 * (lane >> 4) + e;
-        // forward: W[co][ci][tap]; data gradient: the transposed conv, W[ci][co][8 - tap] (roles of the channel axes swapped)
-        float v = tflip ? src[((size_t)ci * C + co) * 9 + (8 - tap)] : src[((size_t)co * C + ci) * 9 + tap];
-        v *= scale;
-        const _Float16 hi = (_Float16)v;
-        dst[idx] = hl == 0 ? hi : (_Float16)(v - (float)hi);
-    }
+    const size_t total = pack_ws_total(C);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+        dst[idx] = pack_ws_element(src, C, tflip, scale, idx);
 }
 
 __global__ __launch_bounds__(1024) void weight_scale_ws_kernel(const float* __restrict__ w, int n, float* __restrict__ meta)
 {
     __shared__ float s_red[16];
-    float m = 0.f;
-    for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(w[i]));
-    m = wave_max_f32(m);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float mx = 0.f;
-        for (int k = 0; k < 16; ++k) mx = fmaxf(mx, s_red[k]);
-        int e = 0;
-        const bool ok = mx > 0.f && isfinite(mx);
-        if (ok) frexpf(mx, &e);
-        meta[0] = ok ? ldexpf(1.f, 13 - e) : 1.f;                   // max |w| * scale in [2^12, 2^13)
-        meta[1] = 1.f / meta[0];
-    }
+    weight_scale_block(w, n, meta, s_red);
 }
 
 hipError_t launch_pack_conv_weights_ws(hipStream_t st, const float* src, int C, int tflip, float* meta, void* dst)

@@ -152,6 +152,86 @@ __global__ void pixel_finalize_kernel(const double* __restrict__ part, int nblk,
     }
 }
 
+// ---- finalize + KL against N(0, 1) (iodine.py:653-659,191-193) + ELBO assembly in ONE launch (three until round 4: 5 us each behind a
+// 50 us kernel, six times per step).  Block b: image b.  img_terms[b] = {ll_b, kl_b}; the LAST block to finish (device-scope counter, reset by
+// that block) forms scal = {elbo, kl, ll} as the means over the images in fixed order - same arithmetic as kl_image_kernel /
+// elbo_mean_kernel (kernels_misc.hip), which remain for the public iodine_elbo path.
+__global__ __launch_bounds__(256)
+void pixel_finalize_elbo_kernel(const double* __restrict__ part, int nblk, int K, int P, int use_ln, float* __restrict__ lnstat,
+                                float* __restrict__ ll_img, const float* __restrict__ pm, const float* __restrict__ plv, int KL_,
+                                float* __restrict__ img_terms, float* __restrict__ scal, unsigned* __restrict__ counter)
+{
+    const int b = blockIdx.x, tid = threadIdx.x, B = gridDim.x;
+    const int NST = 6 * K + 3;
+    __shared__ double s_sum[6 * 16 + 3];
+    __shared__ float s_buf[4];
+    __shared__ unsigned s_last;
+    if (tid < NST) {
+        double v = 0.0;
+        int i = 0;
+        for (; i + 7 < nblk; i += 8) {
+            double q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = part[((size_t)b * nblk + i + j) * NST + tid];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v += q[j];
+        }
+        for (; i < nblk; ++i) v += part[((size_t)b * nblk + i) * NST + tid];
+        s_sum[tid] = v;
+    }
+    float s = 0.f;
+    for (int i = tid; i < KL_; i += 256) {
+        const float mu = pm[(size_t)b * KL_ + i], lv = plv[(size_t)b * KL_ + i];
+        s += 0.5f * (expf(lv) + mu * mu - 1.f - lv);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((tid & 63) == 0) s_buf[tid >> 6] = s;
+    __syncthreads();
+    if (tid < K) {
+        float* o = lnstat + ((size_t)b * K + tid) * 8;
+        const double cnt[4] = {3.0 * P, (double)P, (double)P, (double)P};
+        const double s1[4] = {s_sum[3 + 6 * tid + 0], s_sum[3 + 6 * tid + 2], s_sum[3 + 6 * tid + 4], s_sum[1]};
+        const double s2[4] = {s_sum[3 + 6 * tid + 1], s_sum[3 + 6 * tid + 3], s_sum[3 + 6 * tid + 5], s_sum[2]};
+        for (int j = 0; j < 4; ++j) {
+            const double mean = s1[j] / cnt[j];
+            double var = s2[j] / cnt[j] - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float sd = (float)sqrt(var);
+            o[2 * j + 0] = use_ln ? (float)mean : 0.f;
+            o[2 * j + 1] = use_ln ? 1.f / (sd + 1e-5f) : 1.f;
+        }
+    }
+    if (tid == 0) {
+        const float ll = (float)s_sum[0];
+        const float kl = ((s_buf[0] + s_buf[1]) + s_buf[2]) + s_buf[3];       // block_sum_f's order
+        ll_img[b] = ll;
+        img_terms[2 * b] = ll; img_terms[2 * b + 1] = kl;
+        __threadfence();                                                      // release: the two terms before the ticket
+        s_last = atomicAdd(counter, 1u) == (unsigned)(B - 1);
+    }
+    __syncthreads();
+    if (s_last) {                                                             // block-uniform
+        __threadfence();                                                      // acquire: the other blocks' terms
+        __shared__ float s_t[2 * 256];
+        double ll = 0.0, kl = 0.0;
+        for (int i0 = 0; i0 < B; i0 += 256) {                                 // loads in parallel, sums in image order (elbo_mean_kernel's)
+            if (i0 + tid < B) {
+                s_t[2 * tid] = __builtin_nontemporal_load(img_terms + 2 * (i0 + tid));
+                s_t[2 * tid + 1] = __builtin_nontemporal_load(img_terms + 2 * (i0 + tid) + 1);
+            }
+            __syncthreads();
+            if (tid == 0)
+                for (int i = 0; i < min(256, B - i0); ++i) { ll += s_t[2 * i]; kl += s_t[2 * i + 1]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            ll /= B; kl /= B;
+            scal[0] = (float)(ll - kl); scal[1] = (float)kl; scal[2] = (float)ll;
+            *counter = 0u;                                                    // (next launch: stream order)
+        }
+    }
+}
+
 // ---- pass 2: write the refinement input, NHWC with 20 channels (17 + 3 zero pad) -----------------
 // SPLIT form (split first refinement layer): the 11 channels that differ between the slots of an image go to
 //   enc[n][p][12]    = mean rgb, mask, mask logit, mask posterior, LN(d mean) rgb, LN(d mask), LN(leave-one-out), 0
@@ -321,6 +401,16 @@ hipError_t launch_pixel_finalize(hipStream_t st, const double* part, int B, int 
     IOD_XSKIP(8);
     hipLaunchKernelGGL(pixel_finalize_kernel, dim3(B), dim3(128), 0, st, part, pixel_blocks_per_image(P), K, P,
                        use_ln, lnstat, ll_img);
+    return hipGetLastError();
+}
+
+hipError_t launch_pixel_finalize_elbo(hipStream_t st, const double* part, int B, int K, int P, int use_ln, float* lnstat, float* ll_img,
+                                      const float* pm, const float* plv, int L, float* img_terms, float* scal, unsigned* counter)
+{
+    IOD_XSKIP(8);
+    if (6 * K + 3 > 99 || !counter) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pixel_finalize_elbo_kernel, dim3(B), dim3(256), 0, st, part, pixel_blocks_per_image(P), K, P, use_ln, lnstat, ll_img,
+                       pm, plv, K * L, img_terms, scal, counter);
     return hipGetLastError();
 }
 

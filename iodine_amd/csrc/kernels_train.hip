@@ -516,10 +516,105 @@ void sgemm_kernel(int ta, int tb, int M, int N, int K, float alpha, const float*
     }
 }
 
+// ---- C[M][N] = alpha * A^T . B + beta * C for A [K][M], B [K][N] (the "sum of outer products over rows" shape of every weight gradient of the
+// refinement head and of the broadcast layer's latent channels) on v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate.  Both
+// operands are K-major, so a lane's operand element of MFMA step k is A[k + lane / 32][m0 + lane % 32]: 128 contiguous bytes per half wave,
+// straight from global memory (L2-resident) into the operand register - no LDS, no transposes.  A wave owns a 32 x 32 tile of C;
+//   * SPLITK = false: four tiles per block (the 1024 x 512 x 1120 LSTM gradient: 512 tiles; 16 x 16 scalar LDS tiles took 100 us);
+//   * SPLITK = true: ONE tile per block, its four waves take a quarter of K each and are added in wave order through LDS (deterministic) -
+//     for products with few tiles (64 x 256, K = 1120: 16 tiles).
+// MODE 1 writes through the broadcast layer's index map: row = latent channel ci, column = tap * C + co -> gw[co][ci][tap] (ldc = L + 2).
+template <bool SPLITK, int MODE>
+__global__ __launch_bounds__(256)
+void sgemm_tn_mfma_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                          float beta, float* __restrict__ Cm, int ldc, int mode_c)
+{
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    __shared__ float s_red[SPLITK ? 3 * 1024 : 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tiles_n = N / 32, ntiles = (M / 32) * tiles_n;
+    const int tile = SPLITK ? (int)blockIdx.x : (int)blockIdx.x * 4 + wv;
+    if (tile >= ntiles) return;                              // (wave-uniform; no barrier below unless SPLITK, where it is block-uniform)
+    const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
+    int k0 = 0, k1 = K;
+    if (SPLITK) {
+        const int per = ((K + 3) / 4 + 1) & ~1;              // even: a wave's range starts on an MFMA step
+        k0 = min(K, wv * per); k1 = min(K, k0 + per);
+    }
+    const float* pa = A + m0 + (lane & 31);
+    const float* pb = B + n0 + (lane & 31);
+    const int kh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    constexpr int U = 32;                                    // MFMA steps per group: 2 U loads in flight under the previous group's MFMAs (U = 16:
+                                                             // 1024 matrix cycles per group did not cover an L2 round trip under load - 61 us for the LSTM gradient)
+    float a[U], b[U];
+    auto fetch = [&](int k) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = k + 2 * u + kh;
+            const int kc = min(kk, K - 1);                   // unconditional loads at a clamped row; rows past the range count as zero
+            const float av = pa[(size_t)kc * lda], bv = pb[(size_t)kc * ldb];
+            a[u] = kk < k1 ? av : 0.f; b[u] = bv;
+        }
+    };
+    if (k0 < k1) fetch(k0);
+    for (int k = k0; k < k1; k += 2 * U) {
+        float ca[U], cb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { ca[u] = a[u]; cb[u] = b[u]; }
+        if (k + 2 * U < k1) fetch(k + 2 * U);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[u], cb[u], acc, 0, 0, 0);
+    }
+    if (SPLITK) {
+        // waves 1 - 3 hand their partial tiles to wave 0: [wave - 1][reg][lane], added in wave order
+        if (wv > 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s_red[(wv - 1) * 1024 + i * 64 + lane] = acc[i];
+        }
+        __syncthreads();
+        if (wv > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += s_red[w * 1024 + i * 64 + lane];
+    }
+    const int col = n0 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+        float* c;
+        if (MODE == 1) { const int tap = col / mode_c, co = col % mode_c; c = Cm + ((size_t)co * ldc + row) * 9 + tap; }
+        else c = Cm + (size_t)row * ldc + col;
+        *c = alpha * acc[i] + (beta != 0.f ? beta * *c : 0.f);
+    }
+}
+
+bool sgemm_tn_mfma_ok(int M, int N, int K) { return M % 32 == 0 && N % 32 == 0 && K >= 1; }
+
+// mode 0: C row-major [M][ldc]; mode 1: the broadcast-layer map (see above), mode_c = C channels, ldc = L + 2
+hipError_t launch_sgemm_tn_mfma(hipStream_t st, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
+                                float beta, float* C, int ldc, int mode, int mode_c)
+{
+    IOD_XSKIP(2);
+    if (!sgemm_tn_mfma_ok(M, N, K) || (mode == 1 && (mode_c < 1 || N != 9 * mode_c))) return hipErrorInvalidValue;
+    const int ntiles = (M / 32) * (N / 32);
+    const bool splitk = ntiles <= 512 && K >= 64;            // (two waves per SIMD at 512 tiles: one computes while the other waits)
+#define TN_LAUNCH(SK, MD, GRID) hipLaunchKernelGGL((sgemm_tn_mfma_kernel<SK, MD>), dim3(GRID), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, \
+                                                   beta, C, ldc, mode_c)
+    if (splitk) { if (mode == 1) TN_LAUNCH(true, 1, ntiles); else TN_LAUNCH(true, 0, ntiles); }
+    else { if (mode == 1) TN_LAUNCH(false, 1, (ntiles + 3) / 4); else TN_LAUNCH(false, 0, (ntiles + 3) / 4); }
+#undef TN_LAUNCH
+    return hipGetLastError();
+}
+
 hipError_t launch_sgemm(hipStream_t st, int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
                         const float* B, int ldb, float beta, float* C, int ldc)
 {
     IOD_XSKIP(2);
+    if (ta && !tb && sgemm_tn_mfma_ok(M, N, K)) return launch_sgemm_tn_mfma(st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 0, 0);
     // (the long-K form only where the grid leaves the chip mostly empty: with >= 1024 blocks its 34 KB of LDS costs occupancy -
     // 99 -> 111 us for the 1024 x 512 x 1120 weight gradient)
     if (K >= 512 && ((N + 15) / 16) * ((M + 15) / 16) <= 512)
