@@ -118,13 +118,16 @@ IOD_DEVINL float4 rot4(const float4 v, int r)
     return o;
 }
 
-// (x0, x1) -> packed fp16 pairs hi, lo with x = hi + lo: hi = x truncated to 11 significant bits (mask; exact in fp16 for
-// the scaled range), lo = x - hi (exact in fp32), each pair packed by one v_cvt_pkrtz (same scheme as the tile kernels)
+// (x0, x1) -> packed fp16 pairs hi, lo with x = hi + lo: hi = x rounded toward zero to fp16 (v_cvt_pkrtz: the 11 leading bits for the scaled
+// range), lo = x - hi (exact in fp32; hipcc emits v_fma_mix_f32 with the fp16 hi as a source and folds the caller's power-of-two scale multiply
+// into it), each pair packed by one v_cvt_pkrtz: 6 VALU instructions per pair where the mask-and-subtract form took 8 - every split site was
+// instruction-issue-bound (one VALU instruction per 4 cycles and wave).  Same bits as the mask form except below the fp16 normal range, where
+// lo now also carries what the conversion of hi dropped.
 IOD_DEVINL unsigned pack_hi_lo(float x0, float x1, unsigned& lo_out)
 {
     typedef __fp16 h2_ __attribute__((ext_vector_type(2)));
-    const float h0 = __uint_as_float(__float_as_uint(x0) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(x1) & 0xffffe000u);
-    const h2_ hi = __builtin_amdgcn_cvt_pkrtz(h0, h1), lo = __builtin_amdgcn_cvt_pkrtz(x0 - h0, x1 - h1);
+    const h2_ hi = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    const h2_ lo = __builtin_amdgcn_cvt_pkrtz(x0 - (float)hi.x, x1 - (float)hi.y);
     unsigned uh;
     __builtin_memcpy(&uh, &hi, 4); __builtin_memcpy(&lo_out, &lo, 4);
     return uh;

@@ -1812,11 +1812,9 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
                 unsigned char* sb = reinterpret_cast<unsigned char*>(smem_ws + (q & 1) * BUF_DW);
                 auto split_store = [&](const f32x4 w, float scale, unsigned char* dst, int lo_off) {
                     const float x = w.x * scale, y = w.y * scale, z = w.z * scale, t = w.w * scale;
-                    const float hx = __uint_as_float(__float_as_uint(x) & 0xffffe000u), hy = __uint_as_float(__float_as_uint(y) & 0xffffe000u);
-                    const float hz = __uint_as_float(__float_as_uint(z) & 0xffffe000u), hw = __uint_as_float(__float_as_uint(t) & 0xffffe000u);
                     typedef __fp16 h2_ __attribute__((ext_vector_type(2)));
-                    const h2_ h01 = __builtin_amdgcn_cvt_pkrtz(hx, hy), h23 = __builtin_amdgcn_cvt_pkrtz(hz, hw);
-                    const h2_ l01 = __builtin_amdgcn_cvt_pkrtz(x - hx, y - hy), l23 = __builtin_amdgcn_cvt_pkrtz(z - hz, t - hw);
+                    const h2_ h01 = __builtin_amdgcn_cvt_pkrtz(x, y), h23 = __builtin_amdgcn_cvt_pkrtz(z, t);      // (rounding toward zero = the 11 leading bits)
+                    const h2_ l01 = __builtin_amdgcn_cvt_pkrtz(x - (float)h01.x, y - (float)h01.y), l23 = __builtin_amdgcn_cvt_pkrtz(z - (float)h23.x, t - (float)h23.y);   // v_fma_mix_f32
                     uint2 hi, lo;
                     __builtin_memcpy(&hi.x, &h01, 4); __builtin_memcpy(&hi.y, &h23, 4);
                     __builtin_memcpy(&lo.x, &l01, 4); __builtin_memcpy(&lo.y, &l23, 4);
