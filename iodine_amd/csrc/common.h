@@ -280,7 +280,7 @@ hipError_t launch_pack_dec_out_dgrad(hipStream_t st, const float* w, int C, cons
 hipError_t launch_dec_out_dgrad_f16x3(hipStream_t st, const float* g, const void* wpk, const float* wmeta, const float* aux,
                                       float* out, int N, int S, int C, float* tmax = nullptr);
 hipError_t launch_dec_out_stream_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
-                                       const float* bias, float* out, int N, int S, int C);
+                                       const float* bias, float* out, int N, int S, int C, const float* tmax = nullptr);
 
 // kernels_convws.hip: weight-stationary split-fp16 3x3 conv C -> C (weights in registers, persistent blocks)
 hipError_t launch_pack_conv_weights_ws(hipStream_t st, const float* src, int C, int tflip, float* meta, void* dst);

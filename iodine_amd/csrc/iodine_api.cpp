@@ -490,7 +490,7 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N, const float* z, flo
     }
     if (h->precision == 1)
         PROF(h, st, "dec_out", launch_dec_out_stream_f16x3(st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b, out, N, h->S,
-                                                           h->Cd));
+                                                           h->Cd, ws ? b.tmax_act[h->Dd - 1] : nullptr));
     else
         PROF(h, st, "dec_out", launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, out, N, h->S, h->Cd));
     return IODINE_OK;

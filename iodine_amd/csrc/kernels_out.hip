@@ -21,10 +21,16 @@ typedef int i32x4_ __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
 }  // namespace
 
-template <int C>
+// TM: the power-of-two scale of a tile comes from the producer's per-cell max side buffer (tmax: 4 floats per 8 x 16 cell, written by the
+// weight-stationary conv / the broadcast layer; max over the 4 x 3 cells the 18 x 18 halo touches) instead of a max over every row-block's
+// own values: the kernel is VALU-issue-bound (compute alone 214 us, loads alone 220 us, together 266 us at cfg3: ~300 instructions per
+// row-block and wave), and the per-row-block max + wave reduction + scale + 32 multiplies by 1 / scale were 90 of them.  One scale per
+// tile also moves the rescale behind the 9-tap sum (4 multiplies per pixel).
+template <int C, bool TM>
 __global__ __launch_bounds__(256)
 void dec_out_stream_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
-                                 const float* __restrict__ bias, float4* __restrict__ out, int S, int tiles, int ntiles)
+                                 const float* __restrict__ bias, float4* __restrict__ out, int S, int tiles, int ntiles,
+                                 const float* __restrict__ tmax)
 {
     constexpr int NCHUNK = C / 16;
     constexpr int HALO = 18, NPX = HALO * HALO;                     // 324 halo pixels = 11 row-blocks of 32 (last partial)
@@ -69,18 +75,21 @@ void dec_out_stream_f16x3_kernel(const float* __restrict__ in, const uint4* __re
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(v[2 * c + 1]) : "v"(off), "s"(rsrc), "s"(soff) : "memory");
         }
     };
-    auto process = [&](int rb, auto nleft, f32x4 (&v)[NLD]) {
+    auto process = [&](int rb, auto nleft, f32x4 (&v)[NLD], float tile_sc) {
         constexpr int nl = decltype(nleft)::value;
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(nl) : "memory");
 #pragma unroll
         for (int k = 0; k < NLD; ++k) asm volatile("" : "+v"(v[k]));
         __builtin_amdgcn_sched_barrier(0);
-        float m = 0.f;
+        float scale = tile_sc;
+        if constexpr (!TM) {
+            float m = 0.f;
 #pragma unroll
-        for (int k = 0; k < NLD; ++k)
-            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)), fmaxf(fabsf(v[k].z), fabsf(v[k].w))));
-        m = wave_max_f32(m);
-        const float scale = tile_scale(m, 1.f);
+            for (int k = 0; k < NLD; ++k)
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)), fmaxf(fabsf(v[k].z), fabsf(v[k].w))));
+            m = wave_max_f32(m);
+            scale = tile_scale(m, 1.f);
+        }
         f32x16 acc[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -106,7 +115,7 @@ void dec_out_stream_f16x3_kernel(const float* __restrict__ in, const uint4* __re
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[nt], 0, 0, 0);
             }
         }
-        const float inv = inv_ws / scale;
+        const float inv = TM ? 1.f : inv_ws / scale;         // (TM: rescaled once per pixel behind the tap sum)
         // P rows of this row-block: accumulator register r of lane (li, kh) is pixel (r & 3) + 8 (r >> 2) + 4 kh, column li
         // (+32 for the second column tile, of which only columns 32..35 exist).  Row-block 10 holds pixels 320..323 only.
         float* pb = s_P + (rb * 32 + 4 * kh) * PSTR + li;
@@ -133,28 +142,51 @@ void dec_out_stream_f16x3_kernel(const float* __restrict__ in, const uint4* __re
     using std::integral_constant;
     const float4 b4 = make_float4(bias[0], bias[1], bias[2], bias[3]);
     f32x4 va[NLD], vb[NLD];
+    // (TM) cell maxima of the tile whose loads are in flight: lane i < 48 holds float i & 3 of cell (2 ty - 1 + i / 12, tx - 1 + (i / 4) % 3),
+    // clamped to the image; issued BEFORE the tile's row-blocks, so the counted waits below imply it
+    float tmv = 0.f;
+    auto issue_tmax = [&]() {
+        if constexpr (TM) {
+            const int cell = min(lane, 47) >> 2;
+            const int cy = min(max(2 * ty - 1 + cell / 3, 0), 2 * tiles - 1), cx = min(max(tx - 1 + cell % 3, 0), tiles - 1);
+            const float* p = tmax + (((size_t)n * 2 * tiles + cy) * tiles + cx) * 4 + (lane & 3);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(tmv) : "v"(p) : "memory");
+        }
+    };
     int t = blockIdx.x;
     set_tile(t);
+    issue_tmax();
     issue(rb_offset(wv), va);
     issue(rb_offset(wv + 4), vb);
     for (; t < ntiles; t += gridDim.x) {
         const int ctx = tx, cty = ty, cn = n;
-        process(wv, integral_constant<int, NLD>{}, va);
+        float tsc = 1.f;
+        if constexpr (TM) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NLD) : "memory");          // the tile's cell maxima (older than both row-blocks)
+            asm volatile("" : "+v"(tmv));
+            tsc = tile_scale(wave_max_f32(tmv), 1.f);
+        }
+        process(wv, integral_constant<int, NLD>{}, va, tsc);
         issue(rb_offset(wv + 8), va);
-        process(wv + 4, integral_constant<int, NLD>{}, vb);
-        process(wv + 8, integral_constant<int, 0>{}, va);
+        process(wv + 4, integral_constant<int, NLD>{}, vb, tsc);
+        process(wv + 8, integral_constant<int, 0>{}, va, tsc);
         if (t + (int)gridDim.x < ntiles) {                          // block-uniform
             set_tile(t + gridDim.x);
+            issue_tmax();
             issue(rb_offset(wv), va);
             issue(rb_offset(wv + 4), vb);
         }
         __syncthreads();
         const int y = tid >> 4, x = tid & 15;
-        float4 o = b4;
+        float4 o = TM ? make_float4(0.f, 0.f, 0.f, 0.f) : b4;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const float4 q = *reinterpret_cast<const float4*>(s_P + ((y + tap / 3) * HALO + x + tap % 3) * PSTR + tap * 4);
             o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+        }
+        if constexpr (TM) {
+            const float inv = inv_ws / tsc;
+            o = make_float4(b4.x + o.x * inv, b4.y + o.y * inv, b4.z + o.z * inv, b4.w + o.w * inv);
         }
         out[((size_t)cn * S + cty * 16 + y) * S + ctx * 16 + x] = o;
         __syncthreads();                                            // P tile free for the next tile
@@ -162,23 +194,19 @@ void dec_out_stream_f16x3_kernel(const float* __restrict__ in, const uint4* __re
 }
 
 hipError_t launch_dec_out_stream_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
-                                       const float* bias, float* out, int N, int S, int C)
+                                       const float* bias, float* out, int N, int S, int C, const float* tmax)
 {
     IOD_XSKIP(128);
     if (S % 16 != 0) return hipErrorInvalidValue;
     const int tiles = S / 16, ntiles = N * tiles * tiles;
     const int blocks = ntiles < 512 ? ntiles : 512;                 // two resident blocks per CU (63 KB LDS each), persistent
-    if (C == 64) {
-        constexpr size_t lds = (size_t)4 * 2 * 2 * 64 * 16 + 324 * 36 * 4;
-        hipLaunchKernelGGL((dec_out_stream_f16x3_kernel<64>), dim3(blocks), dim3(256), lds, st, in,
-                           reinterpret_cast<const uint4*>(wpk), wmeta, bias, reinterpret_cast<float4*>(out), S, tiles, ntiles);
-    } else if (C == 32) {
-        constexpr size_t lds = (size_t)2 * 2 * 2 * 64 * 16 + 324 * 36 * 4;
-        hipLaunchKernelGGL((dec_out_stream_f16x3_kernel<32>), dim3(blocks), dim3(256), lds, st, in,
-                           reinterpret_cast<const uint4*>(wpk), wmeta, bias, reinterpret_cast<float4*>(out), S, tiles, ntiles);
-    } else {
-        return hipErrorInvalidValue;
-    }
+#define DO_LAUNCH(CC, TMF) hipLaunchKernelGGL((dec_out_stream_f16x3_kernel<CC, TMF>), dim3(blocks), dim3(256),                                \
+                                              (size_t)(CC / 16) * 2 * 2 * 64 * 16 + 324 * 36 * 4, st, in, reinterpret_cast<const uint4*>(wpk), \
+                                              wmeta, bias, reinterpret_cast<float4*>(out), S, tiles, ntiles, tmax)
+    if (C == 64) { if (tmax) DO_LAUNCH(64, true); else DO_LAUNCH(64, false); }
+    else if (C == 32) { if (tmax) DO_LAUNCH(32, true); else DO_LAUNCH(32, false); }
+    else return hipErrorInvalidValue;
+#undef DO_LAUNCH
     return hipGetLastError();
 }
 
