@@ -63,7 +63,7 @@ PUBLISHED_TRAIN_ITERS_PER_S = 94.0  # 1.7 s / 32-image T=
 DOMINANT = ('conv_tile_fwd', 'conv_tile_dgrad', 'conv_tile_wgrad')
 PROFILE_STRIDE = 7                 # timed region: every 7th launch of each dominant form is bracketed with HIP events (library option profile_stride)
 CATS = DOMINANT + ('dec_out', 'dec_out_dgrad', 'dec_out_wgrad', 'dec_out_bwd', 'dec_l0', 'l0_reduce', 'l0_slot_sum', 'pixel_pass1',
-                   'pixel_pass2', 'refine_conv', 'refine_l0', 'refine_head', 'refine_wgrad', 'refine_dgrad', 'refine_bwd01', 'refine_bias_grad', 'head_bwd')
+                   'pixel_pass2', 'refine_conv', 'refine_l0', 'refine_l0f', 'refine_head', 'refine_wgrad', 'refine_dgrad', 'refine_bwd01', 'refine_bias_grad', 'head_bwd')
 
 
 def parse():
@@ -212,6 +212,9 @@ def hbm_algorithmic_bytes(arch, B, mode):
     # first layer: per-image part (reads 8 floats per image-pixel, writes a map) + per-slot part (reads 12 floats per
     # slot-pixel and the map, writes the activation): two launches
     b['refine_l0'] = (per_layer[0][0] + per_layer[0][1] + 2 * 4.0 * B * (S // 2) * (S // 2) * Cr) / 2.0
+    # round 4: encoding + first layer in one kernel (refine_l0f): reads the decoder output and the image, writes the layer's output; the
+    # encoding itself is only written in training (the backward reads it)
+    b['refine_l0f'] = out4 + x4 + per_layer[0][1] + (enc if mode == 'train' else 0.0)
     if Dr > 1:
         b['refine_conv'] = sum(i + o for i, o in per_layer[1:]) / (Dr - 1)
     if mode == 'train':                                      # one batch of T * N slot-images per layer

@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 HELPERS = (('dec_out_stream_f16x3_kernel', 'dec_out'), ('dec_out_bwd_fused_f16x3_kernel', 'dec_out_bwd'), ('dec_l0_cells_kernel', 'dec_l0'),
            ('dec_out_dgrad_f16x3_kernel', 'dec_out_dgrad'), ('pixel_pass1_kernel', 'pixel_pass1'), ('pixel_pass2_kernel', 'pixel_pass2'),
            ('l0_rows_reduce_kernel', 'l0_reduce'), ('refine_head', 'refine_head'), ('conv3x3_s2_wgrad_f16x3_kernel', 'refine_wgrad'),
-           ('refine_bwd01_kernel', 'refine_bwd01'), ('conv3x3_s2ws_f16x3_kernel', 'refine_conv'))
+           ('refine_bwd01_kernel', 'refine_bwd01'), ('conv3x3_s2ws_f16x3_kernel', 'refine_conv'), ('refine_l0_fused_kernel', 'refine_l0f'))
 
 
 def category(name):
