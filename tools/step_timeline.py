@@ -31,7 +31,7 @@ def main(path, anchor='adam_multi_kernel', dump=False):
         if (n, s, e) == rows[b]:
             buckets['<2' if gap < 2 else '2-5' if gap < 5 else '5-20' if gap < 20 else '>=20'] += gap
             break
-        k = n.split('(')[0][-60:]
+        k = n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][-64:]
         d = per.setdefault(k, [0, 0.0, 0.0])
         d[0] += 1; d[1] += (e - s) / 1e3; d[2] += gap
         buckets['<2' if gap < 2 else '2-5' if gap < 5 else '5-20' if gap < 20 else '>=20'] += gap
