@@ -406,3 +406,28 @@ def test_batches_beyond_one_library_call_run_in_chunks():
 
 def IODINE_chunks(m, B):
     return m._chunks(B, m.max_batch())
+
+
+def test_profile_stride_brackets_every_nth_dominant_launch():
+    """option profile_stride (bench.py: 7): level-1 profiling brackets every n-th launch of a dominant category with HIP events - the
+    bracketed count and the 'seen:' count of iodine_profile_read must be consistent, and the result of the step must not depend on it."""
+    g = load_golden('cfg3_clevr_k7_t5_b1')
+    arch, params, x, eps, _ = golden_setup(g)
+    m = make_hip_model(arch, params)
+    xd, ed = x.to(DEV), eps.to(DEV)
+    ref = m.reconstruct(xd, ed)[0].clone()
+    m.profile_read('conv_tile_fwd'); m.profile_read('seen:conv_tile_fwd')
+    m.set_option('profile_stride', 4)
+    m.set_option('profile', 1)
+    out = m.reconstruct(xd, ed)[0]
+    torch.cuda.synchronize()
+    m.set_option('profile', 0)
+    tot, cnt = m.profile_read('conv_tile_fwd')
+    _, seen = m.profile_read('seen:conv_tile_fwd')
+    layers = arch.dec_layers - 1 if hasattr(arch, 'dec_layers') else 3
+    assert seen == (arch.iters + 1) * layers, (seen, cnt)                 # every 64 -> 64 forward launch of T + 1 decodes
+    assert cnt == (seen + 3) // 4 and tot > 0.0
+    assert torch.equal(out, ref)
+    m.set_option('profile_stride', 1)
+    with pytest.raises(RuntimeError):
+        m.set_option('profile_stride', 0)
