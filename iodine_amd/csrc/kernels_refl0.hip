@@ -108,6 +108,7 @@ void refine_l0_fused_kernel(const float4* __restrict__ x4, const float4* __restr
                                                                               // from the producer lanes (lane % 16: 4-way conflicts); three buffers:
                                                                               // written for unit it, read for unit it - 1, zeroed for unit it + 1
     float* s_bias = reinterpret_cast<float*>(s_max + 3 * NPL * 16);           // [C]
+    float* s_sc = s_bias + C;                                                 // [4 consumer waves][16]: plane scales of the unit being consumed
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,87 +136,106 @@ void refine_l0_fused_kernel(const float4* __restrict__ x4, const float4* __restr
         const float inv_wk = wkmeta[1], inv_ws = wsmeta[1];
         const float4 bq = *reinterpret_cast<const float4*>(s_bias + 16 * cg + 4 * lkb);
         const unsigned zoff = (unsigned)(2 * BUFB);
-        // fragment of (plane, halo row r, tap column kx): 4 fp32 channels (k quarter lkb) of pixel column lpx, scaled and split into fp16 hi / lo
-        // here (in the shadow of the MFMAs); quarters >= nq read the zero slot.  The 15 fragments of a plane are fetched one plane ahead (a
-        // wave is alone on its SIMD: nothing else hides the LDS latency), rows are consumed in the order 0 3 1 4 2 so that consecutive MFMAs
-        // alternate between the two accumulators.
-        auto load_plane = [&](unsigned pbase, int nq, float4 (&raw)[15]) {
-            const unsigned base = lkb < nq ? pbase + (unsigned)(lpx * L0_PXB + lkb * 16) : zoff;
-            const unsigned step = lkb < nq ? (unsigned)L0_PXB : 0u;
-#pragma unroll
-            for (int r = 0; r < L0_HR; ++r)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int pos = r * L0_HC + (kx == 1 ? 17 : (kx == 2 ? 1 : 0));
-                    raw[r * 3 + kx] = *reinterpret_cast<const float4*>(smem_l0 + base + step * (unsigned)pos);
-                }
-        };
-        auto conv_plane = [&](const float4 (&raw)[15], float scale, const f16x4 (&wh)[9], const f16x4 (&wl)[9], f32x4 (&acc)[2]) {
-            acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
-#pragma unroll
-            for (int ri = 0; ri < L0_HR; ++ri) {
-                const int r = ri == 0 ? 0 : (ri == 1 ? 3 : (ri == 2 ? 1 : (ri == 3 ? 4 : 2)));
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float4 v = raw[r * 3 + kx];
-                    unsigned h[2], l[2];
-                    h[0] = pack_hi_lo(v.x * scale, v.y * scale, l[0]);
-                    h[1] = pack_hi_lo(v.z * scale, v.w * scale, l[1]);
-                    f16x4 fh, fl;
-                    __builtin_memcpy(&fh, h, 8); __builtin_memcpy(&fl, l, 8);
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) {
-                        const int ky = r - 2 * y;
-#ifdef L0_DBG_NOCONS
-                        if (ky == 0 && kx == 0) acc[y] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[0], fh, acc[y], 0, 0, 0);
-                        else if (ky >= 0 && ky <= 2) acc[y][0] += (float)fl[0];
-                        continue;
-#endif
-                        if (ky >= 0 && ky <= 2) {
-                            acc[y] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[ky * 3 + kx], fl, acc[y], 0, 0, 0);
-                            acc[y] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl[ky * 3 + kx], fh, acc[y], 0, 0, 0);
-                            acc[y] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[ky * 3 + kx], fh, acc[y], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        };
-        auto plane_scale = [&](const unsigned* mxp, int k) {
+        // The producers leave fp32 planes (the scale needs the maxima of all three producer waves).  Step 1 of a unit: the four consumer waves
+        // turn them into fp16 hi | lo IN PLACE (48-byte pixel: 12 fp32 -> 12 hi + 12 lo fp16), a quarter of the plane pixels each - every wave
+        // converting every fragment it uses (first form) was four times the work, and VALU issue slots are what this kernel runs out of (one
+        // VALU instruction per 4 cycles and SIMD, shared by the producer and the consumer wave of that SIMD).  Step 2, behind a barrier:
+        // fragment of (plane, halo row r, tap column kx) = 4 channels (k quarter lkb) of pixel column lpx as two ds_read_b64; quarters >= nq
+        // read the zero slot.  Rows in the order 0 3 1 4 2: consecutive MFMAs alternate between the two accumulators.
+        float* my_sc = s_sc + wv * 16;
+        auto plane_max_scale = [&](const unsigned* mxp, int k) {
             const uint4* q = reinterpret_cast<const uint4*>(mxp + k * 16);
             const uint4 a = q[0], b2 = q[1], c = q[2], d = q[3];
             const unsigned m = max(max(max(max(a.x, a.y), max(a.z, a.w)), max(max(b2.x, b2.y), max(b2.z, b2.w))),
                                    max(max(max(c.x, c.y), max(c.z, c.w)), max(max(d.x, d.y), max(d.z, d.w))));
             return l0_fresh_scale(__uint_as_float(m));
         };
+        auto convert_share = [&](unsigned bbase, const unsigned* mxp) {
+            // lanes 0 .. NPL - 1: the scale of plane `lane` -> this wave's table (wave-private: LDS operations of a wave complete in order)
+            my_sc[min(lane, 15)] = plane_max_scale(mxp, min(lane, NPL - 1));
+            constexpr int TOT = NPL * L0_NPX, NIT = (TOT + 255) / 256;
+#pragma unroll
+            for (int q = 0; q < NIT; ++q) {
+                const int e = wv * 64 + lane + 256 * q;
+                if (e < TOT) {
+                    const int plane = e / L0_NPX, pos = e - plane * L0_NPX;
+                    const float sc = my_sc[plane];
+                    float4* p = reinterpret_cast<float4*>(smem_l0 + bbase + (unsigned)(plane * L0_PLB + pos * L0_PXB));
+                    const float4 v0 = p[0], v1 = p[1], v2 = p[2];
+                    unsigned h[6], l[6];
+                    h[0] = pack_hi_lo(v0.x * sc, v0.y * sc, l[0]); h[1] = pack_hi_lo(v0.z * sc, v0.w * sc, l[1]);
+                    h[2] = pack_hi_lo(v1.x * sc, v1.y * sc, l[2]); h[3] = pack_hi_lo(v1.z * sc, v1.w * sc, l[3]);
+                    h[4] = pack_hi_lo(v2.x * sc, v2.y * sc, l[4]); h[5] = pack_hi_lo(v2.z * sc, v2.w * sc, l[5]);
+                    uint4* o = reinterpret_cast<uint4*>(p);
+                    o[0] = make_uint4(h[0], h[1], h[2], h[3]); o[1] = make_uint4(h[4], h[5], l[0], l[1]); o[2] = make_uint4(l[2], l[3], l[4], l[5]);
+                }
+            }
+        };
+        auto conv_plane = [&](unsigned pbase, int nq, const f16x4 (&wh)[9], const f16x4 (&wl)[9], f32x4 (&acc)[2]) {
+            const unsigned base = lkb < nq ? pbase + (unsigned)(lpx * L0_PXB + lkb * 8) : zoff;
+            const unsigned step = lkb < nq ? (unsigned)L0_PXB : 0u;
+            const unsigned lo_off = lkb < nq ? 24u : 0u;
+            uint2 fh[15], fl[15];
+#pragma unroll
+            for (int r = 0; r < L0_HR; ++r)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int pos = r * L0_HC + (kx == 1 ? 17 : (kx == 2 ? 1 : 0));
+                    const unsigned a = base + step * (unsigned)pos;
+                    fh[r * 3 + kx] = *reinterpret_cast<const uint2*>(smem_l0 + a);
+                    fl[r * 3 + kx] = *reinterpret_cast<const uint2*>(smem_l0 + a + lo_off);
+                }
+            acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+#pragma unroll
+            for (int ri = 0; ri < L0_HR; ++ri) {
+                const int r = ri == 0 ? 0 : (ri == 1 ? 3 : (ri == 2 ? 1 : (ri == 3 ? 4 : 2)));
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    f16x4 h4, l4;
+                    __builtin_memcpy(&h4, &fh[r * 3 + kx], 8); __builtin_memcpy(&l4, &fl[r * 3 + kx], 8);
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) {
+                        const int ky = r - 2 * y;
+#ifdef L0_DBG_NOCONS
+                        if (ky == 0 && kx == 0) acc[y] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[0], h4, acc[y], 0, 0, 0);
+                        else if (ky >= 0 && ky <= 2) acc[y][0] += (float)l4[0];
+                        continue;
+#endif
+                        if (ky >= 0 && ky <= 2) {
+                            acc[y] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[ky * 3 + kx], l4, acc[y], 0, 0, 0);
+                            acc[y] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl[ky * 3 + kx], h4, acc[y], 0, 0, 0);
+                            acc[y] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[ky * 3 + kx], h4, acc[y], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        };
         f32x4 sh[2];
         TP_DECL;
         for (int it = 0; it <= n_my; ++it) {
             TP_STAMP(0);
             const int j = it - 1, buf = j & 1;
+            const unsigned bbase = (unsigned)(buf * BUFB);
+            if (j >= 0) convert_share(bbase, s_max + (j % 3) * NPL * 16);
+            TP_STAMP(1);
+            l0_lds_barrier();                                 // every plane of the unit is fp16 now (the producers pass through)
+            TP_STAMP(2);
             if (j >= 0) {
                 const int u = (int)blockIdx.x + j * (int)gridDim.x;
                 const int b = u / tiles, t = u % tiles, ty = t / tiles_x, tx = t % tiles_x;
-                const unsigned bbase = (unsigned)(buf * BUFB);
-                const unsigned* mxp = s_max + (j % 3) * NPL * 16;
                 const int X = 16 * tx + lpx;
-                float4 rawa[15], rawb[15];
-                load_plane(bbase + (unsigned)(K * L0_PLB), 2, rawa);
                 {
                     f32x4 acc[2];
-                    const float sc = plane_scale(mxp, K);
-                    load_plane(bbase, 3, rawb);
-                    conv_plane(rawa, sc, wsh, wsl, acc);
-                    const float inv = inv_ws / sc;
+                    conv_plane(bbase + (unsigned)(K * L0_PLB), 2, wsh, wsl, acc);
+                    const float inv = inv_ws / my_sc[K];
                     sh[0] = acc[0] * inv + f32x4{bq.x, bq.y, bq.z, bq.w};
                     sh[1] = acc[1] * inv + f32x4{bq.x, bq.y, bq.z, bq.w};
                 }
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     f32x4 acc[2];
-                    const float sc = plane_scale(mxp, k);
-                    if (k + 1 < K) load_plane(bbase + (unsigned)((k + 1) * L0_PLB), 3, (k & 1) ? rawb : rawa);
-                    conv_plane((k & 1) ? rawa : rawb, sc, wkh, wkl, acc);
-                    const float inv = inv_wk / sc;
+                    conv_plane(bbase + (unsigned)(k * L0_PLB), 3, wkh, wkl, acc);
+                    const float inv = inv_wk / my_sc[k];
 #pragma unroll
                     for (int y = 0; y < 2; ++y) {
                         const int Y = 2 * ty + y;
@@ -225,9 +245,9 @@ void refine_l0_fused_kernel(const float4* __restrict__ x4, const float4* __restr
                     }
                 }
             }
-            TP_STAMP(1);
+            TP_STAMP(3);
             l0_lds_barrier();
-            TP_STAMP(2);
+            TP_STAMP(4);
         }
 #ifdef IODINE_TILE_PROF
         if (tid == 0 && blockIdx.x < TP_MAXBLK) for (int i_ = 0; i_ < 8; ++i_) g_l0_prof[blockIdx.x * 8 + i_] = tp_acc[i_];
@@ -280,6 +300,7 @@ void refine_l0_fused_kernel(const float4* __restrict__ x4, const float4* __restr
 #pragma unroll
                 for (int c = 0; c < 8; ++c) lnv[k][c] = lnb[k * 8 + c];
         }
+        l0_lds_barrier();                                     // the consumers' in-place conversion of the previous unit (they wait for every wave)
         PixelTerms<K> tm;
         const float4 xv = nxv;
         float psum = 1.f;
@@ -375,7 +396,7 @@ hipError_t l0_launch(hipStream_t st, const float* x4, const float* dec, const fl
                      const void* ws, const float* wsmeta, const float* bias, float* out, float* enck, float* encs, int B, int S, float sigma,
                      unsigned chmask)
 {
-    constexpr size_t lds = (size_t)2 * (K + 1) * L0_PLB + 16 + (size_t)3 * (K + 1) * 64 + 64 * 4 + 64;
+    constexpr size_t lds = (size_t)2 * (K + 1) * L0_PLB + 16 + (size_t)3 * (K + 1) * 64 + 64 * 4 + 64 * 4 + 64;
     static std::atomic<unsigned> attr_devs{0}, attr_devs2{0};
     if (hipError_t e = iod_set_max_lds((const void*)refine_l0_fused_kernel<K, true>, (int)lds, attr_devs); e != hipSuccess) return e;
     if (hipError_t e = iod_set_max_lds((const void*)refine_l0_fused_kernel<K, false>, (int)lds, attr_devs2); e != hipSuccess) return e;
@@ -397,7 +418,7 @@ hipError_t l0_launch(hipStream_t st, const float* x4, const float* dec, const fl
         std::vector<unsigned> hp((size_t)2 * TP_MAXBLK * 8);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(g_l0_prof), hp.size() * sizeof(unsigned));
-        static const char* pn[5] = {"loop", "work", "barrier", "-", "-"};
+        static const char* pn[5] = {"loop", "convert / work", "barrier", "mfma / -", "barrier"};
         for (int role = 0; role < 2; ++role) {
             double sum[8] = {0}, tot = 0;
             for (int b2 = 0; b2 < nb; ++b2) for (int i = 0; i < 8; ++i) sum[i] += hp[((size_t)role * TP_MAXBLK + b2) * 8 + i];
