@@ -221,7 +221,7 @@ hipError_t launch_refine_head(hipStream_t st, const float* feat, int N, int PL, 
                               const float* lstm_b, const float* wmT, const float* bm, const float* wvT, const float* bv,
                               const float* latent, const float* h_prev, const float* c_prev, float* h_out, float* c_out,
                               float* pm, float* plv, float* sv_pooled, float* sv_s, float* sv_gates, float* sv_xin,
-                              float* d_mean, float* d_logvar);
+                              float* d_mean, float* d_logvar, float* xh = nullptr, float* gp = nullptr);
 hipError_t launch_transpose(hipStream_t st, const float* src, float* dst, int R, int Cc);
 hipError_t launch_add2(hipStream_t st, const float* a, const float* b, float* o, int n);
 hipError_t launch_pack_dec_out(hipStream_t st, const float* w, float* wk, int C);
@@ -245,7 +245,7 @@ hipError_t launch_sgemm(hipStream_t st, int ta, int tb, int M, int N, int K, flo
 // C = alpha * A^T . B + beta * C, A [K][M], B [K][N], on fp32 MFMA (M, N multiples of 32); mode 1: C through the broadcast layer's weight map
 bool sgemm_tn_mfma_ok(int M, int N, int K);
 hipError_t launch_sgemm_tn_mfma(hipStream_t st, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
-                                float beta, float* C, int ldc, int mode, int mode_c);
+                                float beta, float* C, int ldc, int mode, int mode_c, int a_rowmajor = 0);
 hipError_t launch_l0_tap_sums(hipStream_t st, const float* Rc, float* RT, int N, int C);
 hipError_t launch_l0_scatter_z(hipStream_t st, const float* tmp, int L, int C, float alpha, float* gw);
 hipError_t launch_l0_coord_grads(hipStream_t st, const float* D, const float* lin, int S, int C, int L, float alpha,

@@ -40,6 +40,7 @@ struct Buffers {               // workspace carve-up for one batch size / mode
     float *x4, *V, *dec_out, *g, *lnstat, *ll_img, *img_terms, *scal, *rows, *rows_p, *Rc, *pm, *plv;
     double* part;
     std::vector<float*> act;                   // decoder activations a[0..Dd-1]   (N,P,Cd)
+    float *head_xh = nullptr, *head_gp = nullptr;   // refinement head in three launches: LSTM input rows, gate pre-activations
     float* dpre[2];                            // ping-pong gradient wrt pre-activations
     std::vector<float*> tmax_act;              // per-cell max |act[l]| (4 floats per 8 x 16 cell): tile scales of the weight-stationary conv
     float* tmax_dpre[2] = {nullptr, nullptr};  // the same for the two gradient buffers
@@ -114,6 +115,7 @@ struct iodine_handle {
     float *ref_wk16 = nullptr, *ref_wsh16 = nullptr, *ref_wkmeta = nullptr, *ref_wshmeta = nullptr;   // and their packs
     float* ref_g20 = nullptr;                              // [Cr][20][9] weight gradient in the internal order
     unsigned* elbo_counter = nullptr;                      // ticket of pixel_finalize_elbo_kernel (zero between launches)
+    int head_mfma = 1;                                     // LSTM gate pre-activations of the refinement head as one fp32-MFMA GEMM over all slots
     int refine_l0_fused = 1;                               // encoding + first refinement layer in one kernel (kernels_refl0.hip); 0: pixel_pass2 + two convs
     void *ref_l0k = nullptr, *ref_l0s = nullptr; float *ref_l0kmeta = nullptr, *ref_l0smeta = nullptr;     // its weight packs
     int refine_ws = 1;                                     // forward stride-2 convs of refinement layers 1 .. on the weight-stationary kernel (kernels_refws.hip)
@@ -363,6 +365,11 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
     per_iter(b.u, (size_t)N * H, ncopy);
     per_iter(b.gates, (size_t)N * 4 * H, ncopy);
     per_iter(b.xin, (size_t)N * (H + 4 * L), ncopy);
+    {   // gate GEMM of the refinement head (head_mfma): its input rows [u | latent | h_prev] and its output, rows padded to a multiple of 32
+        const size_t Np = ((size_t)N + 31) / 32 * 32;
+        b.head_xh = a.take<float>(Np * (size_t)(H + 4 * L + H));
+        b.head_gp = a.take<float>(Np * (size_t)4 * H);
+    }
     // LSTM state: h[i], c[i] = state BEFORE iteration i; inference ping-pongs two copies
     b.h.resize(T + 2); b.c.resize(T + 2);
     if (mode == 1) {
@@ -727,7 +734,8 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
     PROF(h, st, "refine_head", launch_refine_head(st, in, N, s * s, h->Cr, h->H, h->L, h->mlp_wT, h->mlp_b, h->wihT, h->whhT, h->lstm_b,
                                  h->wmT, h->bm, h->wvT, h->bv, b.latent[i], b.h[i], b.c[i], b.h[i + 1], b.c[i + 1], b.pm,
                                  b.plv, save ? b.pooled[i] : nullptr, save ? b.u[i] : nullptr,
-                                 save ? b.gates[i] : nullptr, save ? b.xin[i] : nullptr, nullptr, nullptr));
+                                 save ? b.gates[i] : nullptr, save ? b.xin[i] : nullptr, nullptr, nullptr,
+                                 h->head_mfma ? b.head_xh : nullptr, h->head_mfma ? b.head_gp : nullptr));
     return IODINE_OK;
 }
 
@@ -793,7 +801,7 @@ int run_graphed(iodine_handle* h, hipStream_t st, const std::vector<uintptr_t>& 
 std::vector<uintptr_t> graph_key(const iodine_handle* h, int entry, int batch, std::initializer_list<const void*> ptrs)
 {
     std::vector<uintptr_t> k = {(uintptr_t)entry, (uintptr_t)batch, (uintptr_t)h->stop_after, (uintptr_t)h->precision,
-                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)(h->head_fused | (h->refine_bwd_fused << 1) | (h->refine_ws << 2) | (h->refine_l0_fused << 3)),
+                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)(h->head_fused | (h->refine_bwd_fused << 1) | (h->refine_ws << 2) | (h->refine_l0_fused << 3) | (h->head_mfma << 4)),
                                 (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
     for (const void* p : ptrs) k.push_back((uintptr_t)p);
     return k;
@@ -871,7 +879,9 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
         ALLOC(h->ref_b[l], (size_t)Cr);
     }
     ALLOC(h->mlp_wT, (size_t)Cr * H); ALLOC(h->mlp_b, (size_t)H);
-    ALLOC(h->wihT, (size_t)(H + 4 * L) * 4 * H); ALLOC(h->whhT, (size_t)H * 4 * H); ALLOC(h->lstm_b, (size_t)4 * H);
+    ALLOC(h->wihT, (size_t)(H + 4 * L + H) * 4 * H);         // [W_ih^T ; W_hh^T] contiguous: one K-major operand for the gate GEMM (head_mfma)
+    h->whhT = h->wihT + (size_t)(H + 4 * L) * 4 * H;
+    ALLOC(h->lstm_b, (size_t)4 * H);
     ALLOC(h->wmT, (size_t)H * L); ALLOC(h->bm, (size_t)L); ALLOC(h->wvT, (size_t)H * L); ALLOC(h->bv, (size_t)L);
     ALLOC(h->init_mean, (size_t)L); ALLOC(h->init_logvar, (size_t)L);
     ALLOC(h->raw_mlp_w, (size_t)H * Cr); ALLOC(h->raw_wih, (size_t)4 * H * (H + 4 * L)); ALLOC(h->raw_whh, (size_t)4 * H * H);
@@ -1131,6 +1141,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
         if (value < 1) return h->fail(IODINE_ERR_INVALID, "profile_stride must be >= 1");
         h->profile_stride = (int)value; return IODINE_OK;
     }
+    if (!strcmp(key, "head_mfma")) { h->head_mfma = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_l0_fused")) { h->refine_l0_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_ws")) { h->refine_ws = value != 0; return IODINE_OK; }
     if (!strcmp(key, "conv_variant")) {

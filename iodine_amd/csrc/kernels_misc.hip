@@ -672,6 +672,11 @@ hipError_t launch_elbo(hipStream_t st, const float* pm, const float* plv, const 
 //   saved (training): pooled[n][C], s[n][H] (MLP pre-activation), gates[n][4H] (post-activation i,f,g,o),
 //   xin[n][H+4L] (LSTM input); the state buffers are per-iteration in training mode.
 // -----------------------------------------------------------------------------------------------
+// STAGE 0: everything in one launch (the gate pre-activations as sliced matrix-vector products: every block streams the 3.1 MB of LSTM weights
+// from L2 - 0.74 GB per launch at cfg3, L2-bandwidth-bound at 55 us).  STAGE 1 / 2 (round 4): the kernel stops after assembling the LSTM input
+// row xh[n] = [u | latent | h_prev] resp. resumes with the gate pre-activations gp[n][4H] that an fp32-MFMA GEMM over all slots produced in
+// between (launch_sgemm_tn_mfma, A row-major: the weights are read once per 32 slots).
+template <int STAGE>
 __global__ __launch_bounds__(1024)
 void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, int C, int H, int L,
                         const float* __restrict__ mlp_wT /*[C][H]*/, const float* __restrict__ mlp_b,
@@ -684,7 +689,8 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
                         float* __restrict__ h_out, float* __restrict__ c_out,
                         float* __restrict__ pm, float* __restrict__ plv,
                         float* __restrict__ sv_pooled, float* __restrict__ sv_s, float* __restrict__ sv_gates,
-                        float* __restrict__ sv_xin, float* __restrict__ d_mean_out, float* __restrict__ d_logvar_out)
+                        float* __restrict__ sv_xin, float* __restrict__ d_mean_out, float* __restrict__ d_logvar_out,
+                        float* __restrict__ xh /*[.][H + 4L + H]*/, const float* __restrict__ gp /*[.][4H]*/)
 {
     extern __shared__ float sm[];
     float* s_pool = sm;                 // C
@@ -732,7 +738,7 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
     };
 
     // global average pool over the PL pixels of the last conv layer (F.adaptive_avg_pool2d, iodine.py:481)
-    {
+    if constexpr (STAGE != 2) {
         const int c = tid % C, g = tid / C, G = 256 / C;
         float s = 0.f;
         if (lead) {
@@ -750,27 +756,33 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
         __syncthreads();
     }
     // MLP + double ELU
-    const int ns_mlp = matvec4(s_pool, C, mlp_wT, H, H, s_part);
-    __syncthreads();
-    for (int j = tid; lead && j < H; j += 256) {
-        float s = mlp_b[j];
-        for (int q = 0; q < ns_mlp; ++q) s += s_part[(size_t)q * H + j];
-        const float u = elu1(elu1(s));
-        s_x[j] = u;
-        if (sv_s) sv_s[(size_t)n * H + j] = s;                   // pre-activation (training backward recomputes the ELUs)
-        s_h[j] = h_prev[(size_t)n * H + j];
-    }
-    for (int j = tid; lead && j < 4 * L; j += 256) s_x[H + j] = latent[(size_t)n * 4 * L + j];
-    __syncthreads();
-    if (sv_xin && lead)
-        for (int j = tid; j < H + 4 * L; j += 256) sv_xin[(size_t)n * (H + 4 * L) + j] = s_x[j];
-    // LSTM cell, gate order i, f, g, o (torch.nn.LSTMCell)
     const int IN = H + 4 * L, H4 = 4 * H;
+    if constexpr (STAGE != 2) {
+        const int ns_mlp = matvec4(s_pool, C, mlp_wT, H, H, s_part);
+        __syncthreads();
+        for (int j = tid; lead && j < H; j += 256) {
+            float s = mlp_b[j];
+            for (int q = 0; q < ns_mlp; ++q) s += s_part[(size_t)q * H + j];
+            const float u = elu1(elu1(s));
+            s_x[j] = u;
+            if (sv_s) sv_s[(size_t)n * H + j] = s;               // pre-activation (training backward recomputes the ELUs)
+            s_h[j] = h_prev[(size_t)n * H + j];
+        }
+        for (int j = tid; lead && j < 4 * L; j += 256) s_x[H + j] = latent[(size_t)n * 4 * L + j];
+        __syncthreads();
+        if (sv_xin && lead)
+            for (int j = tid; j < H + 4 * L; j += 256) sv_xin[(size_t)n * (H + 4 * L) + j] = s_x[j];
+    }
+    if constexpr (STAGE == 1) {                                  // the row of the gate GEMM: [u | latent | h_prev]
+        for (int j = threadIdx.x; j < IN + H; j += 1024) xh[(size_t)n * (IN + H) + j] = j < IN ? s_x[j] : s_h[j - IN];
+        return;
+    }
+    // LSTM cell, gate order i, f, g, o (torch.nn.LSTMCell)
     // Gate pre-activations: the (H + 4L + H)-term contraction is cut into NS = 16 K slices (rows r = ks, ks + NS, ... of
     // [W_ih^T ; W_hh^T]) and every thread owns FOUR adjacent gate columns, so a lane moves 16 bytes per load: with one
     // column per thread the 3.2 MB of head weights went through the CU's texture path as dword loads (~0.1 ms per launch).
     // Partial sums meet in LDS and are added in slice order (deterministic, independent of the slot's position).
-    {
+    if constexpr (STAGE == 0) {
         const int HQ = H / 4;                                    // column groups
         const int NS = min(16, 1024 / HQ);
         const int t = threadIdx.x, jq = t % HQ, ks = t / HQ;
@@ -811,10 +823,15 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
     __syncthreads();
     for (int j = tid; lead && j < H; j += 256) {
         float gi = lstm_b[j], gf = lstm_b[H + j], gg = lstm_b[2 * H + j], go = lstm_b[3 * H + j];
-        const int NS = min(16, 1024 / (H / 4));
-        for (int q = 0; q < NS; ++q) {
-            const float* ps = s_part + (size_t)q * H4;
+        if constexpr (STAGE == 2) {
+            const float* ps = gp + (size_t)n * H4;
             gi += ps[j]; gf += ps[H + j]; gg += ps[2 * H + j]; go += ps[3 * H + j];
+        } else {
+            const int NS = min(16, 1024 / (H / 4));
+            for (int q = 0; q < NS; ++q) {
+                const float* ps = s_part + (size_t)q * H4;
+                gi += ps[j]; gf += ps[H + j]; gg += ps[2 * H + j]; go += ps[3 * H + j];
+            }
         }
         gi = sigmoidf_(gi); gf = sigmoidf_(gf); gg = tanhf(gg); go = sigmoidf_(go);
         const float c1 = gf * c_prev[(size_t)n * H + j] + gi * gg;
@@ -845,23 +862,36 @@ void refine_head_kernel(const float* __restrict__ feat /*[N][PL][C]*/, int PL, i
     }
 }
 
+// xh / gp (both or neither): scratch [roundup32(N)][H + 4L + H] / [roundup32(N)][4H] for the three-launch form (pre, gate GEMM on fp32 MFMA,
+// post); wihT must then be followed in memory by whhT ([H + 4L + H][4H] contiguous: the GEMM's B operand)
 hipError_t launch_refine_head(hipStream_t st, const float* feat, int N, int PL, int C, int H, int L,
                               const float* mlp_wT, const float* mlp_b, const float* wihT, const float* whhT,
                               const float* lstm_b, const float* wmT, const float* bm, const float* wvT, const float* bv,
                               const float* latent, const float* h_prev, const float* c_prev, float* h_out, float* c_out,
                               float* pm, float* plv, float* sv_pooled, float* sv_s, float* sv_gates, float* sv_xin,
-                              float* d_mean, float* d_logvar)
+                              float* d_mean, float* d_logvar, float* xh, float* gp)
 {
     IOD_XSKIP(4);
     if (256 % C != 0) return hipErrorInvalidValue;
     if ((H + 4 * L) % 4 != 0 || H % 4 != 0 || L % 4 != 0 || C % 4 != 0) return hipErrorInvalidValue;
     const size_t lds = (size_t)(C + (H + 4 * L) + H + H + 256 + 16 * 4 * H) * sizeof(float);
-    static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
-    if (hipError_t e = iod_set_max_lds((const void*)refine_head_kernel, 96 * 1024, attr_devs); e != hipSuccess) return e;
+    static std::atomic<unsigned> attr_devs[3];                             // devices each instance is configured on
     if (lds > 96 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(refine_head_kernel, dim3(N), dim3(1024), lds, st, feat, PL, C, H, L, mlp_wT, mlp_b, wihT, whhT,
-                       lstm_b, wmT, bm, wvT, bv, latent, h_prev, c_prev, h_out, c_out, pm, plv, sv_pooled, sv_s,
-                       sv_gates, sv_xin, d_mean, d_logvar);
+#define HEAD_LAUNCH(STG) do {                                                                                                        \
+        if (hipError_t e = iod_set_max_lds((const void*)refine_head_kernel<STG>, 96 * 1024, attr_devs[STG]); e != hipSuccess) return e;  \
+        hipLaunchKernelGGL(refine_head_kernel<STG>, dim3(N), dim3(1024), lds, st, feat, PL, C, H, L, mlp_wT, mlp_b, wihT, whhT,      \
+                           lstm_b, wmT, bm, wvT, bv, latent, h_prev, c_prev, h_out, c_out, pm, plv, sv_pooled, sv_s,                 \
+                           sv_gates, sv_xin, d_mean, d_logvar, xh, gp);                                                              \
+    } while (0)
+    const int Kg = H + 4 * L + H, Np = (N + 31) / 32 * 32;
+    if (xh && gp && whhT == wihT + (size_t)(H + 4 * L) * 4 * H && sgemm_tn_mfma_ok(Np, 4 * H, Kg)) {
+        HEAD_LAUNCH(1);
+        if (hipError_t e = launch_sgemm_tn_mfma(st, Np, 4 * H, Kg, 1.f, xh, Kg, wihT, 4 * H, 0.f, gp, 4 * H, 0, 0, 1); e != hipSuccess) return e;
+        HEAD_LAUNCH(2);
+    } else {
+        HEAD_LAUNCH(0);
+    }
+#undef HEAD_LAUNCH
     return hipGetLastError();
 }
 

@@ -524,7 +524,9 @@ void sgemm_kernel(int ta, int tb, int M, int N, int K, float alpha, const float*
 //   * SPLITK = true: ONE tile per block, its four waves take a quarter of K each and are added in wave order through LDS (deterministic) -
 //     for products with few tiles (64 x 256, K = 1120: 16 tiles).
 // MODE 1 writes through the broadcast layer's index map: row = latent channel ci, column = tap * C + co -> gw[co][ci][tap] (ldc = L + 2).
-template <bool SPLITK, int MODE>
+// AROW: A is row-major [M][K] (lda = row stride) instead of K-major - lane i of a half wave reads row m0 + i: 32 cache lines per load
+// instruction, 16 MFMA steps per line; for the LSTM gate pre-activations (A = the 224 x 768 head inputs, L1-resident).
+template <bool SPLITK, int MODE, bool AROW>
 __global__ __launch_bounds__(256)
 void sgemm_tn_mfma_kernel(int M, int N, int K, float alpha, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                           float beta, float* __restrict__ Cm, int ldc, int mode_c)
@@ -541,7 +543,7 @@ void sgemm_tn_mfma_kernel(int M, int N, int K, float alpha, const float* __restr
         const int per = ((K + 3) / 4 + 1) & ~1;              // even: a wave's range starts on an MFMA step
         k0 = min(K, wv * per); k1 = min(K, k0 + per);
     }
-    const float* pa = A + m0 + (lane & 31);
+    const float* pa = AROW ? A + (size_t)(m0 + (lane & 31)) * lda : A + m0 + (lane & 31);
     const float* pb = B + n0 + (lane & 31);
     const int kh = lane >> 5;
     f32x16 acc;
@@ -555,7 +557,7 @@ void sgemm_tn_mfma_kernel(int M, int N, int K, float alpha, const float* __restr
         for (int u = 0; u < U; ++u) {
             const int kk = k + 2 * u + kh;
             const int kc = min(kk, K - 1);                   // unconditional loads at a clamped row; rows past the range count as zero
-            const float av = pa[(size_t)kc * lda], bv = pb[(size_t)kc * ldb];
+            const float av = AROW ? pa[kc] : pa[(size_t)kc * lda], bv = pb[(size_t)kc * ldb];
             a[u] = kk < k1 ? av : 0.f; b[u] = bv;
         }
     };
@@ -596,16 +598,19 @@ bool sgemm_tn_mfma_ok(int M, int N, int K) { return M % 32 == 0 && N % 32 == 0 &
 
 // mode 0: C row-major [M][ldc]; mode 1: the broadcast-layer map (see above), mode_c = C channels, ldc = L + 2
 hipError_t launch_sgemm_tn_mfma(hipStream_t st, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
-                                float beta, float* C, int ldc, int mode, int mode_c)
+                                float beta, float* C, int ldc, int mode, int mode_c, int a_rowmajor)
 {
     IOD_XSKIP(2);
     if (!sgemm_tn_mfma_ok(M, N, K) || (mode == 1 && (mode_c < 1 || N != 9 * mode_c))) return hipErrorInvalidValue;
     const int ntiles = (M / 32) * (N / 32);
     const bool splitk = ntiles <= 512 && K >= 64;            // (two waves per SIMD at 512 tiles: one computes while the other waits)
-#define TN_LAUNCH(SK, MD, GRID) hipLaunchKernelGGL((sgemm_tn_mfma_kernel<SK, MD>), dim3(GRID), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, \
-                                                   beta, C, ldc, mode_c)
-    if (splitk) { if (mode == 1) TN_LAUNCH(true, 1, ntiles); else TN_LAUNCH(true, 0, ntiles); }
-    else { if (mode == 1) TN_LAUNCH(false, 1, (ntiles + 3) / 4); else TN_LAUNCH(false, 0, (ntiles + 3) / 4); }
+#define TN_LAUNCH(SK, MD, AR, GRID) hipLaunchKernelGGL((sgemm_tn_mfma_kernel<SK, MD, AR>), dim3(GRID), dim3(256), 0, st, M, N, K, alpha, A, lda, B, \
+                                                       ldb, beta, C, ldc, mode_c)
+    if (a_rowmajor) {
+        if (mode != 0) return hipErrorInvalidValue;
+        if (splitk) TN_LAUNCH(true, 0, true, ntiles); else TN_LAUNCH(false, 0, true, (ntiles + 3) / 4);
+    } else if (splitk) { if (mode == 1) TN_LAUNCH(true, 1, false, ntiles); else TN_LAUNCH(true, 0, false, ntiles); }
+    else { if (mode == 1) TN_LAUNCH(false, 1, false, (ntiles + 3) / 4); else TN_LAUNCH(false, 0, false, (ntiles + 3) / 4); }
 #undef TN_LAUNCH
     return hipGetLastError();
 }
