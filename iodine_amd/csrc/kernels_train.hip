@@ -603,7 +603,9 @@ hipError_t launch_sgemm_tn_mfma(hipStream_t st, int M, int N, int K, float alpha
     IOD_XSKIP(2);
     if (!sgemm_tn_mfma_ok(M, N, K) || (mode == 1 && (mode_c < 1 || N != 9 * mode_c))) return hipErrorInvalidValue;
     const int ntiles = (M / 32) * (N / 32);
-    const bool splitk = ntiles <= 512 && K >= 64;            // (two waves per SIMD at 512 tiles: one computes while the other waits)
+    // (two waves per SIMD at 512 tiles: one computes while the other waits.  Row-major A = per-slot rows of the refinement head: the summation
+    //  order must not depend on how many slots share the launch - a slot's result is the same bits in every batch - so always split)
+    const bool splitk = (a_rowmajor || ntiles <= 512) && K >= 64;
 #define TN_LAUNCH(SK, MD, AR, GRID) hipLaunchKernelGGL((sgemm_tn_mfma_kernel<SK, MD, AR>), dim3(GRID), dim3(256), 0, st, M, N, K, alpha, A, lda, B, \
                                                        ldb, beta, C, ldc, mode_c)
     if (a_rowmajor) {
