@@ -4,17 +4,19 @@
 // RefinementNetwork.mlc.layers[0] (conv k3 s2 p1 17 -> C + ELU, iodine.py:459,480).  Until now three launches per refinement iteration:
 // pixel_pass2 wrote the encoding (176 + 17 MB at cfg3, split into the 11 channels that differ between the slots of an image and the 6 they
 // share), a stride-2 conv reduced the shared part per image, a second one the per-slot part: 0.064 + 0.020 + 0.146 ms for
-// 0.06 GB of real input (the decoder output) and 0.23 GB of output.  Here a block takes one 2 x 16 output tile of ONE IMAGE for ALL K
-// slots:
-//   * phase A: 165 threads evaluate pixel_terms (the same function pixel_pass1 / pixel_pass2 inline: bit-identical channel values) for
-//     the 5 x 33 halo pixels of the tile, apply the layer-norm statistics, and leave the channels in LDS as fp16 hi / lo planes - one
-//     plane of 12 channels per slot, one of 8 channels for what the slots share - scaled per plane by the power of two of its block-wide
-//     max; columns de-interleaved by parity as in kernels_refws.hip, 48-byte pixels (conflict-free 8-byte fragment reads).  In training
-//     the interior pixels also go to HBM in the layout pixel_pass2 writes (the backward reads them);
-//   * phase B: each wave owns 16 output channels and keeps both weight slices (12- and 8-channel part, 9 taps, hi + lo) in 72 VGPRs;
-//     v_mfma_f32_16x16x16_f16, the shared part once per tile, then 54 MFMAs per slot; out = ELU(bias + shared + per-slot), stored as 64
-//     bytes per pixel and wave.
-// Two blocks per CU (61 KB LDS at K = 7): one block's VALU-heavy phase A runs beside the other's phase B.
+// 0.06 GB of real input (the decoder output) and 0.23 GB of output.  Here a persistent 448-thread block takes one 2 x 16 output tile of ONE
+// IMAGE for ALL K slots per unit, two roles, LDS planes double-buffered:
+//   * producers (waves 4-6, 165 threads = the 5 x 33 halo pixels of the tile): pixel_terms (the same function pixel_pass1 / pixel_pass2
+//     inline: bit-identical channel values), layer-norm statistics applied, the channels left in LDS as fp32 planes - one plane of 12 channels
+//     per slot, one for the 6 channels the slots share; columns de-interleaved by parity as in kernels_refws.hip, 48-byte pixels (conflict-free
+//     16-byte accesses); plane maxima by ds_max_u32.  In training the tile's own pixels also go to HBM in pixel_pass2's layout (the backward
+//     reads them).  Loads of a unit are issued one unit ahead at clamped addresses;
+//   * consumers (waves 0-3): first convert a quarter of the plane pixels each to fp16 hi | lo IN PLACE (scale = power of two of the plane
+//     max), then, behind a barrier, each wave owns 16 output channels with both weight slices (12- and 8-channel part, 9 taps, hi + lo) in 72
+//     VGPRs: v_mfma_f32_16x16x16_f16, the shared plane once per tile, then 54 MFMAs per slot; out = ELU(bias + shared + per-slot), 64 bytes
+//     per pixel and wave.
+// Two LDS-only barriers per unit (s_waitcnt lgkmcnt(0); s_barrier - not __syncthreads(), which also drains stores and prefetches).
+// DESIGN.md 4.7 has the measurements and the forms tried on the way.
 #include "common.h"
 #include "pixel_terms.h"
 #include <utility>
