@@ -210,6 +210,7 @@ void iodine_linspace_host(int n, float* out);
 /* 3x3 conv, NHWC activations, OIHW weights; mode 0: stride-1 LDS-tiled fp32 MFMA (epi 0 bias+ELU, 1 multiply by
  * ELU'(aux), 2 none; transpose_flip=1 computes the data-gradient conv), mode 1: strided gather kernel (bias+ELU),
  * mode 2: stride-1 LDS-tiled split-fp16 (3 MFMA) variant of mode 0, modes 9 / 10: the weight-stationary split-fp16 kernel,
+ * mode 12: its exact-fp32 form (weights as fp32 in the same registers, v_mfma_f32_16x16x4_f32; conv_precision 0),
  * modes 5 / 6: split-fp16 stride-2 forward / data gradient of the refinement stack. */
 int iodine_op_conv3x3(void* stream, int mode, const float* in_nhwc, const float* w_oihw, const float* bias,
                       const float* aux, float* out_nhwc, int n, int ih, int iw, int w_o, int w_i, int cin_pad,
@@ -221,6 +222,11 @@ int iodine_op_dec_out(void* stream, const float* in_nhwc, const float* w_oihw, c
  * ACCUMULATED into.  Split-fp16 kernels (stride 1: decoder stack, stride 2: refinement stack). */
 int iodine_op_conv3x3_wgrad(void* stream, const float* in_nhwc, const float* d_nhwc, float* gw_oihw, float* gb, int n,
                             int s, int ci_pad, int ci_real, int co, int stride);
+
+/* the same for the stride-1 conv c -> c (c = 32 / 64) on the exact-fp32 path (conv_precision 0): persistent, prefetched
+ * v_mfma_f32_32x32x2_f32 kernel (kernels_wgrad32.hip); gw_oihw / gb are ACCUMULATED into. */
+int iodine_op_conv3x3_wgrad_f32(void* stream, const float* in_nhwc, const float* d_nhwc, float* gw_oihw, float* gb, int n,
+                                int s, int c);
 
 #ifdef __cplusplus
 }

@@ -293,6 +293,13 @@ hipError_t launch_cell_max(hipStream_t st, const float* x, float* tmax, int N, i
 hipError_t launch_conv3x3_ws_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
                                    const float* aux, float* out, const float* tmax_in, float* tmax_out, int N, int S, int c,
                                    int epi, int rev);
+// exact-fp32 form of the same kernel (conv_precision 0): fp32 weights in the register layout (same byte count), v_mfma_f32_16x16x4_f32
+hipError_t launch_pack_conv_weights_ws32(hipStream_t st, const float* src, int C, int tflip, void* dst);
+hipError_t launch_conv3x3_ws_f32(hipStream_t st, const float* in, const void* wpk, const float* bias, const float* aux, float* out,
+                                 int N, int S, int c, int epi, int rev);
+// kernels_wgrad32.hip: exact-fp32 weight gradient, persistent + prefetched (part: [nparts][9][c][c], part_b: [nbias_parts][c])
+hipError_t launch_conv3x3_wgrad_f32_ws(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N, int S, int c,
+                                       int* nparts, int* ncop, int* nbias_parts);
 inline size_t conv_ws_wpk_bytes(int C) { return (size_t)(C / 16) * (C / 32) * 9 * 2 * 64 * 16; }
 inline size_t conv_ws_tmax_floats(int N, int S) { return (size_t)N * (S / 16) * (S / 8) * 4; }
 

@@ -199,6 +199,9 @@ hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, c
     } while (0)
 
 bool conv_ws_ok(const iodine_handle* h) { return !h->generic && h->variant == 6 && h->precision == 1 && h->S >= 16 && (h->S & (h->S - 1)) == 0; }
+// exact-fp32 path (conv_precision 0): the weight-stationary kernel's fp32 form (v_mfma_f32_16x16x4_f32, no tile scales / side buffers) under the same
+// conditions; conv_variant 1 keeps the round-1 LDS-tiled fp32 kernels
+bool conv_ws32_ok(const iodine_handle* h) { return !h->generic && h->variant == 6 && h->precision == 0 && h->S >= 16 && (h->S & (h->S - 1)) == 0 && (h->Cd == 64 || h->Cd == 32); }
 
 hipError_t conv_f16x3(const iodine_handle* h, hipStream_t st, const float* in, const void* wpk, const void* wpk_ws,
                       const float* wmeta, const float* bias, const float* aux, float* out, const float* tmax_in, float* tmax_out,
@@ -491,6 +494,9 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N, const float* z, flo
             PROF(h, st, "conv_tile_fwd", conv_f16x3(h, st, b.act[l - 1], h->dec_wf16[l], h->dec_wsf[l], h->dec_wmeta[l], h->dec_b[l],
                                                     nullptr, b.act[l], b.tmax_act[l - 1], b.tmax_act[l], N, h->S, h->Cd, h->Cd,
                                                     EPI_BIAS_ELU, l));
+        else if (conv_ws32_ok(h))
+            PROF(h, st, "conv_tile_fwd", launch_conv3x3_ws_f32(st, b.act[l - 1], h->dec_wsf[l], h->dec_b[l], nullptr, b.act[l], N, h->S, h->Cd,
+                                                               EPI_BIAS_ELU, l & 1));
         else
             PROF(h, st, "conv_tile_fwd", launch_conv3x3_tile(st, b.act[l - 1], h->dec_wf[l], h->dec_b[l], nullptr,
                                                              b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
@@ -600,6 +606,9 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
             if (h->precision == 1)
                 PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_f16x3_ws(st, b.act[l - 1], b.dpre[cur], b.wg_part,
                                                                               b.wg_part_b, N, h->S, Cd, Cd, &nparts, &ncop, &nb));
+            else if (conv_ws32_ok(h))
+                PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_f32_ws(st, b.act[l - 1], b.dpre[cur], b.wg_part, b.wg_part_b, N, h->S, Cd,
+                                                                            &nparts, &ncop, &nb));
             else
                 PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_tile(st, b.act[l - 1], b.dpre[cur], b.wg_part,
                                                                           b.wg_part_b, N, h->S, Cd, Cd, &nparts, &ncop, &nb));
@@ -612,12 +621,16 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         // reduces its tile to per-row sums in its epilogue (EPI_L0ROWS) and the 0.94 GB tensor is neither written nor re-read.
         // Training: the same with one more sum per row (EPI_L0ROWSX, weight-stationary kernel only): class sums for dz and the
         // latent-channel weights, slot-summed row sums for the coordinate-channel weights and the bias.
-        fused_l0 = l == 1 && h->precision == 1 && h->fuse_l0 && (train_alpha == 0.f || conv_ws_ok(h));
+        fused_l0 = l == 1 && h->fuse_l0 && (h->precision == 1 ? (train_alpha == 0.f || conv_ws_ok(h)) : conv_ws32_ok(h));
         if (h->precision == 1)
             PROF(h, st, "conv_tile_dgrad", conv_f16x3(h, st, b.dpre[cur], h->dec_wb16[l], h->dec_wsb[l], h->dec_wmeta[l] + 2, nullptr,
                                                       b.act[l - 1], fused_l0 ? b.rows_p : b.dpre[cur ^ 1], b.tmax_dpre[cur],
                                                       b.tmax_dpre[cur ^ 1], N, h->S, Cd, Cd,
                                                       fused_l0 ? (train_alpha != 0.f ? EPI_L0ROWSX : EPI_L0ROWS) : EPI_MUL_ELUGRAD, l));
+        else if (conv_ws32_ok(h))
+            PROF(h, st, "conv_tile_dgrad", launch_conv3x3_ws_f32(st, b.dpre[cur], h->dec_wsb[l], nullptr, b.act[l - 1],
+                                                                 fused_l0 ? b.rows_p : b.dpre[cur ^ 1], N, h->S, Cd,
+                                                                 fused_l0 ? (train_alpha != 0.f ? EPI_L0ROWSX : EPI_L0ROWS) : EPI_MUL_ELUGRAD, l & 1));
         else
             PROF(h, st, "conv_tile_dgrad", launch_conv3x3_tile(st, b.dpre[cur], h->dec_wb[l], nullptr, b.act[l - 1],
                                                                b.dpre[cur ^ 1], N, h->S, Cd, Cd, EPI_MUL_ELUGRAD));
@@ -1020,7 +1033,10 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
                                     h->S, h->wcls, h->wclsT, h->cmap));
     for (int l = 1; l < h->Dd; ++l) {
         const float* w = P("decoder.mlc.layers." + std::to_string(l) + ".weight");
-        if (h->precision == 0) {                               // exact-fp32 path only (conv_precision invalidates the params)
+        if (conv_ws32_ok(h)) {                                 // exact-fp32 path, weight-stationary register layout (fp32)
+            HIPCHK(h, launch_pack_conv_weights_ws32(st, w, Cd, 0, h->dec_wsf[l]));
+            HIPCHK(h, launch_pack_conv_weights_ws32(st, w, Cd, 1, h->dec_wsb[l]));
+        } else if (h->precision == 0) {                        // exact-fp32 path, LDS-tiled kernels (conv_precision invalidates the params)
             HIPCHK(h, launch_pack_conv_weights(st, w, Cd, Cd, Cd, Cd, 0, h->dec_wf[l]));
             HIPCHK(h, launch_pack_conv_weights(st, w, Cd, Cd, Cd, Cd, 1, h->dec_wb[l]));
         }
@@ -1689,6 +1705,17 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, c
         if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(ws): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
         return IODINE_OK;
     }
+    if (mode == 12) {               // exact-fp32 form of the weight-stationary kernel (v_mfma_f32_16x16x4_f32)
+        if (cin_pad != cout || w_o != cout || w_i != cout || ih != iw || ih % 16 != 0) { g_create_error = "iodine_op_conv3x3(ws f32): shape"; return IODINE_ERR_INVALID; }
+        char* buf = nullptr;
+        if (hipMalloc((void**)&buf, conv_ws_wpk_bytes(cout)) != hipSuccess) return IODINE_ERR_HIP;
+        hipError_t e2 = launch_pack_conv_weights_ws32(st, w, cout, tflip, buf);
+        if (e2 == hipSuccess) e2 = launch_conv3x3_ws_f32(st, in, buf, bias, aux, out, n, ih, cout, epi, 0);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+        (void)hipFree(buf);
+        if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(ws f32): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
+        return IODINE_OK;
+    }
 #ifdef IODINE_WITH_WINO
     if (mode == 11) {               // Winograd F(2x2, 3x3) split-fp16 kernel (C = 64): experiment libraries only (tools/wino_variants.sh)
         if (cin_pad != cout || w_o != cout || w_i != cout || ih != iw || ih % 16 != 0) { g_create_error = "iodine_op_conv3x3(wino): shape"; return IODINE_ERR_INVALID; }
@@ -1771,6 +1798,23 @@ int iodine_op_conv3x3_wgrad(void* stream, const float* in, const float* d, float
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(buf);
     if (e != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3_wgrad: ") + hipGetErrorString(e); return IODINE_ERR_HIP; }
+    return IODINE_OK;
+}
+
+int iodine_op_conv3x3_wgrad_f32(void* stream, const float* in, const float* d, float* gw, float* gb, int n, int s, int c)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const size_t part_elems = (size_t)512 * 4 * 9 * 32 * 32, fold_elems = (size_t)WGRAD_FOLD * 9 * 64 * 64;
+    float* buf = nullptr;
+    if (hipMalloc((void**)&buf, (part_elems + fold_elems + (size_t)512 * 64) * sizeof(float)) != hipSuccess) return IODINE_ERR_HIP;
+    float *part = buf, *fold = buf + part_elems, *part_b = fold + fold_elems;
+    int nparts = 0, cop = 0, nb = 0;
+    hipError_t e = launch_conv3x3_wgrad_f32_ws(st, in, d, part, part_b, n, s, c, &nparts, &cop, &nb);
+    if (e == hipSuccess) e = launch_wgrad_reduce(st, part, nparts, c, cop, c, c, c, 1.f, gw, fold);
+    if (e == hipSuccess) e = launch_colsum(st, part_b, nb, c, c, 1.f, gb);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    if (e != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3_wgrad_f32: ") + hipGetErrorString(e); return IODINE_ERR_HIP; }
     return IODINE_OK;
 }
 

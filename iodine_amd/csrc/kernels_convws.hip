@@ -121,7 +121,7 @@ IOD_DEVINL float pixel_lane_sum(float v)
     return v;
 }
 
-template <int C, int EPI>
+template <int C, int EPI, bool F32 = false>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
                              const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
@@ -132,7 +132,8 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
     constexpr int RW = 8 / NPG;                  // output rows per wave
     constexpr int NCHUNK = C / 32;               // K chunks of 32 input channels
     constexpr int HC = 18, HR = 10, NPX = HC * HR;
-    constexpr int PXB = 160;                     // bytes per staged pixel: 64 hi | 64 lo | 32 pad (conflict-free ds_read_b128)
+    constexpr int PXB = 160;                     // bytes per staged pixel: 64 hi | 64 lo | 32 pad (conflict-free ds_read_b128);
+                                                 // exact-fp32 form (F32): 32 channels x 4 bytes | 32 pad - the same geometry
     constexpr int EPS = C * 4 + 32;              // bytes per pixel of the transposed output tile (epilogue)
     constexpr int BUFB = ((NPX + 1) * PXB > 128 * EPS ? (NPX + 1) * PXB : 128 * EPS);    // one LDS buffer (input halo / output tile)
     constexpr int NIN = (NPX * 8 + 255) / 256;   // float4 loads per thread per chunk (6)
@@ -183,7 +184,10 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
 #define WS_SGPR_SETTLE(rsrc, soff) asm volatile("s_nop 4" :: "s"(rsrc), "s"(soff) : "memory")
 
     // ---- this wave's weight slice -> registers (once per block) ----
-    f16x8 wh[NCHUNK][9], wl[NCHUNK][9];
+    // (F32: the same 16 bytes per lane are 4 fp32 weights - row = cout 16 cg + l % 16, cin 32 c + 4 (l / 16) .. + 3 in wh and
+    // + 16 in wl: element j is the A operand of the j-th v_mfma_f32_16x16x4_f32 over the fragment's 16 bytes)
+    using wreg_t = std::conditional_t<F32, f32x4, f16x8>;
+    wreg_t wh[NCHUNK][9], wl[NCHUNK][9];
     {
         const uint4* wp = wpk + (size_t)cg * NCHUNK * 9 * 2 * 64 + lane;
 #pragma unroll
@@ -199,7 +203,8 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
 #pragma unroll
             for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(wh[c][t]), "+v"(wl[c][t]));      // opaque: stay in registers
     }
-    const float inv_w = wmeta[1];
+    float inv_w = 1.f;
+    if constexpr (!F32) inv_w = wmeta[1];
     // (training row-sum form) step of torch.linspace(-1, 1, S), wave-uniform: computed once, kept in a scalar register
     const float xstep_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(__fdiv_rn(2.f, (float)(S - 1)))));
     (void)xstep_u;
@@ -207,7 +212,7 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_b;
     // staging: float4 k of this thread = halo pixel (tid >> 3) + 32 k, channel quad tid & 7 (idle lanes of the last one write
     // the dump slot); fragment reads: pixel (row pg*RW, column lpx), 16-byte k block lkb
-    const unsigned lw0 = (unsigned)((tid >> 3) * PXB + (tid & 7) * 8);
+    const unsigned lw0 = (unsigned)((tid >> 3) * PXB + (tid & 7) * (F32 ? 16 : 8));
     const bool last_idle = tid + (NIN - 1) * 256 >= NPX * 8;
     const unsigned fr_base = lds_base + (unsigned)(((pg * RW) * HC + lpx) * PXB + lkb * 16);
 
@@ -260,7 +265,7 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
     auto issue_stage = [&](int s) {
         const int t = t0 + (s / NCHUNK) * bpx, c = s % NCHUNK;
         issue_loads(t, c);
-        if (c == 0) issue_tmax(t);
+        if constexpr (!F32) { if (c == 0) issue_tmax(t); }
     };
     auto vm_wait = [&](auto nc) {
         constexpr int nleft = decltype(nc)::value;
@@ -278,6 +283,10 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
         constexpr int k = decltype(kc)::value;
         unsigned char* sb = smem_b + buf * BUFB;
         f32x4 v = rin[k];
+        if constexpr (F32) {                                 // exact fp32: the float4 goes to LDS as it is
+            const unsigned o32 = (k == NIN - 1 && last_idle) ? (unsigned)(NPX * PXB) : lw0 + (unsigned)(k * 32 * PXB);
+            *reinterpret_cast<f32x4*>(sb + o32) = v;
+        } else {
         v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
         typedef __fp16 h2 __attribute__((ext_vector_type(2)));
         const h2 h01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);      // (rounding toward zero = the 11 leading bits)
@@ -288,14 +297,15 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
         const unsigned o = (k == NIN - 1 && last_idle) ? (unsigned)(NPX * PXB) : lw0 + (unsigned)(k * 32 * PXB);
         *reinterpret_cast<uint2*>(sb + o) = hi;
         *reinterpret_cast<uint2*>(sb + o + 64) = lo;
+        }
     };
 
     // stores (and the tile-max store) an epilogue leaves in flight: YOUNGER than the input loads of the stage after it
     // (row-sum forms: per wave and tile 2 rows x {left, interior, right [, weighted]} float4 stores by the lanes of pixel lane 0)
-    constexpr int NST = ROWS ? 2 * NQ : NEP + 1;
+    constexpr int NST = ROWS ? 2 * NQ : NEP + (F32 ? 0 : 1);
 
 #define WS_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-    struct Frag { f16x8 h, l; };
+    struct Frag { wreg_t h, l; };
     // All taps of one 32-channel chunk from LDS buffer `buf`: (RW + 2) halo rows x 3 column shifts, each fragment pair feeding
     // the taps dy = 0..2 = output rows hr - dy.  The staging of the NEXT stage rides inside: its loads (in flight since the
     // previous chunk) are waited for after step HOOK0, split + written to the other LDS buffer one float4 per step, and the
@@ -316,6 +326,24 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
         auto MMA = [&](auto sc, const Frag& fr) {
             constexpr int s = decltype(sc)::value;
             constexpr int hr = s / 3, dx = s % 3;
+            if constexpr (F32) {
+                // exact fp32: 8 k-steps of 4 channels (v_mfma_f32_16x16x4_f32: 32 cycles each, 40 cycles dependent latency - the
+                // dy loop inside, so that consecutive MFMAs go to different accumulators)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int y = hr - dy;
+                        if (y >= 0 && y < RW) acc[y] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[c][dy * 3 + dx][j], fr.h[j], acc[y], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int y = hr - dy;
+                        if (y >= 0 && y < RW) acc[y] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[c][dy * 3 + dx][j], fr.l[j], acc[y], 0, 0, 0);
+                    }
+            } else {
             // three passes, accumulators interleaved (consecutive MFMAs never share an accumulator)
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
@@ -331,6 +359,7 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
             for (int dy = 0; dy < 3; ++dy) {
                 const int y = hr - dy;
                 if (y >= 0 && y < RW) acc[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c][dy * 3 + dx], fr.h, acc[y], 0, 0, 0);
+            }
             }
         };
         LOADF(integral_constant<int, 0>{}, f[0], base);
@@ -353,7 +382,7 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
                     if (next_after_epi) vm_wait(integral_constant<int, NST>{});
                     else vm_wait(integral_constant<int, 0>{});
                     // the next stage opens a tile: its scale comes from the side buffer values fetched with its loads
-                    next_scale = c + 1 < NCHUNK ? next_scale_same : fresh_scale(wave_max_f32(lane < 36 ? tmv : 0.f));
+                    if constexpr (!F32) next_scale = c + 1 < NCHUNK ? next_scale_same : fresh_scale(wave_max_f32(lane < 36 ? tmv : 0.f));
                 }
             }
             if constexpr (s > HOOK0 && s <= HOOK0 + NIN) {
@@ -392,7 +421,8 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
     // ---- prologue: stage 0 into buffer 0, stage 1 in flight ----
     issue_stage(0);
     vm_wait(integral_constant<int, 0>{});
-    float cur_scale = fresh_scale(wave_max_f32(lane < 36 ? tmv : 0.f));
+    float cur_scale = 1.f;
+    if constexpr (!F32) cur_scale = fresh_scale(wave_max_f32(lane < 36 ? tmv : 0.f));
     ws_static_for<0, NIN>([&](auto kc) { convert_k(kc, 0, cur_scale); });
     if (nstage > 1) issue_stage(1);
     bool first = true;
@@ -608,7 +638,7 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
                 xw_row_done(0);
             }
 #endif
-            if constexpr (!ROWS) {
+            if constexpr (!ROWS && !F32) {
                 // the wave's share of the cell max of this OUTPUT tile (side buffer for the consumer of `out`)
                 vmax = wave_max_f32(vmax);
                 const int tt = rev ? ntiles - 1 - t : t;
@@ -632,14 +662,14 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
 #undef WS_SGPR_SETTLE
 }
 
-template <int C, int EPI>
+template <int C, int EPI, bool F32 = false>
 static hipError_t launch_ws_inst(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
                                  const float* aux, float* out, const float* tmax_in, float* tmax_out, int N, int S, int rev)
 {
     constexpr size_t buf_in = (size_t)(18 * 10 + 1) * 160, buf_out = (size_t)128 * (C * 4 + 32);
     constexpr size_t lds = 2 * (buf_in > buf_out ? buf_in : buf_out);
     static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
-    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_ws_f16x3_kernel<C, EPI>, (int)lds, attr_devs); e != hipSuccess) return e;
+    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_ws_f16x3_kernel<C, EPI, F32>, (int)lds, attr_devs); e != hipSuccess) return e;
     int n_cu = 0;
     if (hipError_t e = iod_cu_count(&n_cu); e != hipSuccess) return e;
     int lgS = 0;
@@ -651,7 +681,7 @@ static hipError_t launch_ws_inst(hipStream_t st, const float* in, const void* wp
     if (const char* e = getenv("IODINE_WS_BPC")) bpc = atoi(e);
 #endif
     const int bpx = std::min(per_xcd, std::max(1, bpc * n_cu / 8));
-    hipLaunchKernelGGL((conv3x3_ws_f16x3_kernel<C, EPI>), dim3(8 * bpx), dim3(256), lds, st, in,
+    hipLaunchKernelGGL((conv3x3_ws_f16x3_kernel<C, EPI, F32>), dim3(8 * bpx), dim3(256), lds, st, in,
                        reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, tmax_in, tmax_out, S, lgS, ntiles, rev);
 #ifdef IODINE_TILE_PROF
     {
@@ -698,6 +728,45 @@ hipError_t launch_conv3x3_ws_f16x3(hipStream_t st, const float* in, const void* 
     // power-of-two image sizes only; the per-cell max of the INPUT (tmax_in, launch_cell_max or the producer's epilogue) is required
     if (S < 16 || (S & (S - 1)) != 0 || !tmax_in || (epi != EPI_L0ROWS && epi != EPI_L0ROWSX && !tmax_out)) return hipErrorInvalidValue;
 #define WS_CASE(CC, EP) if (c == CC && epi == EP) return launch_ws_inst<CC, EP>(st, in, wpk, wmeta, bias, aux, out, tmax_in, tmax_out, N, S, rev);
+    WS_CASE(64, EPI_BIAS_ELU) WS_CASE(64, EPI_MUL_ELUGRAD) WS_CASE(64, EPI_L0ROWS) WS_CASE(64, EPI_L0ROWSX)
+    WS_CASE(32, EPI_BIAS_ELU) WS_CASE(32, EPI_MUL_ELUGRAD) WS_CASE(32, EPI_L0ROWS) WS_CASE(32, EPI_L0ROWSX)
+#undef WS_CASE
+    return hipErrorInvalidValue;
+}
+
+// ---- exact-fp32 form (option conv_precision 0): the same kernel with fp32 weights in the 144 registers and v_mfma_f32_16x16x4_f32 ----
+// packed weights: [cout group][chunk of 32 cin][tap][half][lane][4 fp32]: lane l holds row = cout 16 cg + l % 16,
+// cin 32 c + 16 half + 4 (l / 16) + j for the j-th MFMA over a 16-byte activation fragment (K index of that MFMA = l / 16)
+__global__ void pack_conv_weights_ws32_kernel(const float* __restrict__ src, int C, int tflip, float* __restrict__ dst)
+{
+    const size_t total = (size_t)(C / 16) * (C / 32) * 9 * 2 * 64 * 4;
+    const int nchunk = C / 32;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = idx & 3;
+        size_t r = idx >> 2;
+        const int lane = r & 63; r >>= 6;
+        const int hl = r & 1; r >>= 1;
+        const int tap = r % 9; r /= 9;
+        const int c = r % nchunk;
+        const int cg = (int)(r / nchunk);
+        const int co = 16 * cg + (lane & 15), ci = 32 * c + 16 * hl + 4 * (lane >> 4) + j;
+        // forward: W[co][ci][tap]; data gradient: the transposed conv, W[ci][co][8 - tap]
+        dst[idx] = tflip ? src[((size_t)ci * C + co) * 9 + (8 - tap)] : src[((size_t)co * C + ci) * 9 + tap];
+    }
+}
+
+hipError_t launch_pack_conv_weights_ws32(hipStream_t st, const float* src, int C, int tflip, void* dst)
+{
+    const size_t total = (size_t)(C / 16) * (C / 32) * 9 * 2 * 64 * 4;
+    hipLaunchKernelGGL(pack_conv_weights_ws32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, C, tflip, (float*)dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_ws_f32(hipStream_t st, const float* in, const void* wpk, const float* bias, const float* aux, float* out,
+                                 int N, int S, int c, int epi, int rev)
+{
+    if (S < 16 || (S & (S - 1)) != 0) return hipErrorInvalidValue;
+#define WS_CASE(CC, EP) if (c == CC && epi == EP) return launch_ws_inst<CC, EP, true>(st, in, wpk, nullptr, bias, aux, out, nullptr, nullptr, N, S, rev);
     WS_CASE(64, EPI_BIAS_ELU) WS_CASE(64, EPI_MUL_ELUGRAD) WS_CASE(64, EPI_L0ROWS) WS_CASE(64, EPI_L0ROWSX)
     WS_CASE(32, EPI_BIAS_ELU) WS_CASE(32, EPI_MUL_ELUGRAD) WS_CASE(32, EPI_L0ROWS) WS_CASE(32, EPI_L0ROWSX)
 #undef WS_CASE

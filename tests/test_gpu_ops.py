@@ -141,6 +141,62 @@ def test_conv_weight_stationary_f16x3(C_, S, N):
     assert torch.equal(gotd, _conv_op(10, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 1, 1, refd.shape))   # deterministic
 
 
+@pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 2), (64, 128, 2), (64, 16, 300), (32, 64, 9), (32, 32, 70)])
+def test_conv_weight_stationary_exact_fp32(C_, S, N):
+    """the exact-fp32 form of the weight-stationary kernel (op mode 12, conv_precision 0: fp32 weights in the 144 registers,
+    v_mfma_f32_16x16x4_f32): every epilogue against ATen in fp64 at the tolerance of the round-1 fp32 kernels (2e-6)"""
+    x = _rand(N, C_, S, S, seed=21)
+    w = _rand(C_, C_, 3, 3, seed=22, scale=3.0 / (C_ * 9) ** 0.5)
+    b = _rand(C_, seed=23, scale=0.5)
+    ref = nhwc(F.elu(F.conv2d(x.double(), w.double(), b.double(), padding=1))).float()
+    got = _conv_op(12, nhwc(x), w, b, None, N, S, S, C_, C_, C_, C_, 1, 0, 0, ref.shape)
+    assert rel_err(got, ref) < 2e-6, rel_err(got, ref)
+    g = _rand(N, C_, S, S, seed=24, scale=1e-3)
+    g[N // 2:] *= 1e-4
+    a = F.elu(_rand(N, C_, S, S, seed=25, scale=2.0))
+    refd = nhwc((F.conv_transpose2d(g.double(), w.double(), padding=1) * torch.where(a > 0, torch.ones_like(a), a + 1).double()).float())
+    gotd = _conv_op(12, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 1, 1, refd.shape)
+    for half in (slice(0, N // 2), slice(N // 2, N)):
+        assert rel_err(gotd[half], refd[half]) < 2e-6, rel_err(gotd[half], refd[half])
+    tiles = S // 16
+    r = refd.view(N, S, tiles, 16, C_).double()
+    want = torch.zeros(N, S, tiles, 3, C_, dtype=torch.float64)
+    want[:, :, :, 1] = r.sum(3)
+    want[:, :, 0, 0] = r[:, :, 0, 0]; want[:, :, 0, 1] -= r[:, :, 0, 0]
+    want[:, :, -1, 2] = r[:, :, -1, 15]; want[:, :, -1, 1] -= r[:, :, -1, 15]
+    rows = _conv_op(12, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 4, 1, (N, S, tiles, 3, C_))
+    rows4 = _conv_op(12, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 5, 1, (N, S, tiles, 4, C_))
+    lin = torch.linspace(-1, 1, S).double().view(1, 1, tiles, 16, 1)
+    want4 = torch.cat([want, (r * lin).sum(3, keepdim=True)], 3)
+    for half in (slice(0, N // 2), slice(N // 2, N)):
+        assert rel_err(rows[half], want[half].float()) < 5e-6, rel_err(rows[half], want[half].float())
+        assert rel_err(rows4[half], want4[half].float()) < 5e-6, rel_err(rows4[half], want4[half].float())
+    assert torch.equal(gotd, _conv_op(12, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 1, 1, 1, refd.shape))   # deterministic
+
+
+@pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 5), (64, 128, 2), (32, 64, 3), (64, 16, 300), (64, 48, 2)])
+def test_conv_wgrad_exact_fp32(C_, S, N):
+    """the persistent, prefetched exact-fp32 weight gradient (kernels_wgrad32.hip) vs autograd in fp64; deterministic"""
+    x = _rand(N, C_, S, S, seed=40).double()
+    d = _rand(N, C_, S, S, seed=41, scale=1e-2).double()
+    w = torch.zeros(C_, C_, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(C_, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x, w, b, padding=1) * d).sum().backward()
+    L = _lib.lib()
+    xs, ds = nhwc(x.float()).to(DEV).contiguous(), nhwc(d.float()).to(DEV).contiguous()
+    res = []
+    for _ in range(2):
+        gw = torch.zeros(C_, C_, 3, 3, device=DEV)
+        gb = torch.zeros(C_, device=DEV)
+        _lib.check(L.iodine_op_conv3x3_wgrad_f32(None, _lib.ptr(xs), _lib.ptr(ds), _lib.ptr(gw), _lib.ptr(gb), N, S, C_), None,
+                   'iodine_op_conv3x3_wgrad_f32')
+        torch.cuda.synchronize()
+        res.append((gw.cpu(), gb.cpu()))
+    assert rel_err(res[0][0], w.grad.float()) < 2e-6, rel_err(res[0][0], w.grad.float())
+    assert rel_err(res[0][1], b.grad.float()) < 2e-6, rel_err(res[0][1], b.grad.float())
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize('cin,cpad,cout,S,N', [(17, 20, 64, 32, 3), (64, 64, 64, 16, 5), (17, 20, 32, 16, 2),
                                                 (32, 32, 32, 8, 7), (64, 64, 64, 128, 1), (32, 32, 32, 4, 3),
                                                 (17, 20, 64, 128, 2), (64, 64, 64, 64, 9)])
