@@ -174,12 +174,14 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * stream; ignored while "profile" is on; 0 -- default),
  * "profile" (bracket kernel launches with HIP events on the launch stream: 1 = the dominant "conv_tile_*" launches only --
  * 54 of ~330 per training step, what bench.py keeps on inside its timed region; 2 = every category; 0 = off),
- * "conv_precision" (3x3 convs of the decoder and refinement stacks: 0 = exact fp32 MFMA, 1 = fp32 operands split into
- * fp16 hi+lo, 3 fp16 MFMAs, fp32 accumulate -- default; only the selected path's weight packs are maintained, so a change
- * must be followed by iodine_set_params before the next compute call),
- * "conv_variant" (split-fp16 stride-1 conv C -> C of the decoder: 6 = weight-stationary persistent kernel, weights in registers
- * -- default for power-of-two image sizes; 1 = LDS-tiled kernel, 16x16 tiles, two blocks per CU -- the fallback for other sizes;
- * like conv_precision a change must be followed by iodine_set_params),
+ * "conv_precision" (3x3 convs of the decoder and refinement stacks: 0 = exact fp32 MFMA -- IEEE fp32 products, fp32 accumulate,
+ * the reference's arithmetic (nn.Conv2d fp32, iodine.py:583); 1 = fp32 operands split into fp16 hi+lo with one power-of-two
+ * scale per 8 x 16 cell, 3 fp16 MFMAs, fp32 accumulate: products carry >= 22 bits relative to the CELL maximum (tile-relative,
+ * not element-relative) -- default; only the selected path's weight packs are maintained, so a change must be followed by
+ * iodine_set_params before the next compute call),
+ * "conv_variant" (stride-1 conv C -> C of the decoder, either precision: 6 = weight-stationary persistent kernel, weights in
+ * registers -- default for power-of-two image sizes; 1 = LDS-tiled kernel, 16x16 tiles, two blocks per CU -- the fallback for
+ * other sizes; like conv_precision a change must be followed by iodine_set_params),
  * "fuse_l0" (1 -- default: the last decoder data gradient reduces its result to the broadcast layer's row sums in its epilogue
  * instead of storing it; 0 = store and reduce in a second kernel),
  * "out_bwd_fused" (1 -- default: in training the output conv's data gradient and weight / bias gradient come from ONE pass
@@ -189,15 +191,32 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * over the 20-float encoding per slot; a change takes effect with the next forward),
  * "head_fused" (1 -- default: the back-propagation through time of the refinement head runs as ONE launch, a block per 8 slots
  * walking the T iterations; 0 = nine launches per iteration -- also the automatic fallback when MLP_UNITS is too large for the
- * fused kernel's LDS footprint).
+ * fused kernel's LDS footprint),
+ * "refine_bwd_fused" (1 -- default: training backward, data gradient of refinement layer 1 + weight / bias gradient of layer 0
+ * in ONE launch, d(pre-activation 0) never stored (kernels_refbwd.hip; power-of-two image sizes >= 64, split first layer);
+ * 0 = the two launches),
+ * "refine_ws" (1 -- default: forward stride-2 convs of refinement layers 1.. on the weight-stationary kernel
+ * (kernels_refws.hip); 0 = the LDS-tiled stride-2 kernel),
+ * "refine_l0_fused" (1 -- default: the 17-channel encoding of get_input_encoding (iodine.py:243-343) and the first refinement
+ * layer in ONE kernel (kernels_refl0.hip) -- in inference the encoding is never written, so iodine_debug_copy("enc") then
+ * needs "stop_after_iters" >= 0 or this option 0; 0 = pixel_pass2 writes the encoding, two convs read it),
+ * "head_mfma" (1 -- default: the LSTM gate pre-activations of the refinement head as one fp32-MFMA GEMM over all slots,
+ * three launches; 0 = the one-launch head kernel),
+ * "profile_stride" (n >= 1, default 1: at "profile" level 1 only every n-th launch of a category is bracketed with events --
+ * a pair of event records idles the GPU for ~12 us; iodine_profile_read("seen:<category>") returns how many launches the
+ * category had in all),
+ * "xskip" (timing-only ablation libraries built with -DIODINE_XSKIP_HOOK; absent from the product build).
  * (The A/B-only selections of rounds 1-2 -- conv_variant 5, wgrad_ws, out_variant, out_dgrad_variant, zigzag -- were retired in
  * round 3; their kernels and measurements live under tools/experiments/ and DESIGN.md 4.3-4.5.) */
 int iodine_set_option(iodine_handle* h, const char* key, double value);
 /* Sum of event-measured durations (ms) and number of launches of one kernel category since the last reset:
  * "conv_tile_fwd", "conv_tile_dgrad", "conv_tile_wgrad", "dec_out", "dec_out_dgrad", "dec_out_wgrad", "dec_out_bwd", "dec_l0",
  * "l0_reduce",
- * "pixel_pass1", "pixel_pass2", "refine_l0" (first refinement layer), "refine_conv" (the others), "refine_head", "refine_wgrad",
- * "refine_dgrad".  Synchronises on the recorded events.  Two more names report
+ * "pixel_pass1", "pixel_pass2", "refine_l0" (first refinement layer), "refine_l0f" (encoding + first refinement layer in one
+ * kernel, option refine_l0_fused), "refine_conv" (the others), "refine_head", "refine_wgrad", "refine_dgrad", "refine_bwd01"
+ * (fused layer-1 data gradient + layer-0 weight gradient, option refine_bwd_fused), "refine_bias_grad", "head_bwd", "gen_conv"
+ * (every conv of the generic path).  "seen:<category>" returns in *launches the number of launches of <category> since the
+ * last reset, bracketed or not (option profile_stride).  Synchronises on the recorded events.  Two more names report
  * the hipGraph bookkeeping of option "graph" in *launches: "graph_captures" (graphs instantiated) and "graph_replays". */
 int iodine_profile_read(iodine_handle* h, const char* category, double* total_ms, long long* launches, int reset);
 /* Copy an internal buffer of the last call (name as listed in DESIGN.md "workspace") to dst (device). */

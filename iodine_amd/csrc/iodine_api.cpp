@@ -140,6 +140,7 @@ struct iodine_handle {
     int fwd_batch = 0;
     // last elbo() call (iodine.py:161-241): which z buffer / batch the decoder output in buf.dec_out belongs to
     int last_elbo_iter = -1, last_elbo_batch = 0;
+    bool enc_valid = false;                     // the last call left the refinement input ("enc") of its iterations in the workspace
     // hipGraph replay of the fixed-shape launch sequences (option "graph"): one instantiated graph per distinct argument tuple
     int graph = 0;
     std::vector<GraphEntry> graphs;
@@ -465,6 +466,7 @@ int ensure_workspace(iodine_handle* h, int B, int mode)
     plan(h, B, mode, a, h->buf);
     h->fwd_done = false;                 // a re-planned arena no longer holds the saved forward / the last elbo() outputs
     h->last_elbo_iter = -1;
+    h->enc_valid = false;
     // captured graphs stay: their key holds the arena's base address, the batch and (through the entry point) the mode, and the
     // carve-up is a pure function of those - a step that alternates training and reconstruct calls keeps replaying both
     return IODINE_OK;
@@ -678,6 +680,10 @@ int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps
     int rc = decoder_forward(h, st, N, b.z[i]);
     if (rc) return rc;
     PROF(h, st, "pixel_pass1", launch_pixel_pass1(st, b.x4, b.dec_out, b.g, b.part, B, h->K, h->P, (float)h->cfg.sigma));
+    // the ticket of pixel_finalize_elbo_kernel is reset by the last block of every launch; the first launch of an entry point also
+    // starts from a fresh 0 (a memset node under graph capture), whatever a failed call or a misuse of the handle from a second
+    // stream left in it - once per call, not per launch (a memset is a launch of its own)
+    if (i == 0) HIPCHK(h, hipMemsetAsync(h->elbo_counter, 0, sizeof(unsigned), st));
     HIPCHK(h, launch_pixel_finalize_elbo(st, b.part, B, h->K, h->P, h->cfg.layernorm, b.lnstat, b.ll_img, b.pm, b.plv, h->L,
                                          b.img_terms + (size_t)i * B * 2, b.scal + 3 * i, h->elbo_counter));
     h->last_elbo_iter = i; h->last_elbo_batch = B;
@@ -1218,6 +1224,8 @@ int iodine_reconstruct(iodine_handle* h, void* stream, int batch, const float* x
     if (rc) return rc;
     h->last_elbo_iter = n_it > 0 ? n_it - 1 : -1;
     h->last_elbo_batch = B;
+    // (host state, outside the graphed body) did this call leave the encoding in the workspace?  refine_step: l0f && !keep_enc skips it
+    h->enc_valid = n_it > 0 && (h->stop_after >= 0 || !(refine_split_on(h) && h->refine_l0_fused && refine_l0_fused_ok(h->S, h->Cr, h->K)));
     return IODINE_OK;
 }
 
@@ -1351,6 +1359,7 @@ int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float*
     rc = run_graphed(h, st, graph_key(h, 4, B, {x, eps, loss, elbo_iter}), body);
     if (rc) return rc;
     h->fwd_done = true;
+    h->enc_valid = true;                                   // training keeps the encoding of every iteration (the backward reads it)
     h->fwd_batch = B;
     h->fwd_split = refine_split_on(h);     // layout of the saved refinement inputs (refine_split is part of the graph key)
     h->last_elbo_iter = T;
@@ -1553,6 +1562,9 @@ int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter
     else if (s == "g") { src = b.g; n = N * P * 4; }
     else if (s == "enc") {
         n = N * P * 20;
+        // with refine_l0_fused the inference loop never writes the encoding (kernels_refl0.hip keeps it on chip) unless stop_after_iters asks
+        if (!h->enc_valid)
+            return h->fail(IODINE_ERR_STATE, "iodine_debug_copy: enc was not materialised by the last call (set stop_after_iters >= 0 or refine_l0_fused=0)");
         if (refine_split_on(h)) {                          // joined back into the reference's 17 (+3 pad) channel order
             if (n_floats) *n_floats = n;
             if (!dst) return IODINE_OK;

@@ -106,15 +106,26 @@ def replicas_identical(params: Iterable[torch.nn.Parameter], group=None) -> bool
         return True
     with torch.no_grad():
         ps = list(params)
-        n = torch.tensor([sum(p.numel() for p in ps), len(ps)], dtype=torch.int64, device=ps[0].device)
+        if not ps:
+            return True                                    # nothing to compare
+        dev = ps[0].device
+        # element counts in units of the view below (bytes for dtypes that are not 4 bytes wide)
+        n = torch.tensor([sum(p.numel() * p.element_size() for p in ps), len(ps)], dtype=torch.int64, device=dev)
         n_lo, n_hi = n.clone(), n.clone()
         dist.all_reduce(n_lo, op=dist.ReduceOp.MIN, group=group)
         dist.all_reduce(n_hi, op=dist.ReduceOp.MAX, group=group)
         if not torch.equal(n_lo, n_hi):
             return False                                   # different shapes: the bit buffers below would not even line up
-        bits = torch.cat([p.detach().contiguous().view(torch.int32).reshape(-1) for p in ps])
-        lo, hi = bits.clone(), bits.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-        same = torch.equal(lo, hi)
+        # per tensor, in chunks of at most 16 Mi elements: one reused pair of buffers instead of three copies of all parameters;
+        # every rank runs the same sequence of collectives (the shapes were just found equal); the verdict is formed at the end
+        same = True
+        CH = 1 << 24
+        for p in ps:
+            flat = p.detach().contiguous().reshape(-1)
+            bits = flat.view(torch.int32) if flat.element_size() == 4 else flat.view(torch.uint8).to(torch.int16)
+            for o in range(0, bits.numel(), CH):
+                lo, hi = bits[o:o + CH].clone(), bits[o:o + CH].clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+                same = same and torch.equal(lo, hi)
     return bool(same)

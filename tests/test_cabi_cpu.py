@@ -24,6 +24,23 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.iodine_abi_version() == 3
 
 
+def test_header_documents_every_option_and_profile_category():
+    """include/iodine_hip.h is the contract: every key iodine_set_option accepts, every category a launch is profiled under and the
+    `seen:` query must be named in it (five options and two categories had been added to the library only)."""
+    header = open(os.path.join(ROOT, 'include', 'iodine_hip.h')).read()
+    api = open(os.path.join(ROOT, 'iodine_amd', 'csrc', 'iodine_api.cpp')).read()
+    body = api[api.index('int iodine_set_option('):api.index('int iodine_reconstruct(')]
+    options = set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', body))
+    assert {'conv_precision', 'refine_l0_fused', 'profile_stride'} <= options            # the scan itself works
+    missing = sorted(o for o in options if f'"{o}"' not in header)
+    assert not missing, f'options accepted by iodine_set_option but absent from the header: {missing}'
+    cats = set(re.findall(r'PROF\(h, st, (?:[^",;]*\? *)?"([a-z_0-9]+)"', api)) | set(re.findall(r'\? "([a-z_0-9]+)" : "([a-z_0-9]+)"', api)[0])
+    assert {'conv_tile_fwd', 'refine_l0f', 'refine_bwd01', 'dec_out_bwd'} <= cats
+    missing = sorted(c for c in cats if f'"{c}"' not in header)
+    assert not missing, f'profile categories absent from the header: {missing}'
+    assert '"seen:<category>"' in header
+
+
 def test_config_struct_matches_header_field_order():
     header = open(os.path.join(ROOT, 'include', 'iodine_hip.h')).read()
     body = header[header.index('typedef struct iodine_config {'):header.index('} iodine_config;')]

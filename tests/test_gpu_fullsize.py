@@ -86,10 +86,11 @@ def _train(m, x, eps):
     return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}
 
 
-@pytest.mark.parametrize('case,B', [('cfg3_clevr_k7_t5_b1', 32), ('cfg5_clevr_k11_t7_b1', 8), ('cfg2_dsprites_k6_t5_b2', 32)])
-def test_full_size_train_step(case, B):
+@pytest.mark.parametrize('case,B,prec', [('cfg3_clevr_k7_t5_b1', 32, 1), ('cfg5_clevr_k11_t7_b1', 8, 1), ('cfg2_dsprites_k6_t5_b2', 32, 1),
+                                         ('cfg3_clevr_k7_t5_b1', 32, 0), ('cfg2_dsprites_k6_t5_b2', 32, 0)])     # prec 0: the strict exact-fp32 path
+def test_full_size_train_step(case, B, prec):
     g, arch, params, x, eps = _full_batch(case, B)
-    m = make_hip_model(arch, params)
+    m = make_hip_model(arch, params, options={'conv_precision': prec})
     xd, ed = x.to(DEV), eps.to(DEV)
     loss, grads = _train(m, xd, ed)
     elbos = m.elbo_terms[:, 0].clone()

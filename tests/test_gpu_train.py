@@ -59,22 +59,23 @@ def test_train_step_matches_reference_goldens(case):
     assert not bad, bad
 
 
+@pytest.mark.parametrize('prec', [1, 0], ids=['split_f16x3', 'exact_fp32'])
 @pytest.mark.parametrize('case', ['cfg3_clevr_k7_t5_b1', 'cfg5_clevr_k11_t7_b1'])
-def test_headline_architecture_gradients_element_wise(case):
+def test_headline_architecture_gradients_element_wise(case, prec):
     """Round 4: every gradient tensor of the HIP training step at the headline architecture against the FULL
     tensors of the reference's fp64 run (`<case>_grads.npz`, gen_goldens.py run_grad_case), element-wise: rel-L2 per tensor <= 1e-3
     (north_star gate), all tensors together <= 1e-3 - the same comparison tests/test_oracle_golden.py makes for the oracle."""
     from util import grad_views
     g, gg = load_golden(case), load_golden(case + '_grads')
     arch, params, x, eps, _ = golden_setup(g)
-    m = make_hip_model(arch, params)
+    m = make_hip_model(arch, params, options={'conv_precision': prec})       # round 5: the strict exact-fp32 path too (conv_precision 0)
     loss = _train_step(m, x, eps)
     assert abs(loss.item() - float(gg['f64.train.loss'])) <= 1e-4 * abs(float(gg['f64.train.loss']))
     assert rel_err(m.elbo_terms[:, 0].cpu(), gg['f64.train.elbos']) < 1e-4
     worst = max((rel_l2(*grad_views(n, p.grad.cpu().numpy(), gg['f64.train.grad.' + n])), n) for n, p in m.named_parameters())
     num = sum(float(((p.grad.double().cpu().numpy() - gg['f64.train.grad.' + n].astype(np.float64)) ** 2).sum()) for n, p in m.named_parameters())
     den = sum(float((gg['f64.train.grad.' + n].astype(np.float64) ** 2).sum()) for n, _ in m.named_parameters())
-    print(f'[{case}] HIP vs reference fp64, element-wise: worst tensor {worst[1]} {worst[0]:.2e}, all tensors {np.sqrt(num / den):.2e}')
+    print(f'[{case}, conv_precision {prec}] HIP vs reference fp64, element-wise: worst tensor {worst[1]} {worst[0]:.2e}, all tensors {np.sqrt(num / den):.2e}')
     assert worst[0] <= 1e-3, worst
     assert np.sqrt(num / den) <= 1e-3
 

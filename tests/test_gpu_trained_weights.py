@@ -23,8 +23,12 @@ CASES = ([('teacher_tiny', c, k) for c in (10, 30, 60, 100) for k in (1.0, 8.0)]
          + [('teacher_cfg1_long', 1000, k) for k in (1.0, 32.0)] + [('teacher_cfg1_long', 3000, k) for k in (1.0, 8.0, 32.0, 128.0)])
 
 
-@pytest.mark.parametrize('name,ckpt,sharpen', CASES)
-def test_training_step_on_trained_weights(name, ckpt, sharpen):
+# round 5: the strict path (conv_precision 0 = exact fp32 MFMA) on the hardest cases of each family, same gates
+STRICT = [('teacher_cfg3', 12, 32.0), ('teacher_cfg1_long', 3000, 32.0), ('teacher_cfg1_long', 3000, 128.0), ('teacher_cfg1', 40, 8.0)]
+
+
+@pytest.mark.parametrize('name,ckpt,sharpen,prec', [c + (1,) for c in CASES] + [c + (0,) for c in STRICT])
+def test_training_step_on_trained_weights(name, ckpt, sharpen, prec):
     t = load_golden(name)
     fam, K, T, B = str(t['meta_family']), int(t['meta_K']), int(t['meta_T']), int(t['meta_B'])
     arch = {'tiny': O.tiny_arch, 'dsprites': O.dsprites_arch, 'clevr': O.clevr_arch}[fam](slots=K, iters=T)
@@ -38,7 +42,7 @@ def test_training_step_on_trained_weights(name, ckpt, sharpen):
     eps = torch.from_numpy(synth.make_eps(T, B, K, arch.dim_latent, seed=se + 5000 + ckpt))
     out, rg = O.train_step_grads(x, eps, params, arch)
     sharp = float(out['final_mask'].max(dim=1).values.mean())
-    m = make_hip_model(arch, params)
+    m = make_hip_model(arch, params, options={'conv_precision': prec})
     m.zero_grad(set_to_none=True)
     loss = m(x.to(DEV), eps.to(DEV))
     loss.backward()
@@ -65,7 +69,7 @@ def test_training_step_on_trained_weights(name, ckpt, sharpen):
         floor['grad'] = (sum(float(((rg[n].double() - g64[n]) ** 2).sum()) for n in g64) / sum(float((g64[n] ** 2).sum()) for n in g64)) ** 0.5
         floor['worst'] = max(rel_l2(*grad_views(n, rg[n].numpy(), g64[n].numpy())) for n in g64 if float(g64[n].abs().max()) > 0)
         floor['pred'] = rel_err(ref['pred'], r64['pred'])
-    print(f'[trained weights] {name} step {ckpt} sharpen x{sharpen:g}: mean max-mask {sharp:.3f}, loss {e_loss:.1e}, ELBOs {e_elbo:.1e}, '
+    print(f'[trained weights] {name} step {ckpt} sharpen x{sharpen:g} conv_precision {prec}: mean max-mask {sharp:.3f}, loss {e_loss:.1e}, ELBOs {e_elbo:.1e}, '
           f'grad rel-L2 {e_grad:.1e}, worst tensor {worst[1]} {worst[0]:.1e}'
           + (f' | fp32-vs-fp64 floor of the oracle: grad {floor["grad"]:.1e}, worst tensor {floor["worst"]:.1e}, pred {floor["pred"]:.1e}' if floor['pred'] else ''))
     assert np.isfinite(ref_loss)

@@ -66,9 +66,12 @@ def hip_arch(arch):
                           kernels=(arch.ref_kernel, arch.dec_kernel))
 
 
-def make_hip_model(arch, params, device='cuda:0'):
+def make_hip_model(arch, params, device='cuda:0', options=None):
+    """options: library options set before the first call, e.g. {'conv_precision': 0} = the strict exact-fp32 path"""
     from iodine_amd import IODINE
     m = IODINE(hip_arch(arch))
+    for k, v in (options or {}).items():
+        m.set_option(k, v)
     sd = m.state_dict()
     assert list(sd.keys()) == list(params.keys()), 'state_dict names differ from the reference'
     m.load_state_dict({k: v.to(torch.float32) for k, v in params.items()})
