@@ -202,6 +202,10 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * needs "stop_after_iters" >= 0 or this option 0; 0 = pixel_pass2 writes the encoding, two convs read it),
  * "head_mfma" (1 -- default: the LSTM gate pre-activations of the refinement head as one fp32-MFMA GEMM over all slots,
  * three launches; 0 = the one-launch head kernel),
+ * "wgrad_accum" (0 -- default: the partial weight-gradient tiles of a decoder launch are reduced right behind it; 1 = every block
+ * keeps its partial tile over the T + 1 decoder passes of a training step (adds alpha_i x pass i; alpha_i = the pass's loss
+ * weight) and the fixed-order reduction runs once per layer and step, 3 + 1 instead of 18 + 6 reductions per cfg3 step --
+ * measured equal in time, so not the default; a change re-plans the workspace),
  * "profile_stride" (n >= 1, default 1: at "profile" level 1 only every n-th launch of a category is bracketed with events --
  * a pair of event records idles the GPU for ~12 us; iodine_profile_read("seen:<category>") returns how many launches the
  * category had in all),

@@ -95,7 +95,8 @@ def lib() -> C.CDLL:
     L.iodine_op_conv3x3.argtypes = [vp, ci] + [vp] * 5 + [ci] * 10
     L.iodine_op_dec_out.argtypes = [vp] + [vp] * 4 + [ci] * 3
     L.iodine_op_conv3x3_wgrad.argtypes = [vp] + [vp] * 4 + [ci] * 6
-    L.iodine_op_conv3x3_wgrad_f32.argtypes = [vp] + [vp] * 4 + [ci] * 3
+    if hasattr(L, 'iodine_op_conv3x3_wgrad_f32'):       # (absent from older builds loaded through IODINE_HIP_LIB for same-box A/B)
+        L.iodine_op_conv3x3_wgrad_f32.argtypes = [vp] + [vp] * 4 + [ci] * 3
     if L.iodine_abi_version() != 3:
         raise RuntimeError('libiodine_hip.so ABI version mismatch')
     _lib = L

@@ -299,7 +299,7 @@ hipError_t launch_conv3x3_ws_f32(hipStream_t st, const float* in, const void* wp
                                  int N, int S, int c, int epi, int rev);
 // kernels_wgrad32.hip: exact-fp32 weight gradient, persistent + prefetched (part: [nparts][9][c][c], part_b: [nbias_parts][c])
 hipError_t launch_conv3x3_wgrad_f32_ws(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N, int S, int c,
-                                       int* nparts, int* ncop, int* nbias_parts);
+                                       int* nparts, int* ncop, int* nbias_parts, float alpha = 1.f, int accum = 0);
 inline size_t conv_ws_wpk_bytes(int C) { return (size_t)(C / 16) * (C / 32) * 9 * 2 * 64 * 16; }
 inline size_t conv_ws_tmax_floats(int N, int S) { return (size_t)N * (S / 16) * (S / 8) * 4; }
 
@@ -358,6 +358,7 @@ hipError_t launch_dec_out_wgrad_gemm_f16x3(hipStream_t st, const float* a, const
                                            int S, int c, int* nparts, int* nbias_parts);
 hipError_t launch_dec_out_bwd_fused_f16x3(hipStream_t st, const float* a, const float* g, const void* wpk, const float* wmeta,
                                           float* out, float* tmax, float* part, float* part_b, int N, int S, int c,
-                                          int* nparts, int* nbias_parts);
+                                          int* nparts, int* nbias_parts, float alpha = 1.f, int accum = 0);
+// alpha / accum (round 5): part / part_b = (accum ? part : 0) + alpha x this launch - a block's partial tile kept over the decoder passes
 hipError_t launch_conv3x3_wgrad_f16x3_ws(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
-                                         int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts);
+                                         int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts, float alpha = 1.f, int accum = 0);

@@ -51,6 +51,9 @@ struct Buffers {               // workspace carve-up for one batch size / mode
     std::vector<std::vector<float*>> ract;     // [iter][layer] refinement activations
     // training only
     float *wg_part = nullptr, *wg_part_b = nullptr, *wg_fold = nullptr, *Dsum = nullptr, *Dpart = nullptr, *RT = nullptr, *tmp_lz = nullptr;
+    // round 5 (option wgrad_accum): per-layer partial weight-gradient tiles kept over the T + 1 decoder passes of a step (one reduction
+    // per layer and step); [0] = the output conv, [l] = decoder layer l
+    std::vector<float*> wg_acc, wg_acc_b;
     float *rown = nullptr, *Rsum = nullptr;     // training row-sum form of the broadcast layer's backward (EPI_L0ROWSX)
     float* l0scr = nullptr;                     // partial class sums of the row-sum reductions (l0_rows_scratch_floats)
     float *ddm = nullptr, *ddv = nullptr, *dc1 = nullptr, *dgates = nullptr, *dxin = nullptr, *ds = nullptr,
@@ -118,6 +121,11 @@ struct iodine_handle {
     int head_mfma = 1;                                     // LSTM gate pre-activations of the refinement head as one fp32-MFMA GEMM over all slots
     int refine_l0_fused = 1;                               // encoding + first refinement layer in one kernel (kernels_refl0.hip); 0: pixel_pass2 + two convs
     void *ref_l0k = nullptr, *ref_l0s = nullptr; float *ref_l0kmeta = nullptr, *ref_l0smeta = nullptr;     // its weight packs
+    int wgrad_accum = 0;                                   // 1: the decoder's partial weight-gradient tiles accumulate over the T + 1 passes of a training
+                                                           // step (alpha = pass weight) and are reduced once per layer and step.  Measured (round 5, same
+                                                           // process A/B): cfg3 48.197 vs 48.200 ms, cfg2 6.55 vs 6.53 ms - the read-modify-write of the
+                                                           // partial tiles in the kernels' tails costs what the 20 saved reduce launches cost: NOT adopted,
+                                                           // kept as an option (off: no extra workspace)
     int refine_ws = 1;                                     // forward stride-2 convs of refinement layers 1 .. on the weight-stationary kernel (kernels_refws.hip)
     std::vector<float*> ref_wsf, ref_wsf_meta;             // their weights in its register layout
     float *ref_w1ws = nullptr, *ref_w1ws_meta = nullptr;   // layer 1's weights in the register layout of the fused layer-1/0 backward
@@ -402,6 +410,15 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
                                       ? (size_t)512 * 4 * 9 * 32 * 32 : (size_t)512 * 9 * Cmax * Cmax;
         b.wg_part = a.take<float>(part_elems);
         b.wg_part_b = a.take<float>((size_t)512 * 64);
+        b.wg_acc.assign(h->Dd, nullptr); b.wg_acc_b.assign(h->Dd, nullptr);
+        if (h->wgrad_accum && !h->generic) {
+            b.wg_acc[0] = a.take<float>((size_t)1024 * 2 * 9 * Cd * 4);       // dec_out_bwd_fused: <= 1024 blocks x KS <= 2 tiles of [9][Cd][4]
+            b.wg_acc_b[0] = a.take<float>((size_t)1024 * 4);
+            for (int l = 1; l < h->Dd; ++l) {
+                b.wg_acc[l] = a.take<float>((size_t)512 * 4 * 9 * 32 * 32 > (size_t)512 * 9 * Cd * Cd ? (size_t)512 * 4 * 9 * 32 * 32 : (size_t)512 * 9 * Cd * Cd);
+                b.wg_acc_b[l] = a.take<float>((size_t)512 * 64);
+            }
+        }
         b.wg_fold = a.take<float>((size_t)WGRAD_FOLD * 9 * Cmax * Cmax);
         b.Dsum = a.take<float>((size_t)P * Cd);
         b.Dpart = a.take<float>((size_t)l0_dgroups(N) * P * Cd);
@@ -570,13 +587,23 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
 #ifdef IODINE_XSKIP_HOOK
     if (!(g_iod_xskip & 256))
 #endif
+    // round 5: a block's partial tile accumulates alpha_i x (pass i) in a per-layer buffer; reduced once, after the last pass (it == T)
+    const bool acc_w = train_alpha != 0.f && h->wgrad_accum && !b.wg_acc.empty() && b.wg_acc[0];
     if (out_fused) {
         const int wi = param_index(h, "decoder.conv.weight"), bi = param_index(h, "decoder.conv.bias");
+        if (acc_w) {
+            PROF(h, st, "dec_out_bwd", launch_dec_out_bwd_fused_f16x3(st, b.act[Dd - 1], b.g, h->dec_out_wb16, h->dec_out_meta,
+                                                                       b.dpre[cur], conv_ws_ok(h) ? b.tmax_dpre[cur] : nullptr,
+                                                                       b.wg_acc[0], b.wg_acc_b[0], N, h->S, Cd, &nparts, &nb, train_alpha, it != 0));
+            if (it == h->T)
+                HIPCHK(h, launch_wgrad_reduce(st, b.wg_acc[0], nparts, Cd, 4, 4, Cd, Cd, 1.f, h->gacc[wi], b.wg_fold, b.wg_acc_b[0], nb, h->gacc[bi]));
+        } else {
         PROF(h, st, "dec_out_bwd", launch_dec_out_bwd_fused_f16x3(st, b.act[Dd - 1], b.g, h->dec_out_wb16, h->dec_out_meta,
                                                                    b.dpre[cur], conv_ws_ok(h) ? b.tmax_dpre[cur] : nullptr,
                                                                    b.wg_part, b.wg_part_b, N, h->S, Cd, &nparts, &nb));
         HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, Cd, 4, 4, Cd, Cd, train_alpha, h->gacc[wi], b.wg_fold,
                                       b.wg_part_b, nb, h->gacc[bi]));
+        }
     } else
     {
         if (h->precision == 1)
@@ -604,7 +631,19 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         }
     }
     for (int l = Dd - 1; l >= 1; --l) {
-        if (train_alpha != 0.f) {
+        if (train_alpha != 0.f && acc_w && (h->precision == 1 || conv_ws32_ok(h))) {
+            if (h->precision == 1)
+                PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_f16x3_ws(st, b.act[l - 1], b.dpre[cur], b.wg_acc[l], b.wg_acc_b[l], N, h->S, Cd, Cd,
+                                                                              &nparts, &ncop, &nb, train_alpha, it != 0));
+            else
+                PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_f32_ws(st, b.act[l - 1], b.dpre[cur], b.wg_acc[l], b.wg_acc_b[l], N, h->S, Cd,
+                                                                            &nparts, &ncop, &nb, train_alpha, it != 0));
+            if (it == h->T) {
+                const std::string base = "decoder.mlc.layers." + std::to_string(l);
+                HIPCHK(h, launch_wgrad_reduce(st, b.wg_acc[l], nparts, Cd, ncop, Cd, Cd, Cd, 1.f, h->gacc[param_index(h, base + ".weight")], b.wg_fold,
+                                              b.wg_acc_b[l], nb, h->gacc[param_index(h, base + ".bias")]));
+            }
+        } else if (train_alpha != 0.f) {
             if (h->precision == 1)
                 PROF(h, st, "conv_tile_wgrad", launch_conv3x3_wgrad_f16x3_ws(st, b.act[l - 1], b.dpre[cur], b.wg_part,
                                                                               b.wg_part_b, N, h->S, Cd, Cd, &nparts, &ncop, &nb));
@@ -820,7 +859,7 @@ int run_graphed(iodine_handle* h, hipStream_t st, const std::vector<uintptr_t>& 
 std::vector<uintptr_t> graph_key(const iodine_handle* h, int entry, int batch, std::initializer_list<const void*> ptrs)
 {
     std::vector<uintptr_t> k = {(uintptr_t)entry, (uintptr_t)batch, (uintptr_t)h->stop_after, (uintptr_t)h->precision,
-                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)(h->head_fused | (h->refine_bwd_fused << 1) | (h->refine_ws << 2) | (h->refine_l0_fused << 3) | (h->head_mfma << 4)),
+                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)(h->head_fused | (h->refine_bwd_fused << 1) | (h->refine_ws << 2) | (h->refine_l0_fused << 3) | (h->head_mfma << 4) | (h->wgrad_accum << 5)),
                                 (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
     for (const void* p : ptrs) k.push_back((uintptr_t)p);
     return k;
@@ -1166,6 +1205,10 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "head_mfma")) { h->head_mfma = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_l0_fused")) { h->refine_l0_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_ws")) { h->refine_ws = value != 0; return IODINE_OK; }
+    if (!strcmp(key, "wgrad_accum")) {
+        if (h->wgrad_accum != (value != 0)) { h->buf = Buffers(); h->fwd_done = false; h->last_elbo_iter = -1; h->enc_valid = false; }   // the arena is re-planned
+        h->wgrad_accum = value != 0; return IODINE_OK;
+    }
     if (!strcmp(key, "conv_variant")) {
         if (value != 1 && value != 6) return h->fail(IODINE_ERR_INVALID, "conv_variant must be 1 (LDS-tiled) or 6 (weight-stationary)");
         if (((int)value == 6) != (h->variant == 6)) h->params_set = false;   // the other kernel's weight packs are not kept up to date

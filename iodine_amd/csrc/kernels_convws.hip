@@ -121,8 +121,16 @@ IOD_DEVINL float pixel_lane_sum(float v)
     return v;
 }
 
+// LDS / occupancy: 160-byte staged pixels, two persistent blocks per CU.  Round 5 tried THREE blocks per CU at C = 32 (144-byte pixels:
+// 3 x 52 KB of LDS, 165 VGPRs): the cfg2 step did not move (6.57 -> 6.54 ms incl. the pixel-kernel gains of the same build).  The phase
+// counters say why: the three waves of a SIMD run their MFMA phases in lockstep (4.9 k ticks per tile for 3 x 1.7 k cycles of MFMA:
+// the pipe is saturated while they are in it) and their epilogues too; per launch only 8 - 12 tiles per block follow a ~8 us prologue
+// (weights -> registers, first halo: two exposed HBM round trips) - at 64 x 64 images the launch is latency-, not occupancy-bound.
+constexpr int ws_pxb(int c) { return 160; }
+constexpr int ws_bpc(int c, int epi) { return 2; }
+
 template <int C, int EPI, bool F32 = false>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, ws_bpc(C, EPI))
 void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
                              const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
                              const float* __restrict__ tmax_in, float* __restrict__ tmax_out, int S, int lgS, int ntiles, int rev)
@@ -132,7 +140,7 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
     constexpr int RW = 8 / NPG;                  // output rows per wave
     constexpr int NCHUNK = C / 32;               // K chunks of 32 input channels
     constexpr int HC = 18, HR = 10, NPX = HC * HR;
-    constexpr int PXB = 160;                     // bytes per staged pixel: 64 hi | 64 lo | 32 pad (conflict-free ds_read_b128);
+    constexpr int PXB = ws_pxb(C);               // bytes per staged pixel: 64 hi | 64 lo | 32 (C = 32: 16) pad (conflict-free ds_read_b128);
                                                  // exact-fp32 form (F32): 32 channels x 4 bytes | 32 pad - the same geometry
     constexpr int EPS = C * 4 + 32;              // bytes per pixel of the transposed output tile (epilogue)
     constexpr int BUFB = ((NPX + 1) * PXB > 128 * EPS ? (NPX + 1) * PXB : 128 * EPS);    // one LDS buffer (input halo / output tile)
@@ -666,7 +674,7 @@ template <int C, int EPI, bool F32 = false>
 static hipError_t launch_ws_inst(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
                                  const float* aux, float* out, const float* tmax_in, float* tmax_out, int N, int S, int rev)
 {
-    constexpr size_t buf_in = (size_t)(18 * 10 + 1) * 160, buf_out = (size_t)128 * (C * 4 + 32);
+    constexpr size_t buf_in = (size_t)(18 * 10 + 1) * ws_pxb(C), buf_out = (size_t)128 * (C * 4 + 32);
     constexpr size_t lds = 2 * (buf_in > buf_out ? buf_in : buf_out);
     static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
     if (hipError_t e = iod_set_max_lds((const void*)conv3x3_ws_f16x3_kernel<C, EPI, F32>, (int)lds, attr_devs); e != hipSuccess) return e;
@@ -676,7 +684,7 @@ static hipError_t launch_ws_inst(hipStream_t st, const float* in, const void* wp
     while ((1 << lgS) < S) ++lgS;
     const int ntiles = N * (S / 16) * (S / 8);
     const int per_xcd = (ntiles + 7) / 8;
-    int bpc = 2;                                                           // two persistent blocks per CU
+    int bpc = ws_bpc(C, EPI);                                                   // persistent blocks per CU (see ws_bpc)
 #ifdef WS_TUNE_ENV
     if (const char* e = getenv("IODINE_WS_BPC")) bpc = atoi(e);
 #endif

@@ -1158,6 +1158,7 @@ __global__ __launch_bounds__(256, 4)
 void dec_out_wgrad_gemm_f16x3_kernel(const float* __restrict__ a, const float* __restrict__ g, float* __restrict__ part,
                                      float* __restrict__ part_b, int S, int ntiles, int tiles_x, int tiles_y)
 {
+    constexpr float alpha = 1.f; constexpr int accum = 0;    // (this two-kernel form reduces after every launch: option out_bwd_fused 0)
     constexpr int NTT = C / 32;                          // ci tiles
     constexpr int KS = 2 / NTT;                          // waves = 2 (j tiles) x NTT x KS
     constexpr int TH = 4, RW = TH / KS;
@@ -1294,14 +1295,18 @@ void dec_out_wgrad_gemm_f16x3_kernel(const float* __restrict__ a, const float* _
     }
 
     // rows of the accumulator are j = tap*4 + co: registers 4q .. 4q+3 of a lane are the 4 output channels of one tap
-    const float inv = 1.f / acc_prod;
+    // (accum / alpha: the block's partial tile accumulates over the decoder passes of a training step, see conv3x3_wgrad_f16x3_ws_kernel)
+    const float inv = alpha / acc_prod;
     float* pw = part + (size_t)(blockIdx.x * KS + ks) * 9 * C * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int tp = mj * 8 + 2 * q + kh;
-        if (tp < 9)
-            *reinterpret_cast<float4*>(pw + ((size_t)tp * C + ci) * 4) =
-                make_float4(acc[4 * q] * inv, acc[4 * q + 1] * inv, acc[4 * q + 2] * inv, acc[4 * q + 3] * inv);
+        if (tp < 9) {
+            float4* dst4 = reinterpret_cast<float4*>(pw + ((size_t)tp * C + ci) * 4);
+            float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (accum) o4 = *dst4;
+            *dst4 = make_float4(o4.x + acc[4 * q] * inv, o4.y + acc[4 * q + 1] * inv, o4.z + acc[4 * q + 2] * inv, o4.w + acc[4 * q + 3] * inv);
+        }
     }
     __syncthreads();
     float4* s_red = reinterpret_cast<float4*>(s_b);
@@ -1310,7 +1315,10 @@ void dec_out_wgrad_gemm_f16x3_kernel(const float* __restrict__ a, const float* _
     if (tid == 0) {
         float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int q = 0; q < 256; ++q) { const float4 v = s_red[q]; t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w; }
-        *reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * 4) = t4;
+        float4* pb = reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * 4);
+        float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (accum) o4 = *pb;
+        *pb = make_float4(o4.x + alpha * t4.x, o4.y + alpha * t4.y, o4.z + alpha * t4.z, o4.w + alpha * t4.w);
     }
 }
 
@@ -1350,7 +1358,7 @@ __global__ __launch_bounds__(256, (C == 64 && PF) ? 3 : 4)
 void dec_out_bwd_fused_f16x3_kernel(const float* __restrict__ a, const float* __restrict__ g, const uint4* __restrict__ wpk,
                                     const float* __restrict__ wmeta, float* __restrict__ out, float* __restrict__ tmax,
                                     float* __restrict__ part, float* __restrict__ part_b, int S, int ntiles, int tiles_x,
-                                    int tiles_y)
+                                    int tiles_y, float alpha, int accum)
 {
     constexpr int NTT = C / 32;                          // ci tiles
     constexpr int KS = 2 / NTT;                          // waves = 2 (j tiles) x NTT x KS
@@ -1597,14 +1605,18 @@ void dec_out_bwd_fused_f16x3_kernel(const float* __restrict__ a, const float* __
         tmax[prev_tm + tid] = fmaxf(fmaxf(s_omax[0], s_omax[1]), fmaxf(s_omax[2], s_omax[3]));
 
     // rows of the accumulator are j = tap*4 + co: registers 4q .. 4q+3 of a lane are the 4 output channels of one tap
-    const float inv = 1.f / acc_prod;
+    // (accum / alpha: the block's partial tile accumulates over the decoder passes of a training step, see conv3x3_wgrad_f16x3_ws_kernel)
+    const float inv = alpha / acc_prod;
     float* pw = part + (size_t)(blockIdx.x * KS + ks) * 9 * C * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int tp = mj * 8 + 2 * q + kh;
-        if (tp < 9)
-            *reinterpret_cast<float4*>(pw + ((size_t)tp * C + ci) * 4) =
-                make_float4(acc[4 * q] * inv, acc[4 * q + 1] * inv, acc[4 * q + 2] * inv, acc[4 * q + 3] * inv);
+        if (tp < 9) {
+            float4* dst4 = reinterpret_cast<float4*>(pw + ((size_t)tp * C + ci) * 4);
+            float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (accum) o4 = *dst4;
+            *dst4 = make_float4(o4.x + acc[4 * q] * inv, o4.y + acc[4 * q + 1] * inv, o4.z + acc[4 * q + 2] * inv, o4.w + acc[4 * q + 3] * inv);
+        }
     }
     __syncthreads();
     float4* s_red = reinterpret_cast<float4*>(s_b);
@@ -1613,14 +1625,17 @@ void dec_out_bwd_fused_f16x3_kernel(const float* __restrict__ a, const float* __
     if (tid == 0) {
         float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int q = 0; q < 256; ++q) { const float4 v = s_red[q]; t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w; }
-        *reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * 4) = t4;
+        float4* pb = reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * 4);
+        float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (accum) o4 = *pb;
+        *pb = make_float4(o4.x + alpha * t4.x, o4.y + alpha * t4.y, o4.z + alpha * t4.z, o4.w + alpha * t4.w);
     }
 }
 
 // part: nparts x [9][c][4], part_b: nbias_parts x [4]; out = d(pre-activation) of the last hidden layer, tmax its side buffer
 hipError_t launch_dec_out_bwd_fused_f16x3(hipStream_t st, const float* a, const float* g, const void* wpk, const float* wmeta,
                                           float* out, float* tmax, float* part, float* part_b, int N, int S, int c,
-                                          int* nparts, int* nbias_parts)
+                                          int* nparts, int* nbias_parts, float alpha, int accum)
 {
     if (S % 16 != 0 || (c != 64 && c != 32)) return hipErrorInvalidValue;
     const int tiles_x = S / 16, tiles_y = S / 4, ntiles = N * tiles_x * tiles_y;
@@ -1630,7 +1645,7 @@ hipError_t launch_dec_out_bwd_fused_f16x3(hipStream_t st, const float* a, const 
     const int blocks = ntiles < cap ? ntiles : cap;
 #define IOD_LAUNCH_OUTBWD(CC, PFV)                                                                                            \
     hipLaunchKernelGGL((dec_out_bwd_fused_f16x3_kernel<CC, PFV>), dim3(blocks), dim3(256), 0, st, a, g, (const uint4*)wpk, wmeta, \
-                       out, tmax, part, part_b, S, ntiles, tiles_x, tiles_y)
+                       out, tmax, part, part_b, S, ntiles, tiles_x, tiles_y, alpha, accum)
     if (c == 64) { if (pf) IOD_LAUNCH_OUTBWD(64, true); else IOD_LAUNCH_OUTBWD(64, false); }
     else { if (pf) IOD_LAUNCH_OUTBWD(32, true); else IOD_LAUNCH_OUTBWD(32, false); }
 #undef IOD_LAUNCH_OUTBWD
@@ -1664,7 +1679,7 @@ IOD_DEVINL void iod_static_for(F&& f) { iod_static_for_impl(f, std::make_integer
 template <int CI, int NCO, bool TR>
 __global__ __launch_bounds__(512, 2)
 void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __restrict__ d, float* __restrict__ part,
-                                   float* __restrict__ part_b, int S, int ntiles, int tiles_x, int tiles_y)
+                                   float* __restrict__ part_b, int S, int ntiles, int tiles_x, int tiles_y, float alpha, int accum)
 {
     constexpr int MT = CI / 32, NTT = NCO / 32, KS = 4 / (MT * NTT);
     constexpr int TH = 4, HH = TH + 2;
@@ -2034,8 +2049,22 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
     if (tid == 0 && blockIdx.x < TP_MAXBLK) for (int i_ = 0; i_ < 2; ++i_) g_wgrad_prof[blockIdx.x * 8 + i_] = tp_acc[i_];
 #endif
     constexpr int NCOP = NTT * 32;
-    const float inv = 1.f / acc_prod;
+    // Round 5: the partial tile of THIS block can be kept across the T + 1 decoder passes of a training step (accum: add alpha x this
+    // launch to what the block left there in the previous pass; alpha = the pass's loss weight -w_i / B), so that the fixed-order
+    // reduction over the blocks runs once per layer and step instead of once per launch (18 -> 3 reduce launches per cfg3 step).
+    const float inv = alpha / acc_prod;
     float* pw = part + ((size_t)(blockIdx.x * KS + ks) * 9) * CI * NCOP;
+    if (accum) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            float old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = pw[((size_t)tap * CI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * NCOP + ni * 32 + li];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                pw[((size_t)tap * CI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * NCOP + ni * 32 + li] = old[r] + (nq > 0 ? acc[tap][r] * inv : 0.f);
+        }
+    } else {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -2043,19 +2072,23 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
             const int cr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             pw[((size_t)tap * CI + cr) * NCOP + ni * 32 + li] = nq > 0 ? acc[tap][r] * inv : 0.f;
         }
+    }
     __builtin_amdgcn_s_barrier();                                           // F1
     __builtin_amdgcn_s_barrier();                                           // F2: producers' bias sums are in LDS
     if (tid < D4) {
         const float4* s_red = reinterpret_cast<const float4*>(smem_ws);
         float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = tid; j < 256; j += D4) { const float4 v = s_red[j]; t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w; }
-        *reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * NCO + tid * 4) = t4;
+        float4* pb = reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * NCO + tid * 4);
+        float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (accum) o4 = *pb;
+        *pb = make_float4(o4.x + alpha * t4.x, o4.y + alpha * t4.y, o4.z + alpha * t4.z, o4.w + alpha * t4.w);
     }
 }
 
 template <int CI, int NCO, bool TR>
 static hipError_t launch_wgrad_f16_ws_inst(hipStream_t st, const float* a, const float* d, float* part, float* part_b,
-                                           int N, int S, int* nparts, int* ncop, int* nbias)
+                                           int N, int S, int* nparts, int* ncop, int* nbias, float alpha, int accum)
 {
     constexpr int MT = CI / 32, NTT = NCO / 32, KS = 4 / (MT * NTT);
     constexpr size_t buf = true ? (size_t)6 * 20 * (2 * CI * 2 + 64) + (size_t)4 * 16 * (2 * NCO * 2 + 64)
@@ -2066,7 +2099,7 @@ static hipError_t launch_wgrad_f16_ws_inst(hipStream_t st, const float* a, const
     const int tiles_x = S / 16, tiles_y = S / 4, ntiles = N * tiles_x * tiles_y;
     const int blocks = ntiles < 256 ? ntiles : 256;
     hipLaunchKernelGGL((conv3x3_wgrad_f16x3_ws_kernel<CI, NCO, TR>), dim3(blocks), dim3(512), lds, st, a, d, part, part_b, S,
-                       ntiles, tiles_x, tiles_y);
+                       ntiles, tiles_x, tiles_y, alpha, accum);
 #ifdef IODINE_TILE_PROF
     {
         std::vector<unsigned> hp((size_t)blocks * 8);
@@ -2088,10 +2121,10 @@ static hipError_t launch_wgrad_f16_ws_inst(hipStream_t st, const float* a, const
 
 // variant 1: transposing stagers + v_alignbit shifts; variant 2: natural-order staging + ds_read_b64_tr_b16
 hipError_t launch_conv3x3_wgrad_f16x3_ws(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
-                                         int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts)
+                                         int S, int ci, int nco, int* nparts, int* ncop, int* nbias_parts, float alpha, int accum)
 {
     if (S % 16 != 0) return hipErrorInvalidValue;
-    if (ci == 64 && nco == 64) return launch_wgrad_f16_ws_inst<64, 64, true>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts);
-    if (ci == 32 && nco == 32) return launch_wgrad_f16_ws_inst<32, 32, true>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts);
+    if (ci == 64 && nco == 64) return launch_wgrad_f16_ws_inst<64, 64, true>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts, alpha, accum);
+    if (ci == 32 && nco == 32) return launch_wgrad_f16_ws_inst<32, 32, true>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts, alpha, accum);
     return hipErrorInvalidValue;
 }

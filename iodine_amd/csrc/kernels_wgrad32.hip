@@ -36,7 +36,7 @@ IOD_DEVINL void w32_static_for(F&& f)
 template <int C>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_wgrad_f32_ws_kernel(const float* __restrict__ a, const float* __restrict__ d, float* __restrict__ part,
-                                 float* __restrict__ part_b, int S, int ntiles)
+                                 float* __restrict__ part_b, int S, int ntiles, float alpha, int accum)
 {
     constexpr int MT = C / 32;                   // ci halves
     constexpr int NTT = C / 32;                  // co halves
@@ -179,15 +179,19 @@ void conv3x3_wgrad_f32_ws_kernel(const float* __restrict__ a, const float* __res
     }
 
     // partial dW: rows = ci (accumulator rows), cols = co (lane & 31)
+    // (accum / alpha: the block's partial tile accumulates alpha x this launch over the decoder passes of a training step - one
+    // fixed-order reduction per layer and step, see conv3x3_wgrad_f16x3_ws_kernel)
     constexpr int NCOP = NTT * 32;
     float* pw = part + ((size_t)(blockIdx.x * KS + ks) * 9) * C * NCOP;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < 9; ++tap) {
+        float old[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ci = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            pw[((size_t)tap * C + ci) * NCOP + ni * 32 + li] = acc[tap][r];
-        }
+        for (int r = 0; r < 16; ++r) old[r] = accum ? pw[((size_t)tap * C + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * NCOP + ni * 32 + li] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            pw[((size_t)tap * C + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * NCOP + ni * 32 + li] = old[r] + alpha * acc[tap][r];
+    }
     // partial bias gradient: a thread's channel quad is fixed (256 % Q == 0); fixed-order sum over the threads that share it
     __syncthreads();
     f32x4* s_red = reinterpret_cast<f32x4*>(smem_w32);
@@ -196,7 +200,10 @@ void conv3x3_wgrad_f32_ws_kernel(const float* __restrict__ a, const float* __res
     if (tid < Q) {
         f32x4 t4 = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int j = tid; j < 256; j += Q) t4 += s_red[j];
-        *reinterpret_cast<f32x4*>(part_b + (size_t)blockIdx.x * C + tid * 4) = t4;
+        f32x4* pb = reinterpret_cast<f32x4*>(part_b + (size_t)blockIdx.x * C + tid * 4);
+        f32x4 o4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (accum) o4 = *pb;
+        *pb = o4 + t4 * alpha;
     }
 #undef W32_BLOAD4
 #undef W32_SGPR_SETTLE
@@ -212,7 +219,7 @@ int wgrad_f32_ws_blocks(int N, int S, int n_cu)
 
 template <int C>
 static hipError_t launch_wgrad_f32_ws_inst(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N, int S,
-                                           int* nparts, int* ncop, int* nbias_parts)
+                                           int* nparts, int* ncop, int* nbias_parts, float alpha, int accum)
 {
     constexpr int KS = 4 / ((C / 32) * (C / 32));
     constexpr size_t lds = (size_t)(C / 32) * (6 * 18 + 4 * 16) * 128;
@@ -223,7 +230,7 @@ static hipError_t launch_wgrad_f32_ws_inst(hipStream_t st, const float* a, const
     const int ntiles = N * (S / 4) * (S / 16);
     int blocks = wgrad_f32_ws_blocks(N, S, n_cu);
     if (blocks > 512) blocks = 512;                                      // capacity of the partial-tile buffers (plan(): 512 blocks)
-    hipLaunchKernelGGL((conv3x3_wgrad_f32_ws_kernel<C>), dim3(blocks), dim3(256), lds, st, a, d, part, part_b, S, ntiles);
+    hipLaunchKernelGGL((conv3x3_wgrad_f32_ws_kernel<C>), dim3(blocks), dim3(256), lds, st, a, d, part, part_b, S, ntiles, alpha, accum);
     *nparts = blocks * KS;
     *ncop = C;
     *nbias_parts = blocks;
@@ -232,10 +239,10 @@ static hipError_t launch_wgrad_f32_ws_inst(hipStream_t st, const float* a, const
 
 // a, d: NHWC [N][S][S][c]; part: [nparts][9][c][c], part_b: [nbias_parts][c] (reduced by launch_wgrad_reduce)
 hipError_t launch_conv3x3_wgrad_f32_ws(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N, int S, int c,
-                                       int* nparts, int* ncop, int* nbias_parts)
+                                       int* nparts, int* ncop, int* nbias_parts, float alpha, int accum)
 {
     if (S % 16 != 0 || (size_t)S * S * c * 4 >= ((size_t)1 << 31)) return hipErrorInvalidValue;
-    if (c == 64) return launch_wgrad_f32_ws_inst<64>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts);
-    if (c == 32) return launch_wgrad_f32_ws_inst<32>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts);
+    if (c == 64) return launch_wgrad_f32_ws_inst<64>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts, alpha, accum);
+    if (c == 32) return launch_wgrad_f32_ws_inst<32>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts, alpha, accum);
     return hipErrorInvalidValue;
 }

@@ -18,6 +18,18 @@ struct PixelTerms {
     float loo[K];         // leave-one-out likelihood (iodine.py:321-328), see pixel_terms
 };
 
+// Round 5: of the ~2080 VALU instructions this function took per pixel at K = 7, 740 were the range / denormal handling around the 57
+// v_exp_f32 of libm's expf and 530 the IEEE sequences of 53 divisions - and every kernel that inlines it (pass 1, pass 2, the fused first
+// refinement layer) is VALU-issue-bound.  Where the argument is bounded and the result enters a sum next to a term of order 1 - the
+// sigmoids, the max-subtracted softmax over the slots, the max-subtracted responsibilities - exp is now v_exp_f32(x log2 e) (relative
+// error <= |x| 2^-24 + 1 ulp; results below the normal range flush to 0 next to a 1) and a / b is a * v_rcp_f32(b) (1 ulp + 1 rounding;
+// 1 / inf = 0 and NaN propagate like the IEEE sequence).  The UN-stabilised terms of the reference keep libm's expf and the IEEE
+// division: p_k = exp(sum_c l_kc) and exp(ll_sum) (arguments down to -140: denormal results matter for WHERE the 0 / 0 of
+// mask_posterior appears, iodine.py:286-293) and the leave-one-out channel (the reference's exact sequence of rounded operations, below).
+IOD_DEVINL float pt_exp_bounded(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+IOD_DEVINL float pt_rcp(float d) { return __builtin_amdgcn_rcpf(d); }
+IOD_DEVINL float pt_sigmoid(float v) { return pt_rcp(1.f + pt_exp_bounded(-v)); }
+
 // dv[k] = decoder output (rgb logits, mask logit) of slot k at this pixel
 template <int K>
 IOD_DEVINL void pixel_terms_core(const float4 xv, const float4 (&dv)[K], float inv2s2, float invs2, float lconst, PixelTerms<K>& t)
@@ -33,17 +45,23 @@ IOD_DEVINL void pixel_terms_core(const float4 xv, const float4 (&dv)[K], float i
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const float4 d = dv[k];
-        t.mu[k][0] = sigmoidf_(d.x); t.mu[k][1] = sigmoidf_(d.y); t.mu[k][2] = sigmoidf_(d.z);
+        t.mu[k][0] = pt_sigmoid(d.x); t.mu[k][1] = pt_sigmoid(d.y); t.mu[k][2] = pt_sigmoid(d.z);
         t.logit[k] = d.w;
         mx = fmaxf(mx, d.w);
     }
     float den = 0.f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) { t.m[k] = expf(t.logit[k] - mx); den += t.m[k]; }
-    const float rden = 1.f / den;
-    float lm[K];
+    for (int k = 0; k < K; ++k) { t.m[k] = pt_exp_bounded(t.logit[k] - mx); den += t.m[k]; }
+    const float rden = pt_rcp(den);
+    float lm[K], rme[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { t.m[k] *= rden; lm[k] = logf(t.m[k] + 1e-12f); t.g2[k] = 0.f; }
+    for (int k = 0; k < K; ++k) {
+        t.m[k] *= rden;
+        const float me = t.m[k] + 1e-12f;
+        lm[k] = logf(me);
+        rme[k] = pt_rcp(me);                                   // 1 / (m_k + 1e-12): d log(m + 1e-12) / dm, once per slot
+        t.g2[k] = 0.f;
+    }
     float lsum[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) lsum[k] = 0.f;
@@ -62,14 +80,14 @@ IOD_DEVINL void pixel_terms_core(const float4 xv, const float4 (&dv)[K], float i
         }
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < K; ++k) { a[k] = expf(a[k] - amax); s += a[k]; }
+        for (int k = 0; k < K; ++k) { a[k] = pt_exp_bounded(a[k] - amax); s += a[k]; }
         t.ll_sum += amax + logf(s);
-        const float rs = 1.f / s;
+        const float rs = pt_rcp(s);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float r = a[k] * rs;                         // responsibility of slot k for channel c
             t.g1[k][c] = r * (xs[c] - t.mu[k][c]) * invs2;
-            t.g2[k] += r / (t.m[k] + 1e-12f);
+            t.g2[k] += r * rme[k];
         }
     }
     t.like = expf(t.ll_sum);

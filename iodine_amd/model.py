@@ -366,6 +366,8 @@ class IODINE(nn.Module):
             _lib.check(_lib.lib().iodine_set_option(self._handle, key.encode(), float(value)), self._handle)
         if key in ('conv_precision', 'conv_variant'):
             self._param_versions = None          # the library keeps only the selected path's weight packs: re-send the parameters
+        if key == 'wgrad_accum':
+            self._ws_key = None                  # the workspace plan depends on it: ask the library again
 
     def profile_read(self, category: str, reset: bool = True):
         """(total_ms, launches) of one kernel category measured with HIP events (set_option('profile', 2); level 1 brackets the

@@ -32,6 +32,8 @@ RUNS = {   # name: (family, K, T, B, steps, checkpoints, lr)
 # IODINE: sharpness logged every 50 steps, parameters kept at the checkpoints listed + the first step whose mean max-mask reaches 0.98
 LONG_RUNS = {   # name: (family, K, T, B, max steps, keep-at, lr, stop-at sharpness)
     'teacher_cfg1_long': ('dsprites', 4, 3, 4, 3000, (250, 500, 1000, 1500, 2000, 3000), 1e-3, 0.98),
+    # Round 5: the headline architecture (CLEVR6 shapes: 128 x 128, 64 channels, K = 7, T = 5), one image, 300 Adam steps
+    'teacher_cfg3_long': ('clevr', 7, 5, 1, 300, (100, 300), 1e-3, 0.98),
 }
 SEED_W, SEED_X, SEED_E = 11, 12, 1000
 
