@@ -201,8 +201,10 @@ hipError_t launch_dec_l0(hipStream_t st, const float* V, const float* cmap, floa
 // slot groups of the fused layer-0 reduction (each at most 32 slots); Dpart holds l0_dgroups(N) * P * C floats
 inline int l0_dgroups(int N) { const int g = (N + 31) / 32; return g < 8 ? 8 : g; }
 // several small device-to-device copies in ONE launch (iodine_set_params: biases and raw weight copies)
-constexpr int MCOPY_MAX = 24;
-struct MultiCopy { const float* src[MCOPY_MAX]; float* dst[MCOPY_MAX]; int n[MCOPY_MAX]; int count; };
+// (round 5: also the transposes [R][Cc] -> [Cc][R] (op 1, n = R * Cc, cols = Cc) and the sum of two vectors (op 2, src + src2) of the same
+// parameter update - one launch instead of seven)
+constexpr int MCOPY_MAX = 40;
+struct MultiCopy { const float* src[MCOPY_MAX]; const float* src2[MCOPY_MAX]; float* dst[MCOPY_MAX]; int n[MCOPY_MAX]; int op[MCOPY_MAX]; int cols[MCOPY_MAX]; int count; };
 hipError_t launch_multi_copy(hipStream_t st, const MultiCopy& mc);
 size_t l0_rows_scratch_floats(int N, int C);
 hipError_t launch_l0_reduce_cls_tiles(hipStream_t st, const float* rows_p, float* Rc, int N, int S, int C, float* scratch);
@@ -286,6 +288,8 @@ hipError_t launch_dec_out_stream_f16x3(hipStream_t st, const float* in, const vo
 hipError_t launch_pack_conv_weights_ws(hipStream_t st, const float* src, int C, int tflip, float* meta, void* dst);
 // kernels_pack.hip: the packs above for many tensors in two launches.  kind 0 = launch_pack_conv_weights_ws(src, C = p[0], tflip = p[1]),
 // kind 1 = launch_pack_conv_weights_f16(src, O = p[0], I = p[1], cin = p[2], cout = p[3], tflip = p[4]); meta / dst as there
+// round 5: kind 2 = launch_refine_l0_pack(src, O = p[0], cinw = p[1]), kind 3 = launch_pack_dec_out_gemm(src, C = p[0]),
+// kind 4 = launch_pack_dec_out_dgrad(src, C = p[0]) with the scale kind 3 of the same batch leaves in the shared meta (p[1] = 1: no scale of its own)
 constexpr int PACK_BATCH_MAX = 48;
 struct PackJob { const float* src; void* dst; float* meta; int kind; int p[5]; };
 hipError_t launch_pack_batch(hipStream_t st, const PackJob* jobs, int n);

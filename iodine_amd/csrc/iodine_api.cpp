@@ -1038,8 +1038,20 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
             if (e != hipSuccess) return e;
             mc.count = 0;
         }
-        mc.src[mc.count] = src; mc.dst[mc.count] = dst; mc.n[mc.count] = (int)count; ++mc.count;
+        mc.src[mc.count] = src; mc.src2[mc.count] = nullptr; mc.dst[mc.count] = dst; mc.n[mc.count] = (int)count; mc.op[mc.count] = 0;
+        mc.cols[mc.count] = 0; ++mc.count;
         return hipSuccess;
+    };
+    // (round 5) the head's transposes [R][Cc] -> [Cc][R] and the bias sum ride in the same launch as the plain copies
+    auto queue_transpose = [&](float* dst, const float* src, int R, int Cc) -> hipError_t {
+        const hipError_t e = queue_copy(dst, src, (size_t)R * Cc);
+        if (e == hipSuccess) { mc.op[mc.count - 1] = 1; mc.cols[mc.count - 1] = Cc; }
+        return e;
+    };
+    auto queue_add2 = [&](float* dst, const float* a, const float* b2, int count) -> hipError_t {
+        const hipError_t e = queue_copy(dst, a, (size_t)count);
+        if (e == hipSuccess) { mc.op[mc.count - 1] = 2; mc.src2[mc.count - 1] = b2; }
+        return e;
     };
     const int L = h->L, Cd = h->Cd, Cr = h->Cr, H = h->H;
     // split-fp16 packs (power-of-two scale + layout per tensor and direction) are collected and issued as two launches at the end
@@ -1095,11 +1107,14 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         }
         HIPCHK(h, queue_copy(h->dec_b[l], P("decoder.mlc.layers." + std::to_string(l) + ".bias"), Cd));
     }
-    HIPCHK(h, launch_pack_dec_out(st, P("decoder.conv.weight"), h->dec_out_w, Cd));
     HIPCHK(h, queue_copy(h->dec_out_b, P("decoder.conv.bias"), 4));
-    HIPCHK(h, launch_pack_conv_weights(st, P("decoder.conv.weight"), 4, Cd, 4, Cd, 1, h->dec_out_wb));
-    HIPCHK(h, launch_pack_dec_out_gemm(st, P("decoder.conv.weight"), Cd, h->dec_out_meta, h->dec_out_w16));
-    HIPCHK(h, launch_pack_dec_out_dgrad(st, P("decoder.conv.weight"), Cd, h->dec_out_meta, h->dec_out_wb16));   // same scale
+    if (h->precision == 0) {                                   // exact-fp32 forms of the output conv (conv_precision invalidates the params)
+        HIPCHK(h, launch_pack_dec_out(st, P("decoder.conv.weight"), h->dec_out_w, Cd));
+        HIPCHK(h, launch_pack_conv_weights(st, P("decoder.conv.weight"), 4, Cd, 4, Cd, 1, h->dec_out_wb));
+    }
+    // split-fp16 GEMM-form packs of the output conv, forward and data gradient (one scale): two more jobs of the batched pack
+    pj.push_back(PackJob{P("decoder.conv.weight"), h->dec_out_w16, h->dec_out_meta, 3, {Cd, 0, 0, 0, 0}});
+    pj.push_back(PackJob{P("decoder.conv.weight"), h->dec_out_wb16, h->dec_out_meta, 4, {Cd, 1, 0, 0, 0}});
     // refinement conv stack
     const bool ref_fp32 = h->precision == 0 || !refine_f16_ok(h);
     // first layer: the reference weight has n_in input channels (ARCH.ENCODING subset); the kernels see 17
@@ -1129,8 +1144,8 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         HIPCHK(h, pack_f16(h->ref_wk, Cr, 12, 16, Cr, 0, h->ref_wkmeta, h->ref_wk16));
         HIPCHK(h, pack_f16(h->ref_wsh, Cr, 8, 16, Cr, 0, h->ref_wshmeta, h->ref_wsh16));
         if (h->ref_l0k) {                                      // fused encoding + layer 0: both parts as K = 16 MFMA operands
-            HIPCHK(h, launch_refine_l0_pack(st, h->ref_wk, Cr, 12, h->ref_l0kmeta, h->ref_l0k));
-            HIPCHK(h, launch_refine_l0_pack(st, h->ref_wsh, Cr, 8, h->ref_l0smeta, h->ref_l0s));
+            pj.push_back(PackJob{h->ref_wk, h->ref_l0k, h->ref_l0kmeta, 2, {Cr, 12, 0, 0, 0}});
+            pj.push_back(PackJob{h->ref_wsh, h->ref_l0s, h->ref_l0smeta, 2, {Cr, 8, 0, 0, 0}});
         }
         if (Cr == 64)                                           // weight-stationary forward of layers 1 ..
             for (int l = 1; l < h->Dr; ++l)
@@ -1148,13 +1163,13 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     HIPCHK(h, copy_raw(h->raw_wm, "refine.mean_update.weight"));
     HIPCHK(h, copy_raw(h->raw_wv, "refine.logvar_update.weight"));
     // head
-    HIPCHK(h, launch_transpose(st, P("refine.mlp.layers.0.weight"), h->mlp_wT, H, Cr));
+    HIPCHK(h, queue_transpose(h->mlp_wT, P("refine.mlp.layers.0.weight"), H, Cr));
     HIPCHK(h, queue_copy(h->mlp_b, P("refine.mlp.layers.0.bias"), H));
-    HIPCHK(h, launch_transpose(st, P("refine.lstm.weight_ih"), h->wihT, 4 * H, H + 4 * L));
-    HIPCHK(h, launch_transpose(st, P("refine.lstm.weight_hh"), h->whhT, 4 * H, H));
-    HIPCHK(h, launch_add2(st, P("refine.lstm.bias_ih"), P("refine.lstm.bias_hh"), h->lstm_b, 4 * H));
-    HIPCHK(h, launch_transpose(st, P("refine.mean_update.weight"), h->wmT, L, H));
-    HIPCHK(h, launch_transpose(st, P("refine.logvar_update.weight"), h->wvT, L, H));
+    HIPCHK(h, queue_transpose(h->wihT, P("refine.lstm.weight_ih"), 4 * H, H + 4 * L));
+    HIPCHK(h, queue_transpose(h->whhT, P("refine.lstm.weight_hh"), 4 * H, H));
+    HIPCHK(h, queue_add2(h->lstm_b, P("refine.lstm.bias_ih"), P("refine.lstm.bias_hh"), 4 * H));
+    HIPCHK(h, queue_transpose(h->wmT, P("refine.mean_update.weight"), L, H));
+    HIPCHK(h, queue_transpose(h->wvT, P("refine.logvar_update.weight"), L, H));
     HIPCHK(h, queue_copy(h->bm, P("refine.mean_update.bias"), L));
     HIPCHK(h, queue_copy(h->bv, P("refine.logvar_update.bias"), L));
     HIPCHK(h, queue_copy(h->init_mean, P("posterior.init_mean"), L));

@@ -949,20 +949,9 @@ __global__ void pack_dec_out_gemm_kernel(const float* __restrict__ w /*[4][C][3]
                                          _Float16* __restrict__ dst)
 {
     const float scale = meta[0];
-    const int total = (C / 16) * 2 * 2 * 64 * 8;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int e = idx & 7;
-        int r = idx >> 3;
-        const int n = r & 63; r >>= 6;
-        const int kh = r & 1; r >>= 1;
-        const int term = r & 1; r >>= 1;
-        const int chunk = r;
-        const int ci = chunk * 16 + kh * 8 + e;
-        float v = 0.f;
-        if (n < 36) v = w[((size_t)(n & 3) * C + ci) * 9 + (n >> 2)] * scale;
-        const _Float16 hi = (_Float16)v;
-        dst[idx] = term == 0 ? hi : (_Float16)(v - (float)hi);
-    }
+    const int total = (int)pack_out_gemm_total(C);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
+        dst[idx] = pack_out_gemm_element(w, C, scale, (size_t)idx);          // (pack_bodies.h: shared with the batched form)
 }
 
 hipError_t launch_pack_dec_out_gemm(hipStream_t st, const float* w, int C, float* meta, void* dst)

@@ -912,7 +912,16 @@ __global__ void multi_copy_kernel(const MultiCopy mc)
     const int j = blockIdx.y;
     const float* __restrict__ src = mc.src[j];
     float* __restrict__ dst = mc.dst[j];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < mc.n[j]; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    const int op = mc.op[j], n = mc.n[j];
+    if (op == 1) {                                           // transpose [R][Cc] -> [Cc][R]
+        const int Cc = mc.cols[j], R = n / Cc;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[(size_t)(i % Cc) * R + i / Cc] = src[i];
+    } else if (op == 2) {
+        const float* __restrict__ s2 = mc.src2[j];
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i] + s2[i];
+    } else {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    }
 }
 
 hipError_t launch_multi_copy(hipStream_t st, const MultiCopy& mc)

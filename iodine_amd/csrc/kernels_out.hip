@@ -12,6 +12,7 @@
 // floor of ~0.17 ms.  Power-of-two scaling is per row-block (wave-local max over all C channels), so there is no
 // accumulator rescale either.  Arithmetic per accumulator: the same three f16 MFMAs per chunk in the same order.
 #include "common.h"
+#include "pack_bodies.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -224,20 +225,9 @@ __global__ void pack_dec_out_dgrad_kernel(const float* __restrict__ w /*[4][C][3
                                           _Float16* __restrict__ dst)
 {
     const float scale = meta[0];
-    const int total = 3 * 2 * 2 * C * 8;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int e = idx & 7;
-        int r = idx >> 3;
-        const int c = r % C; r /= C;
-        const int kh = r & 1; r >>= 1;
-        const int term = r & 1; r >>= 1;
-        const int chunk = r;
-        const int k = chunk * 16 + kh * 8 + e, tap = k >> 2, o = k & 3;
-        float v = 0.f;
-        if (tap < 9) v = w[((size_t)o * C + c) * 9 + (8 - tap)] * scale;
-        const _Float16 hi = (_Float16)v;
-        dst[idx] = term == 0 ? hi : (_Float16)(v - (float)hi);
-    }
+    const int total = (int)pack_out_dgrad_total(C);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
+        dst[idx] = pack_out_dgrad_element(w, C, scale, (size_t)idx);         // (pack_bodies.h: shared with the batched form)
 }
 
 hipError_t launch_pack_dec_out_dgrad(hipStream_t st, const float* w, int C, const float* meta, void* dst)

@@ -19,6 +19,7 @@
 // DESIGN.md 4.7 has the measurements and the forms tried on the way.
 #include "common.h"
 #include "pixel_terms.h"
+#include "pack_bodies.h"
 #include <utility>
 #include <vector>
 #include <cstdio>
@@ -40,14 +41,9 @@ constexpr int L0_PLB = L0_NPX * L0_PXB;                            // one plane:
 __global__ void l0_pack_weights_kernel(const float* __restrict__ w, int O, int CINW, const float* __restrict__ meta, _Float16* __restrict__ dst)
 {
     const float scale = meta[0];
-    const int total = (O / 16) * 9 * 2 * 64 * 4;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int j = idx & 3, lane = (idx >> 2) & 63, hl = (idx >> 8) & 1, tap = (idx >> 9) % 9, g = (idx >> 9) / 9;
-        const int co = 16 * g + (lane & 15), ci = 4 * (lane >> 4) + j;
-        const float v = ci < CINW ? w[((size_t)co * CINW + ci) * 9 + tap] * scale : 0.f;
-        const _Float16 hi = (_Float16)v;
-        dst[idx] = hl == 0 ? hi : (_Float16)(v - (float)hi);
-    }
+    const int total = (int)pack_l0_total(O);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
+        dst[idx] = pack_l0_element(w, CINW, scale, (size_t)idx);             // (pack_bodies.h: shared with the batched form)
 }
 
 __global__ __launch_bounds__(1024) void l0_weight_scale_kernel(const float* __restrict__ w, int n, float* __restrict__ meta)

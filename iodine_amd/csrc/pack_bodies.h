@@ -45,6 +45,49 @@ IOD_DEVINL _Float16 pack_f16_element(const float* __restrict__ src, int O, int I
 }
 IOD_DEVINL size_t pack_f16_total(int cin, int cout) { return (size_t)(cin / 16) * 9 * 2 * 2 * cout * 8; }
 
+// element idx of the fused first refinement layer's operand (kernels_refl0.hip): [O / 16][9 taps][hi / lo][64 lanes] x 4 fp16
+IOD_DEVINL _Float16 pack_l0_element(const float* __restrict__ w, int CINW, float scale, size_t idx)
+{
+    const int j = idx & 3, lane = (idx >> 2) & 63, hl = (idx >> 8) & 1, tap = (int)((idx >> 9) % 9), g = (int)((idx >> 9) / 9);
+    const int co = 16 * g + (lane & 15), ci = 4 * (lane >> 4) + j;
+    const float v = ci < CINW ? w[((size_t)co * CINW + ci) * 9 + tap] * scale : 0.f;
+    const _Float16 hi = (_Float16)v;
+    return hl == 0 ? hi : (_Float16)(v - (float)hi);
+}
+IOD_DEVINL size_t pack_l0_total(int O) { return (size_t)(O / 16) * 9 * 2 * 64 * 4; }
+
+// element idx of the output conv's GEMM-form operand (kernels_conv.hip: pack_dec_out_gemm_kernel)
+IOD_DEVINL _Float16 pack_out_gemm_element(const float* __restrict__ w, int C, float scale, size_t idx)
+{
+    const int e = idx & 7;
+    int r = (int)(idx >> 3);
+    const int n = r & 63; r >>= 6;
+    const int kh = r & 1; r >>= 1;
+    const int term = r & 1; r >>= 1;
+    const int ci = r * 16 + kh * 8 + e;
+    float v = 0.f;
+    if (n < 36) v = w[((size_t)(n & 3) * C + ci) * 9 + (n >> 2)] * scale;
+    const _Float16 hi = (_Float16)v;
+    return term == 0 ? hi : (_Float16)(v - (float)hi);
+}
+IOD_DEVINL size_t pack_out_gemm_total(int C) { return (size_t)(C / 16) * 2 * 2 * 64 * 8; }
+
+// element idx of the output conv's data-gradient operand (kernels_out.hip: pack_dec_out_dgrad_kernel)
+IOD_DEVINL _Float16 pack_out_dgrad_element(const float* __restrict__ w, int C, float scale, size_t idx)
+{
+    const int e = idx & 7;
+    int r = (int)(idx >> 3);
+    const int c = r % C; r /= C;
+    const int kh = r & 1; r >>= 1;
+    const int term = r & 1; r >>= 1;
+    const int k = r * 16 + kh * 8 + e, tap = k >> 2, o = k & 3;
+    float v = 0.f;
+    if (tap < 9) v = w[((size_t)o * C + c) * 9 + (8 - tap)] * scale;
+    const _Float16 hi = (_Float16)v;
+    return term == 0 ? hi : (_Float16)(v - (float)hi);
+}
+IOD_DEVINL size_t pack_out_dgrad_total(int C) { return (size_t)3 * 2 * 2 * C * 8; }
+
 // max |w| of a tensor (block of 1024 threads) -> meta[0] = power-of-two scale with max * scale in [2^12, 2^13), meta[1] = 1 / scale
 IOD_DEVINL void weight_scale_block(const float* __restrict__ w, int n, float* __restrict__ meta, float* s_red /*[16]*/)
 {
