@@ -202,6 +202,9 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * needs "stop_after_iters" >= 0 or this option 0; 0 = pixel_pass2 writes the encoding, two convs read it),
  * "head_mfma" (1 -- default: the LSTM gate pre-activations of the refinement head as one fp32-MFMA GEMM over all slots,
  * three launches; 0 = the one-launch head kernel),
+ * "dec_out_rows" (1 -- default: the output conv's forward runs as a row-streaming kernel -- a block walks a strip of image
+ * rows, every row of the [pixels x 36] product is computed once and kept in an LDS ring until the rows above and below are
+ * there -- for image sizes 32 / 64 / 128 on the split path; 0 = 16 x 16 tiles, each recomputing its 18 x 18 halo),
  * "wgrad_accum" (0 -- default: the partial weight-gradient tiles of a decoder launch are reduced right behind it; 1 = every block
  * keeps its partial tile over the T + 1 decoder passes of a training step (adds alpha_i x pass i; alpha_i = the pass's loss
  * weight) and the fixed-order reduction runs once per layer and step, 3 + 1 instead of 18 + 6 reductions per cfg3 step --
@@ -240,6 +243,11 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in_nhwc, const float*
                       int cout, int stride, int epi, int transpose_flip);
 int iodine_op_dec_out(void* stream, const float* in_nhwc, const float* w_oihw, const float* bias, float* out_nhwc4,
                       int n, int s, int c);
+/* the split-fp16 forms of the output conv C -> 4 (GEMM + 9-tap sum): variant 0 = 16 x 16 tiles with halo recompute
+ * (dec_out_stream_f16x3_kernel, per-cell max side buffer), 1 = row-streaming kernel without halo recompute
+ * (dec_out_rows_f16x3_kernel, s in {32, 64, 128}), 2 = the tiled kernel without a side buffer. */
+int iodine_op_dec_out_f16x3(void* stream, const float* in_nhwc, const float* w_oihw, const float* bias, float* out_nhwc4,
+                            int n, int s, int c, int variant);
 /* weight + bias gradient of a 3x3 conv (kernel-level tests): in_nhwc [n][s][s][ci_pad] (ci_real of them meaningful),
  * d_nhwc [n][so][so][co] with so = s (stride 1) or s/2 (stride 2); gw_oihw [co][ci_real][3][3] and gb [co] are
  * ACCUMULATED into.  Split-fp16 kernels (stride 1: decoder stack, stride 2: refinement stack). */

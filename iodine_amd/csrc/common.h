@@ -284,6 +284,11 @@ hipError_t launch_dec_out_dgrad_f16x3(hipStream_t st, const float* g, const void
 hipError_t launch_dec_out_stream_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta,
                                        const float* bias, float* out, int N, int S, int C, const float* tmax = nullptr);
 
+// row-streaming form of the same output conv (round 5: no halo recompute; S in {32, 64, 128}, needs the producer's cell maxima)
+bool dec_out_rows_ok(int S, int C, const float* tmax);
+hipError_t launch_dec_out_rows_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias, float* out,
+                                     int N, int S, int C, const float* tmax);
+
 // kernels_convws.hip: weight-stationary split-fp16 3x3 conv C -> C (weights in registers, persistent blocks)
 hipError_t launch_pack_conv_weights_ws(hipStream_t st, const float* src, int C, int tflip, float* meta, void* dst);
 // kernels_pack.hip: the packs above for many tensors in two launches.  kind 0 = launch_pack_conv_weights_ws(src, C = p[0], tflip = p[1]),

@@ -126,6 +126,7 @@ struct iodine_handle {
                                                            // process A/B): cfg3 48.197 vs 48.200 ms, cfg2 6.55 vs 6.53 ms - the read-modify-write of the
                                                            // partial tiles in the kernels' tails costs what the 20 saved reduce launches cost: NOT adopted,
                                                            // kept as an option (off: no extra workspace)
+    int dec_out_rows = 1;                                  // output conv forward: row-streaming kernel without halo recompute (S in {32, 64, 128}); 0 = 16 x 16 tiles
     int refine_ws = 1;                                     // forward stride-2 convs of refinement layers 1 .. on the weight-stationary kernel (kernels_refws.hip)
     std::vector<float*> ref_wsf, ref_wsf_meta;             // their weights in its register layout
     float *ref_w1ws = nullptr, *ref_w1ws_meta = nullptr;   // layer 1's weights in the register layout of the fused layer-1/0 backward
@@ -520,7 +521,10 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N, const float* z, flo
             PROF(h, st, "conv_tile_fwd", launch_conv3x3_tile(st, b.act[l - 1], h->dec_wf[l], h->dec_b[l], nullptr,
                                                              b.act[l], N, h->S, h->Cd, h->Cd, EPI_BIAS_ELU));
     }
-    if (h->precision == 1)
+    if (h->precision == 1 && h->dec_out_rows && ws && dec_out_rows_ok(h->S, h->Cd, b.tmax_act[h->Dd - 1]))
+        PROF(h, st, "dec_out", launch_dec_out_rows_f16x3(st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b, out, N, h->S, h->Cd,
+                                                         b.tmax_act[h->Dd - 1]));
+    else if (h->precision == 1)
         PROF(h, st, "dec_out", launch_dec_out_stream_f16x3(st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b, out, N, h->S,
                                                            h->Cd, ws ? b.tmax_act[h->Dd - 1] : nullptr));
     else
@@ -859,7 +863,7 @@ int run_graphed(iodine_handle* h, hipStream_t st, const std::vector<uintptr_t>& 
 std::vector<uintptr_t> graph_key(const iodine_handle* h, int entry, int batch, std::initializer_list<const void*> ptrs)
 {
     std::vector<uintptr_t> k = {(uintptr_t)entry, (uintptr_t)batch, (uintptr_t)h->stop_after, (uintptr_t)h->precision,
-                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)(h->head_fused | (h->refine_bwd_fused << 1) | (h->refine_ws << 2) | (h->refine_l0_fused << 3) | (h->head_mfma << 4) | (h->wgrad_accum << 5)),
+                                (uintptr_t)h->variant, (uintptr_t)h->fuse_l0, (uintptr_t)h->out_bwd_fused, (uintptr_t)h->refine_split, (uintptr_t)(h->head_fused | (h->refine_bwd_fused << 1) | (h->refine_ws << 2) | (h->refine_l0_fused << 3) | (h->head_mfma << 4) | (h->wgrad_accum << 5) | (h->dec_out_rows << 6)),
                                 (uintptr_t)(h->ws_user ? h->ws_user : h->ws_own)};
     for (const void* p : ptrs) k.push_back((uintptr_t)p);
     return k;
@@ -1220,6 +1224,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
     if (!strcmp(key, "head_mfma")) { h->head_mfma = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_l0_fused")) { h->refine_l0_fused = value != 0; return IODINE_OK; }
     if (!strcmp(key, "refine_ws")) { h->refine_ws = value != 0; return IODINE_OK; }
+    if (!strcmp(key, "dec_out_rows")) { h->dec_out_rows = value != 0; return IODINE_OK; }
     if (!strcmp(key, "wgrad_accum")) {
         if (h->wgrad_accum != (value != 0)) { h->buf = Buffers(); h->fwd_done = false; h->last_elbo_iter = -1; h->enc_valid = false; }   // the arena is re-planned
         h->wgrad_accum = value != 0; return IODINE_OK;
@@ -1839,6 +1844,26 @@ int iodine_op_dec_out(void* stream, const float* in, const float* w, const float
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(wk);
     if (e != hipSuccess) { g_create_error = std::string("iodine_op_dec_out: ") + hipGetErrorString(e); return IODINE_ERR_HIP; }
+    return IODINE_OK;
+}
+
+int iodine_op_dec_out_f16x3(void* stream, const float* in, const float* w, const float* bias, float* out, int n, int s, int c, int variant)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const size_t wb = (size_t)(c / 16) * 2 * 2 * 64 * 16, tf = conv_ws_tmax_floats(n, s);
+    char* buf = nullptr;
+    if (s % 16 != 0 || (c != 64 && c != 32)) { g_create_error = "iodine_op_dec_out_f16x3: shape"; return IODINE_ERR_INVALID; }
+    if (hipMalloc((void**)&buf, wb + 64 + tf * sizeof(float)) != hipSuccess) return IODINE_ERR_HIP;
+    float* meta = (float*)(buf + wb);
+    float* tin = (float*)(buf + wb + 64);
+    hipError_t e = launch_pack_dec_out_gemm(st, w, c, meta, buf);
+    if (e == hipSuccess) e = launch_cell_max(st, in, tin, n, s, c);
+    if (e == hipSuccess)
+        e = variant == 1 ? launch_dec_out_rows_f16x3(st, in, buf, meta, bias, out, n, s, c, tin)
+                         : launch_dec_out_stream_f16x3(st, in, buf, meta, bias, out, n, s, c, variant == 2 ? nullptr : tin);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    if (e != hipSuccess) { g_create_error = std::string("iodine_op_dec_out_f16x3: ") + hipGetErrorString(e); return IODINE_ERR_HIP; }
     return IODINE_OK;
 }
 

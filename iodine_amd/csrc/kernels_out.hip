@@ -212,6 +212,208 @@ hipError_t launch_dec_out_stream_f16x3(hipStream_t st, const float* in, const vo
 }
 
 // =========================================================================================
+// Round 5: the same GEMM + 9-tap sum WITHOUT the halo recompute.  The tiled kernel above evaluates P for the 18 x 18 halo of every
+// 16 x 16 tile (11 row-blocks of 32 pixels for 8 row-blocks of output: 1.375x the loads, splits and MFMAs) and is VALU-issue-bound on
+// exactly that work.  Here a persistent block walks a strip of image rows top to bottom: a STEP is 128 consecutive pixels of the strip
+// (one 32-pixel row-block per wave; 128 / S rows), its P values go into a ring of four step slots in LDS (4 x 18 KB), and as soon as
+// step j is complete (ONE barrier per step) the outputs of step j - 1 - which need the rows above and below, i.e. steps j - 2 .. j - are
+// summed and stored.  Every P row is computed once; a strip of R rows costs R + 2 (128 / S) rows of work (3.6 % at cfg3: 56-row strips).
+// Loads are two steps ahead in three register sets (16 KB in flight per wave, 128 KB per CU); the 64 weight fragment registers are
+// filled straight from global memory once per block, so LDS holds only the ring (two blocks per CU).  The power-of-two scale of a
+// row-block comes from the producer's cell maxima of the two 8 x 16 cells it lies in (tmax, fetched with the row-block) and P is
+// stored in true units.  S in {32, 64, 128}; other sizes use the tiled kernel.
+template <int C>
+__global__ __launch_bounds__(256, 2)
+void dec_out_rows_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
+                               const float* __restrict__ bias, float* __restrict__ out, int S, int rows_total, int rpb, int nblk,
+                               const float* __restrict__ tmax)
+{
+    constexpr int NCHUNK = C / 16;
+    constexpr int PSTR = 36;                                        // floats per pixel of P: (tap, co)
+    constexpr int NLD = NCHUNK * 2;                                 // float4 loads per lane and row-block
+    constexpr int SLOT = 128 * PSTR;                                // floats per ring slot (one step)
+    extern __shared__ __attribute__((aligned(16))) float s_ring[];  // [4][128][PSTR]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, kh = lane >> 5, li = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int SPR = 128 / S;                                        // rows per step
+    // XCD-aware: block b runs on XCD b % 8; every XCD gets one contiguous eighth of the row ranges (neighbours share a halo row in L2)
+    const int per_xcd = (nblk + 7) >> 3;
+    const int vb = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (vb >= nblk) return;
+    const int r0 = vb * rpb, r1 = min(rows_total, r0 + rpb);
+
+    // weight fragments -> registers (loop-invariant): lane (li, kh), column tile nt, chunk c, hi / lo
+    f16x8 wh[NCHUNK][2], wl[NCHUNK][2];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const uint4 a = wpk[((c * 2 + 0) * 2 + kh) * 64 + nt * 32 + li], b = wpk[((c * 2 + 1) * 2 + kh) * 64 + nt * 32 + li];
+            __builtin_memcpy(&wh[c][nt], &a, 16); __builtin_memcpy(&wl[c][nt], &b, 16);
+        }
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) asm volatile("" : "+v"(wh[c][nt]), "+v"(wl[c][nt]));
+    float inv_ws = wmeta[1];
+    float2 b2 = make_float2(bias[2 * (tid & 1)], bias[2 * (tid & 1) + 1]);            // this thread's channel pair of the output
+    // (pinned here: hipcc's own wait for these two loads would otherwise be a vmcnt(0) at their first use INSIDE the pipelined loop)
+    asm volatile("" : "+v"(inv_ws), "+v"(b2.x), "+v"(b2.y));
+
+    f32x4 v0[NLD], v1[NLD], v2[NLD];
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    i32x4_ rsrc;
+    const int tcx = S >> 4, tcy = S >> 3;                           // cells per row / column of the side buffer
+
+    for (int ra = r0; ra < r1;) {
+        // ---- sub-strip [ya, yb) of image n (a block's row range is cut at image boundaries) ----
+        const int n = ra / S, ya = ra - n * S;
+        const int yb = min(S, ya + (r1 - ra));
+        ra += yb - ya;
+        const int G = (yb - ya) / SPR, J = G + 2;                   // output groups, P steps (one group of rows above, one below)
+        {
+            const unsigned long long p = (unsigned long long)(in + (size_t)n * S * S * C);
+            rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+            rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+            rsrc.z = __builtin_amdgcn_readfirstlane(S * S * C * 4);
+            rsrc.w = 0x00020000;
+        }
+        const int ystart = ya - SPR;                                // image row of pixel 0 of step 0 (may be negative: zeros)
+        // loads of (step j, this wave's row-block) + the two cell maxima its scale comes from: NLD + 1 memory operations
+        auto issue = [&](int j, f32x4 (&v)[NLD], float& tm) {
+            const int q0 = j * 128 + 32 * wv;                       // first pixel of the row-block (wave-uniform)
+            const int row = ystart + q0 / S, x = q0 % S + li;
+            const bool ok = row >= 0 && row < S;
+            const unsigned off = ok ? (unsigned)(((row * S + x) * C + kh * 8) * 4) : 0x80000000u;
+            const int crow = min(max(row, 0), S - 1) >> 3, ccol = (q0 % S) >> 4;
+            const float* tp = tmax + (((size_t)n * tcy + crow) * tcx + ccol) * 4 + (lane & 7);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(tm) : "v"(tp) : "memory");
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c) {
+                const int soff = c * 64;
+                asm volatile("s_nop 4" :: "s"(rsrc), "s"(soff) : "memory");
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v[2 * c]) : "v"(off), "s"(rsrc), "s"(soff) : "memory");
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(v[2 * c + 1]) : "v"(off), "s"(rsrc), "s"(soff) : "memory");
+            }
+        };
+        // P of (step j, this wave's row-block) -> ring slot j & 3
+        auto process = [&](int j, f32x4 (&v)[NLD], float& tm) {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) asm volatile("" : "+v"(v[k]));
+            asm volatile("" : "+v"(tm));
+            __builtin_amdgcn_sched_barrier(0);
+            const float scale = tile_scale(wave_max_f32(lane < 8 ? tm : 0.f), 1.f);
+            f32x16 acc[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c) {
+                const f32x4 a = v[2 * c] * scale, b = v[2 * c + 1] * scale;
+                unsigned l0, l1, l2, l3;
+                const unsigned h0 = pack_hi_lo(a.x, a.y, l0), h1 = pack_hi_lo(a.z, a.w, l1);
+                const unsigned h2 = pack_hi_lo(b.x, b.y, l2), h3 = pack_hi_lo(b.z, b.w, l3);
+                const u32x4_ uh = {h0, h1, h2, h3}, ul = {l0, l1, l2, l3};
+                f16x8 ah, al;
+                __builtin_memcpy(&ah, &uh, 16); __builtin_memcpy(&al, &ul, 16);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[c][nt], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[c][nt], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[c][nt], acc[nt], 0, 0, 0);
+                }
+            }
+            const float inv = inv_ws / scale;
+            // accumulator register r of lane (li, kh) is pixel (r & 3) + 8 (r >> 2) + 4 kh of the row-block, column li (+ 32: columns 32 .. 35)
+            float* pb = s_ring + (j & 3) * SLOT + (32 * wv + 4 * kh) * PSTR + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pb[((r & 3) + 8 * (r >> 2)) * PSTR] = acc[0][r] * inv;
+            if (li < 4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pb[((r & 3) + 8 * (r >> 2)) * PSTR + 32] = acc[1][r] * inv;
+            }
+        };
+        // outputs of group g (its pixels are those of P step g + 1): thread = (pixel tid / 2, channel pair tid & 1)
+        auto emit = [&](int g) {
+            const int i = tid >> 1, cp = tid & 1;
+            const int y = ya + g * SPR + i / S, x = i % S;
+            const int q = (g + 1) * 128 + i;
+            float2 o = b2;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                if ((unsigned)(x + dx) < (unsigned)S) {
+                    const int qq = q + dy * S + dx;
+                    const float2 pv = *reinterpret_cast<const float2*>(s_ring + ((qq >> 7) & 3) * SLOT + (qq & 127) * PSTR + tap * 4 + cp * 2);
+                    o.x += pv.x; o.y += pv.y;
+                }
+            }
+            float2* op = reinterpret_cast<float2*>(out + (((size_t)n * S + y) * S + x) * 4 + cp * 2);
+            asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" :: "v"(op), "v"(o) : "memory");
+        };
+        // ---- software pipeline: loads two steps ahead (three register sets), one barrier per step ----
+        // vmcnt is in order: behind the loads of step j sit [store of emit(j - 4)] [loads j + 1] [store of emit(j - 3)] [loads j + 2];
+        // the stores do not exist in the first steps of a strip, so the counts below allow for the two younger load groups only
+        // (at worst an old 8-byte store is waited for as well)
+        auto stepf = [&](int j, f32x4 (&cur)[NLD], float& tcur, f32x4 (&nx2)[NLD], float& tnx2) {
+            if (j + 2 < J) {
+                issue(j + 2, nx2, tnx2);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (NLD + 1)) : "memory");
+            } else if (j + 1 < J) {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD + 1) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            process(j, cur, tcur);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS-only barrier: the prefetch stays in flight
+            if (j >= 2) emit(j - 2);
+        };
+        issue(0, v0, t0);
+        issue(1, v1, t1);
+        int j = 0;
+        for (; j + 2 < J; j += 3) {
+            stepf(j, v0, t0, v2, t2);
+            stepf(j + 1, v1, t1, v0, t0);
+            stepf(j + 2, v2, t2, v1, t1);
+        }
+        if (j < J) { stepf(j, v0, t0, v2, t2); ++j; }
+        if (j < J) { stepf(j, v1, t1, v0, t0); ++j; }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // the ring is free for the next sub-strip
+    }
+}
+
+bool dec_out_rows_ok(int S, int C, const float* tmax) { return tmax && (S == 32 || S == 64 || S == 128) && (C == 64 || C == 32); }
+
+hipError_t launch_dec_out_rows_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias, float* out,
+                                     int N, int S, int C, const float* tmax)
+{
+    IOD_XSKIP(128);
+    if (!dec_out_rows_ok(S, C, tmax)) return hipErrorInvalidValue;
+    int n_cu = 0;
+    if (hipError_t e = iod_cu_count(&n_cu); e != hipSuccess) return e;
+    const int spr = 128 / S, rows_total = N * S;
+    const int want = 2 * n_cu;                                      // two resident blocks per CU (72 KB of LDS each)
+    int rpb = (rows_total + want - 1) / want;
+    rpb = (rpb + spr - 1) / spr * spr;
+    const int nblk = (rows_total + rpb - 1) / rpb;
+    const int grid = ((nblk + 7) / 8) * 8;
+    constexpr size_t lds = (size_t)4 * 128 * 36 * 4;
+#define DO_ROWS(CC)                                                                                                                     \
+    {                                                                                                                                   \
+        static std::atomic<unsigned> attr_devs{0};                                                                                      \
+        if (hipError_t e = iod_set_max_lds((const void*)dec_out_rows_f16x3_kernel<CC>, (int)lds, attr_devs); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((dec_out_rows_f16x3_kernel<CC>), dim3(grid), dim3(256), lds, st, in, reinterpret_cast<const uint4*>(wpk),    \
+                           wmeta, bias, out, S, rows_total, rpb, nblk, tmax);                                                           \
+    }
+    if (C == 64) DO_ROWS(64) else DO_ROWS(32)
+#undef DO_ROWS
+    return hipGetLastError();
+}
+
+// =========================================================================================
 // Data gradient of the output conv (4 -> C channels, times ELU' of the saved activation): the first kernel of every
 // decoder backward pass.  out[p][c] = ELU'(aux[p][c]) * sum_{tap, o} g[p + tap - 1][o] * W[o][c][8 - tap]: a
 // [pixels x 36] . [36 x C] GEMM (K = tap*4 + o, padded to 48) whose A operand comes from the 4-channel gradient of the

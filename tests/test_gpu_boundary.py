@@ -212,7 +212,7 @@ def test_hip_graph_replay_is_bit_identical(case):
     m.set_option('graph', 0)
 
 
-OPTIONS = [('conv_precision', 0), ('conv_variant', 1), ('out_bwd_fused', 0), ('fuse_l0', 0), ('refine_split', 0), ('head_fused', 0), ('refine_bwd_fused', 0), ('refine_ws', 0), ('refine_l0_fused', 0), ('head_mfma', 0), ('wgrad_accum', 1), ('graph', 1)]
+OPTIONS = [('conv_precision', 0), ('conv_variant', 1), ('out_bwd_fused', 0), ('fuse_l0', 0), ('refine_split', 0), ('head_fused', 0), ('refine_bwd_fused', 0), ('refine_ws', 0), ('refine_l0_fused', 0), ('head_mfma', 0), ('wgrad_accum', 1), ('dec_out_rows', 0), ('graph', 1)]
 
 
 @pytest.mark.parametrize('case', ['cfg1_dsprites_k4_t3_b4', 'cfg3_clevr_k7_t5_b1'])

@@ -87,6 +87,37 @@ def test_dec_out_conv(C_, S, N):
     assert rel_err(out.cpu(), ref) < 2e-6
 
 
+@pytest.mark.parametrize('variant', [0, 1, 2], ids=['tiles', 'rows', 'tiles_no_side_buffer'])
+@pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 64, 5), (64, 128, 2), (32, 128, 3), (64, 64, 37), (32, 32, 70)])
+def test_dec_out_conv_split_fp16(C_, S, N, variant):
+    """the split-fp16 output conv (GEMM + 9-tap sum): the tiled kernel and the round-5 row-streaming kernel (no halo recompute, LDS ring of
+    four steps, strips cut at image boundaries: N = 37 / 70 give blocks whose row range spans two images) against ATen in fp64; the rows
+    are given very different ranges so that a wrong per-row-block scale would show"""
+    x = _rand(N, C_, S, S, seed=13)
+    if variant == 1:
+        x[:, :, S // 2:] *= 1e-3                                 # lower half of every image 1000x smaller: the row-streaming kernel scales per
+                                                                 # row-block (the tiled kernels per tile incl. its halo: tile-relative precision)
+    x[N // 2:] *= 50.0
+    w = _rand(4, C_, 3, 3, seed=14, scale=0.1)
+    b = _rand(4, seed=15, scale=1e-5 if variant == 1 else 1.0)   # (a bias of order 1 would hide the small rows behind its own fp32 rounding)
+    ref = nhwc(F.conv2d(x.double(), w.double(), b.double(), padding=1)).float()
+    L = _lib.lib()
+    xs, ws, bs = nhwc(x).to(DEV).contiguous(), w.to(DEV), b.to(DEV)
+    outs = []
+    for _ in range(2):
+        out = torch.full(ref.shape, float('nan'), device=DEV)
+        _lib.check(L.iodine_op_dec_out_f16x3(None, _lib.ptr(xs), _lib.ptr(ws), _lib.ptr(bs), _lib.ptr(out), N, S, C_, variant), None,
+                   'iodine_op_dec_out_f16x3')
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])                         # deterministic
+    for sl in (slice(0, N // 2), slice(N // 2, N)):
+        for rows in (slice(0, S // 2 - 1), slice(S // 2 + 1, S)):
+            got, want = outs[0][sl, rows], ref[sl, rows]
+            assert rel_err(got - bs.cpu(), want - bs.cpu()) < 3e-6, (variant, rel_err(got - bs.cpu(), want - bs.cpu()))
+    assert rel_err(outs[0], ref) < 3e-6
+
+
 @pytest.mark.parametrize('mode', [2])
 @pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 2), (64, 128, 1), (64, 16, 300), (32, 32, 70)])
 def test_conv_tile_f16x3_forward_and_dgrad(C_, S, N, mode):
