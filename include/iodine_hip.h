@@ -245,7 +245,8 @@ int iodine_op_dec_out(void* stream, const float* in_nhwc, const float* w_oihw, c
                       int n, int s, int c);
 /* the split-fp16 forms of the output conv C -> 4 (GEMM + 9-tap sum): variant 0 = 16 x 16 tiles with halo recompute
  * (dec_out_stream_f16x3_kernel, per-cell max side buffer), 1 = row-streaming kernel without halo recompute
- * (dec_out_rows_f16x3_kernel, s in {32, 64, 128}), 2 = the tiled kernel without a side buffer. */
+ * (dec_out_rows_f16x3_kernel, s in {32, 64, 128}), 2 = the tiled kernel without a side buffer, 3 = the row-streaming kernel on
+ * exact fp32 MFMA (conv_precision 0). */
 int iodine_op_dec_out_f16x3(void* stream, const float* in_nhwc, const float* w_oihw, const float* bias, float* out_nhwc4,
                             int n, int s, int c, int variant);
 /* weight + bias gradient of a 3x3 conv (kernel-level tests): in_nhwc [n][s][s][ci_pad] (ci_real of them meaningful),
@@ -255,7 +256,8 @@ int iodine_op_conv3x3_wgrad(void* stream, const float* in_nhwc, const float* d_n
                             int s, int ci_pad, int ci_real, int co, int stride);
 
 /* the same for the stride-1 conv c -> c (c = 32 / 64) on the exact-fp32 path (conv_precision 0): persistent, prefetched
- * v_mfma_f32_32x32x2_f32 kernel (kernels_wgrad32.hip); gw_oihw / gb are ACCUMULATED into. */
+ * v_mfma_f32_32x32x2_f32 kernel (kernels_wgrad32.hip); gw_oihw / gb are ACCUMULATED into.  c < 0: the output conv |c| -> 4 in
+ * GEMM form (d_nhwc has 4 channels, gw_oihw [4][|c|][3][3], gb [4]). */
 int iodine_op_conv3x3_wgrad_f32(void* stream, const float* in_nhwc, const float* d_nhwc, float* gw_oihw, float* gb, int n,
                                 int s, int c);
 

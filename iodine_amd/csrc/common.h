@@ -286,8 +286,10 @@ hipError_t launch_dec_out_stream_f16x3(hipStream_t st, const float* in, const vo
 
 // row-streaming form of the same output conv (round 5: no halo recompute; S in {32, 64, 128}, needs the producer's cell maxima)
 bool dec_out_rows_ok(int S, int C, const float* tmax);
+// f32 = 1: exact fp32 MFMA form (wpk = launch_pack_dec_out_rows32, wmeta / tmax unused)
 hipError_t launch_dec_out_rows_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias, float* out,
-                                     int N, int S, int C, const float* tmax);
+                                     int N, int S, int C, const float* tmax, int f32 = 0);
+hipError_t launch_pack_dec_out_rows32(hipStream_t st, const float* w, int C, float* dst);
 
 // kernels_convws.hip: weight-stationary split-fp16 3x3 conv C -> C (weights in registers, persistent blocks)
 hipError_t launch_pack_conv_weights_ws(hipStream_t st, const float* src, int C, int tflip, float* meta, void* dst);
@@ -309,6 +311,9 @@ hipError_t launch_conv3x3_ws_f32(hipStream_t st, const float* in, const void* wp
 // kernels_wgrad32.hip: exact-fp32 weight gradient, persistent + prefetched (part: [nparts][9][c][c], part_b: [nbias_parts][c])
 hipError_t launch_conv3x3_wgrad_f32_ws(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N, int S, int c,
                                        int* nparts, int* ncop, int* nbias_parts, float alpha = 1.f, int accum = 0);
+// exact-fp32 weight gradient of the output conv c -> 4 in GEMM form (part: [nparts][9][c][4], part_b: [nbias_parts][4])
+hipError_t launch_dec_out_wgrad_f32(hipStream_t st, const float* a, const float* g, float* part, float* part_b, int N, int S, int c,
+                                    int* nparts, int* nbias_parts);
 inline size_t conv_ws_wpk_bytes(int C) { return (size_t)(C / 16) * (C / 32) * 9 * 2 * 64 * 16; }
 inline size_t conv_ws_tmax_floats(int N, int S) { return (size_t)N * (S / 16) * (S / 8) * 4; }
 

@@ -105,6 +105,7 @@ struct iodine_handle {
     bool fwd_split = false;                     // the form the saved training forward used
     int variant = 6;                            // split-fp16 stride-1 conv: 6 = weight-stationary persistent kernel (power-of-two image sizes;
                                                 // other sizes use 1), 1 = LDS-tiled 16x16 tiles (2 blocks/CU)
+    float* dec_out_w32 = nullptr;               // fp32 operand of the row-streaming output conv (conv_precision 0)
     float *dec_out_w = nullptr, *dec_out_b = nullptr, *dec_out_wb = nullptr, *dec_out_w16 = nullptr, *dec_out_meta = nullptr,
           *dec_out_wb16 = nullptr;               // split-fp16 pack of the output conv for its data gradient
     std::vector<float*> ref_w, ref_b;
@@ -527,6 +528,8 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N, const float* z, flo
     else if (h->precision == 1)
         PROF(h, st, "dec_out", launch_dec_out_stream_f16x3(st, b.act[h->Dd - 1], h->dec_out_w16, h->dec_out_meta, h->dec_out_b, out, N, h->S,
                                                            h->Cd, ws ? b.tmax_act[h->Dd - 1] : nullptr));
+    else if (h->dec_out_rows && dec_out_rows_ok(h->S, h->Cd, b.act[h->Dd - 1]) && h->dec_out_w32)      // exact fp32 MFMA, row-streaming
+        PROF(h, st, "dec_out", launch_dec_out_rows_f16x3(st, b.act[h->Dd - 1], h->dec_out_w32, nullptr, h->dec_out_b, out, N, h->S, h->Cd, nullptr, 1));
     else
         PROF(h, st, "dec_out", launch_dec_out(st, b.act[h->Dd - 1], h->dec_out_w, h->dec_out_b, out, N, h->S, h->Cd));
     return IODINE_OK;
@@ -625,6 +628,10 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         if (h->precision == 1) {                           // GEMM form: rows (tap, co), no N = 4 -> 32 padding
             PROF(h, st, "dec_out_wgrad", launch_dec_out_wgrad_gemm_f16x3(st, b.act[Dd - 1], b.g, b.wg_part, b.wg_part_b, N, h->S,
                                                                           Cd, &nparts, &nb));
+            HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, Cd, 4, 4, Cd, Cd, train_alpha, h->gacc[wi], b.wg_fold,
+                                          b.wg_part_b, nb, h->gacc[bi]));
+        } else if (conv_ws32_ok(h)) {                      // exact fp32, GEMM form (kernels_wgrad32.hip)
+            PROF(h, st, "dec_out_wgrad", launch_dec_out_wgrad_f32(st, b.act[Dd - 1], b.g, b.wg_part, b.wg_part_b, N, h->S, Cd, &nparts, &nb));
             HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, Cd, 4, 4, Cd, Cd, train_alpha, h->gacc[wi], b.wg_fold,
                                           b.wg_part_b, nb, h->gacc[bi]));
         } else {
@@ -930,6 +937,7 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
         ALLOC(h->dec_wmeta[l], (size_t)4);
     }
     ALLOC(h->dec_out_w, (size_t)9 * Cd * 4);
+    if (Cd == 64 || Cd == 32) ALLOC(h->dec_out_w32, (size_t)2 * (Cd / 2) * 64);
     ALLOC(h->dec_out_b, (size_t)4);
     ALLOC(h->dec_out_wb, conv_wpk_elems(4, Cd) * 4);
     ALLOC(h->dec_out_w16, (size_t)(Cd / 16) * 2 * 2 * 64 * 4);            // GEMM-form pack: [chunk][hi/lo][kh][64][8 fp16]
@@ -1115,6 +1123,7 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     if (h->precision == 0) {                                   // exact-fp32 forms of the output conv (conv_precision invalidates the params)
         HIPCHK(h, launch_pack_dec_out(st, P("decoder.conv.weight"), h->dec_out_w, Cd));
         HIPCHK(h, launch_pack_conv_weights(st, P("decoder.conv.weight"), 4, Cd, 4, Cd, 1, h->dec_out_wb));
+        if (h->dec_out_w32) HIPCHK(h, launch_pack_dec_out_rows32(st, P("decoder.conv.weight"), Cd, h->dec_out_w32));
     }
     // split-fp16 GEMM-form packs of the output conv, forward and data gradient (one scale): two more jobs of the batched pack
     pj.push_back(PackJob{P("decoder.conv.weight"), h->dec_out_w16, h->dec_out_meta, 3, {Cd, 0, 0, 0, 0}});
@@ -1858,7 +1867,10 @@ int iodine_op_dec_out_f16x3(void* stream, const float* in, const float* w, const
     float* tin = (float*)(buf + wb + 64);
     hipError_t e = launch_pack_dec_out_gemm(st, w, c, meta, buf);
     if (e == hipSuccess) e = launch_cell_max(st, in, tin, n, s, c);
-    if (e == hipSuccess)
+    if (e == hipSuccess && variant == 3) {          // exact-fp32 row-streaming form: its own weight operand (the buffer is large enough)
+        e = launch_pack_dec_out_rows32(st, w, c, (float*)buf);
+        if (e == hipSuccess) e = launch_dec_out_rows_f16x3(st, in, buf, nullptr, bias, out, n, s, c, nullptr, 1);
+    } else if (e == hipSuccess)
         e = variant == 1 ? launch_dec_out_rows_f16x3(st, in, buf, meta, bias, out, n, s, c, tin)
                          : launch_dec_out_stream_f16x3(st, in, buf, meta, bias, out, n, s, c, variant == 2 ? nullptr : tin);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1904,9 +1916,17 @@ int iodine_op_conv3x3_wgrad_f32(void* stream, const float* in, const float* d, f
     if (hipMalloc((void**)&buf, (part_elems + fold_elems + (size_t)512 * 64) * sizeof(float)) != hipSuccess) return IODINE_ERR_HIP;
     float *part = buf, *fold = buf + part_elems, *part_b = fold + fold_elems;
     int nparts = 0, cop = 0, nb = 0;
-    hipError_t e = launch_conv3x3_wgrad_f32_ws(st, in, d, part, part_b, n, s, c, &nparts, &cop, &nb);
+    hipError_t e;
+    if (c < 0) {                                    // the output conv |c| -> 4 in GEMM form (d has 4 channels; gw [4][|c|][3][3], gb [4])
+        c = -c;
+        e = launch_dec_out_wgrad_f32(st, in, d, part, part_b, n, s, c, &nparts, &nb);
+        if (e == hipSuccess) e = launch_wgrad_reduce(st, part, nparts, c, 4, 4, c, c, 1.f, gw, fold);
+        if (e == hipSuccess) e = launch_colsum(st, part_b, nb, 4, 4, 1.f, gb);
+    } else {
+    e = launch_conv3x3_wgrad_f32_ws(st, in, d, part, part_b, n, s, c, &nparts, &cop, &nb);
     if (e == hipSuccess) e = launch_wgrad_reduce(st, part, nparts, c, cop, c, c, c, 1.f, gw, fold);
     if (e == hipSuccess) e = launch_colsum(st, part_b, nb, c, c, 1.f, gb);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(buf);
     if (e != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3_wgrad_f32: ") + hipGetErrorString(e); return IODINE_ERR_HIP; }

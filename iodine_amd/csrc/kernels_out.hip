@@ -222,7 +222,10 @@ hipError_t launch_dec_out_stream_f16x3(hipStream_t st, const float* in, const vo
 // filled straight from global memory once per block, so LDS holds only the ring (two blocks per CU).  The power-of-two scale of a
 // row-block comes from the producer's cell maxima of the two 8 x 16 cells it lies in (tmax, fetched with the row-block) and P is
 // stored in true units.  S in {32, 64, 128}; other sizes use the tiled kernel.
-template <int C>
+// F32 (conv_precision 0): the same pipeline on exact fp32 MFMA - v_mfma_f32_32x32x2_f32, C / 2 k-steps of (2 channels: one per half
+// wave) x 2 column tiles, weights as 64 fp32 registers per lane, no scales / side buffer (replaces the round-1 VALU kernel dec_out_kernel:
+// 1.25 ms per cfg3 launch).
+template <int C, bool F32 = false>
 __global__ __launch_bounds__(256, 2)
 void dec_out_rows_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
                                const float* __restrict__ bias, float* __restrict__ out, int S, int rows_total, int rpb, int nblk,
@@ -245,7 +248,20 @@ void dec_out_rows_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     const int r0 = vb * rpb, r1 = min(rows_total, r0 + rpb);
 
     // weight fragments -> registers (loop-invariant): lane (li, kh), column tile nt, chunk c, hi / lo
-    f16x8 wh[NCHUNK][2], wl[NCHUNK][2];
+    constexpr int NOPS = NLD + (F32 ? 0 : 1);                      // memory operations per issue(): the row-block (+ its cell maxima)
+    f16x8 wh[F32 ? 1 : NCHUNK][2], wl[F32 ? 1 : NCHUNK][2];
+    float wf[F32 ? C / 2 : 1][2];                                  // F32: B operand of k-step s, column tile nt (pack_dec_out_rows32_kernel)
+    if constexpr (F32) {
+        const float* wp = reinterpret_cast<const float*>(wpk);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < C / 2; ++ks) wf[ks][nt] = wp[(nt * (C / 2) + ks) * 64 + lane];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < C / 2; ++ks) asm volatile("" : "+v"(wf[ks][nt]));
+    } else {
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
@@ -257,7 +273,9 @@ void dec_out_rows_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) asm volatile("" : "+v"(wh[c][nt]), "+v"(wl[c][nt]));
-    float inv_ws = wmeta[1];
+    }
+    float inv_ws = 1.f;
+    if constexpr (!F32) inv_ws = wmeta[1];
     float2 b2 = make_float2(bias[2 * (tid & 1)], bias[2 * (tid & 1) + 1]);            // this thread's channel pair of the output
     // (pinned here: hipcc's own wait for these two loads would otherwise be a vmcnt(0) at their first use INSIDE the pipelined loop)
     asm volatile("" : "+v"(inv_ws), "+v"(b2.x), "+v"(b2.y));
@@ -288,8 +306,10 @@ void dec_out_rows_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             const bool ok = row >= 0 && row < S;
             const unsigned off = ok ? (unsigned)(((row * S + x) * C + kh * 8) * 4) : 0x80000000u;
             const int crow = min(max(row, 0), S - 1) >> 3, ccol = (q0 % S) >> 4;
-            const float* tp = tmax + (((size_t)n * tcy + crow) * tcx + ccol) * 4 + (lane & 7);
-            asm volatile("global_load_dword %0, %1, off" : "=v"(tm) : "v"(tp) : "memory");
+            if constexpr (!F32) {
+                const float* tp = tmax + (((size_t)n * tcy + crow) * tcx + ccol) * 4 + (lane & 7);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(tm) : "v"(tp) : "memory");
+            }
 #pragma unroll
             for (int c = 0; c < NCHUNK; ++c) {
                 const int soff = c * 64;
@@ -304,12 +324,21 @@ void dec_out_rows_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             for (int k = 0; k < NLD; ++k) asm volatile("" : "+v"(v[k]));
             asm volatile("" : "+v"(tm));
             __builtin_amdgcn_sched_barrier(0);
-            const float scale = tile_scale(wave_max_f32(lane < 8 ? tm : 0.f), 1.f);
+            float scale = 1.f;
+            if constexpr (!F32) scale = tile_scale(wave_max_f32(lane < 8 ? tm : 0.f), 1.f);
             f32x16 acc[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            if constexpr (F32) {
+                // k-step ks: this lane's channel 16 (ks / 8) + 8 kh + ks % 8 = element ks of its NLD float4 (the loads' own order)
+#pragma unroll
+                for (int ks = 0; ks < C / 2; ++ks)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[ks / 4][ks % 4], wf[ks][nt], acc[nt], 0, 0, 0);
+            } else
 #pragma unroll
             for (int c = 0; c < NCHUNK; ++c) {
                 const f32x4 a = v[2 * c] * scale, b = v[2 * c + 1] * scale;
@@ -361,9 +390,9 @@ void dec_out_rows_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
         auto stepf = [&](int j, f32x4 (&cur)[NLD], float& tcur, f32x4 (&nx2)[NLD], float& tnx2) {
             if (j + 2 < J) {
                 issue(j + 2, nx2, tnx2);
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (NLD + 1)) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NOPS) : "memory");
             } else if (j + 1 < J) {
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD + 1) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NOPS) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -387,11 +416,29 @@ void dec_out_rows_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 
 bool dec_out_rows_ok(int S, int C, const float* tmax) { return tmax && (S == 32 || S == 64 || S == 128) && (C == 64 || C == 32); }
 
+// fp32 weights of the F32 form: dst[(nt * (C / 2) + ks) * 64 + lane] = W[column nt * 32 + lane % 32 (= tap * 4 + co, zero from 36)][channel of
+// (k-step ks, half wave lane / 32) = 16 (ks / 8) + 8 (lane / 32) + ks % 8]
+__global__ void pack_dec_out_rows32_kernel(const float* __restrict__ w /*[4][C][3][3]*/, int C, float* __restrict__ dst)
+{
+    const int total = 2 * (C / 2) * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, ks = (idx >> 6) % (C / 2), nt = (idx >> 6) / (C / 2);
+        const int j = nt * 32 + (lane & 31), ci = 16 * (ks / 8) + 8 * (lane >> 5) + ks % 8;
+        dst[idx] = j < 36 ? w[((size_t)(j & 3) * C + ci) * 9 + (j >> 2)] : 0.f;
+    }
+}
+
+hipError_t launch_pack_dec_out_rows32(hipStream_t st, const float* w, int C, float* dst)
+{
+    hipLaunchKernelGGL(pack_dec_out_rows32_kernel, dim3(C / 2), dim3(128), 0, st, w, C, dst);
+    return hipGetLastError();
+}
+
 hipError_t launch_dec_out_rows_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias, float* out,
-                                     int N, int S, int C, const float* tmax)
+                                     int N, int S, int C, const float* tmax, int f32)
 {
     IOD_XSKIP(128);
-    if (!dec_out_rows_ok(S, C, tmax)) return hipErrorInvalidValue;
+    if (!dec_out_rows_ok(S, C, f32 ? in : tmax)) return hipErrorInvalidValue;      // (the fp32 form needs no side buffer)
     int n_cu = 0;
     if (hipError_t e = iod_cu_count(&n_cu); e != hipSuccess) return e;
     const int spr = 128 / S, rows_total = N * S;
@@ -401,14 +448,15 @@ hipError_t launch_dec_out_rows_f16x3(hipStream_t st, const float* in, const void
     const int nblk = (rows_total + rpb - 1) / rpb;
     const int grid = ((nblk + 7) / 8) * 8;
     constexpr size_t lds = (size_t)4 * 128 * 36 * 4;
-#define DO_ROWS(CC)                                                                                                                     \
-    {                                                                                                                                   \
-        static std::atomic<unsigned> attr_devs{0};                                                                                      \
-        if (hipError_t e = iod_set_max_lds((const void*)dec_out_rows_f16x3_kernel<CC>, (int)lds, attr_devs); e != hipSuccess) return e; \
-        hipLaunchKernelGGL((dec_out_rows_f16x3_kernel<CC>), dim3(grid), dim3(256), lds, st, in, reinterpret_cast<const uint4*>(wpk),    \
-                           wmeta, bias, out, S, rows_total, rpb, nblk, tmax);                                                           \
+#define DO_ROWS(CC, FF)                                                                                                                     \
+    {                                                                                                                                       \
+        static std::atomic<unsigned> attr_devs{0};                                                                                          \
+        if (hipError_t e = iod_set_max_lds((const void*)dec_out_rows_f16x3_kernel<CC, FF>, (int)lds, attr_devs); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((dec_out_rows_f16x3_kernel<CC, FF>), dim3(grid), dim3(256), lds, st, in, reinterpret_cast<const uint4*>(wpk),    \
+                           wmeta, bias, out, S, rows_total, rpb, nblk, tmax);                                                               \
     }
-    if (C == 64) DO_ROWS(64) else DO_ROWS(32)
+    if (C == 64) { if (f32) DO_ROWS(64, true) else DO_ROWS(64, false) }
+    else { if (f32) DO_ROWS(32, true) else DO_ROWS(32, false) }
 #undef DO_ROWS
     return hipGetLastError();
 }

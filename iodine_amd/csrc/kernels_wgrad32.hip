@@ -246,3 +246,174 @@ hipError_t launch_conv3x3_wgrad_f32_ws(hipStream_t st, const float* a, const flo
     if (c == 32) return launch_wgrad_f32_ws_inst<32>(st, a, d, part, part_b, N, S, nparts, ncop, nbias_parts, alpha, accum);
     return hipErrorInvalidValue;
 }
+
+// =========================================================================================
+// Exact-fp32 weight gradient of the OUTPUT conv C -> 4 (conv_precision 0) in GEMM form:
+//     dW[tap][ci][co] = sum_q a[q][ci] * g[q - (tap - centre)][co]          rows ci, columns j = tap * 4 + co (36 of 64), K = pixels
+// - the tap shift is moved onto the 4-channel gradient g (a 6 x 18 halo tile of float4, 1.7 KB), the 64-channel operand needs no halo
+// and is read exactly once: 4 MFMAs (v_mfma_f32_32x32x2_f32) per pixel pair and block where the direct form with N = 4 padded to 32
+// (conv3x3_wgrad_tile_kernel<C, 4>, round 1) issues 18 - 1.29 ms per cfg3 launch for 0.94 GB of input.  Same persistent / prefetched
+// structure as conv3x3_wgrad_f32_ws_kernel above; partial tiles part[block * KS + ks][tap][ci][4], part_b[block][4].
+// =========================================================================================
+template <int C>
+__global__ __launch_bounds__(256, 4)
+void dec_out_wgrad_f32_kernel(const float* __restrict__ a, const float* __restrict__ g, float* __restrict__ part, float* __restrict__ part_b,
+                              int S, int ntiles)
+{
+    constexpr int MT = C / 32, KS = 2 / MT;              // waves = MT (ci halves) x 2 (column tiles) x KS (pixel split)
+    constexpr int TH = 4, TW = 16, HW = TW + 2, NHALO = (TH + 2) * HW, NPXT = TH * TW;
+    constexpr int Q = C / 4, NA = NPXT * Q / 256, PSTEP = 256 / Q;
+    constexpr int PLANE_A = NPXT * 128;
+    constexpr int STEPS = NPXT / KS / 2;
+    static_assert(C == 64 || C == 32, "channel counts of the shipped decoders");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ow[];
+    unsigned char* s_a = smem_ow;                                      // [MT][64 px][32] floats
+    float* s_g = reinterpret_cast<float*>(smem_ow + MT * PLANE_A);     // [NHALO][4] floats
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, half = lane >> 5, li = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mi = wv % MT, nt = (wv / MT) & 1, ks = wv / (MT * 2);
+
+    auto make_rsrc = [&](const void* base, unsigned bytes) {
+        const unsigned long long p = (unsigned long long)base;
+        i32x4w_ r;
+        r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+        r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+        r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+        r.w = 0x00020000;
+        return r;
+    };
+#define OW_BLOAD4(dst, voff, rsrc, soff) \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory")
+
+    const int nblk = gridDim.x;
+    const int xcd = blockIdx.x & 7, bix = blockIdx.x >> 3, bpx = (nblk + 7) >> 3;
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int t_begin = xcd * per_xcd, t_end = min(ntiles, t_begin + per_xcd);
+    const int tiles_x = S / TW, tiles_y = S / TH;
+
+    // staging roles: a - float4 q4 of pixel p0 + PSTEP k (row (PSTEP / 16) k + p0 / 16, column p0 % 16); g - thread < NHALO: one halo pixel
+    const int q4 = tid % Q, p0 = tid / Q;
+    const unsigned lw_a = (unsigned)((q4 >> 3) * PLANE_A + (q4 & 7) * 16);
+    const unsigned rel_a = (unsigned)((((p0 / TW) * S + p0 % TW) * C + q4 * 4) * 4);
+    const int a_kstride = (PSTEP / TW) * S * C * 4;
+    const int ghy = tid / HW, ghx = tid - ghy * HW;
+    const bool g_role = tid < NHALO;
+    const bool g_inner = g_role && ghy >= 1 && ghy <= TH && ghx >= 1 && ghx <= TW;
+    const unsigned gmask = (unsigned)((ghy == 0 ? 1 : 0) | (ghy == TH + 1 ? 2 : 0) | (ghx == 0 ? 4 : 0) | (ghx == HW - 1 ? 8 : 0));
+    const unsigned rel_g = g_role ? (unsigned)((ghy * S + ghx) * 16) : 0xC0000000u;
+
+    f32x4 ra[NA], rg;
+    auto issue_tile = [&](int t) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+        const i32x4w_ rs_a = make_rsrc(a + (size_t)n * S * S * C, (unsigned)(S * S * C * 4));
+        const i32x4w_ rs_g = make_rsrc(g + (size_t)n * S * S * 4, (unsigned)(S * S * 16));
+        const unsigned tb = (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == tiles_x - 1 ? 8u : 0u);
+        const unsigned oa = rel_a + (unsigned)((((ty * TH) * S + tx * TW) * C) * 4);
+        const unsigned og = (gmask & tb) ? 0x80000000u : rel_g + (unsigned)(((ty * TH - 1) * S + tx * TW - 1) * 16);
+        asm volatile("s_nop 4" :: "s"(rs_a) : "memory");
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int soff = k * a_kstride;
+            asm volatile("s_nop 4" :: "s"(soff) : "memory");
+            OW_BLOAD4(ra[k], oa, rs_a, soff);
+        }
+        asm volatile("s_nop 4" :: "s"(rs_g) : "memory");
+        OW_BLOAD4(rg, og, rs_g, 0);
+    };
+    f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto land_tile = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < NA; ++k) asm volatile("" : "+v"(ra[k]));
+        asm volatile("" : "+v"(rg));
+#pragma unroll
+        for (int k = 0; k < NA; ++k) *reinterpret_cast<f32x4*>(s_a + lw_a + (unsigned)(p0 + PSTEP * k) * 128) = ra[k];
+        if (g_role) *reinterpret_cast<f32x4*>(s_g + tid * 4) = rg;
+        if (g_inner) bsum += rg;
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // B operand of this lane: column j = nt * 32 + li = tap * 4 + co (zero from 36): g[(row + 2 - dy, col + 2 - dx)][co] of the halo tile
+    const int j = nt * 32 + li;
+    const bool jok = j < 36;
+    const int tap = jok ? j >> 2 : 0, co = j & 3;
+    const float* gp = s_g + ((2 - tap / 3) * HW + (2 - tap % 3) + half) * 4 + co + (ks * (TH / KS) * HW) * 4;
+    const float* ap = reinterpret_cast<const float*>(s_a + mi * PLANE_A) + (ks * (NPXT / KS) + half) * 32 + li;
+
+    const int t0 = t_begin + bix;
+    if (t0 < t_end) {
+        issue_tile(t0);
+        land_tile();
+        __syncthreads();
+        for (int t = t0; t < t_end; t += bpx) {
+            const bool has_next = t + bpx < t_end;
+            if (has_next) issue_tile(t + bpx);
+            w32_static_for<0, STEPS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int r = (2 * s) / TW, c = (2 * s) % TW;
+                const float aval = ap[(2 * s) * 32];
+                float bval = gp[(r * HW + c) * 4];
+                bval = jok ? bval : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bval, acc, 0, 0, 0);
+            });
+            if (has_next) {
+                __syncthreads();
+                land_tile();
+                __syncthreads();
+            }
+        }
+    }
+    // partial dW: accumulator rows = ci, columns = j -> part[(tap * C + ci) * 4 + co]
+    if (jok) {
+        float* pw = part + (size_t)(blockIdx.x * KS + ks) * 9 * C * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            pw[((size_t)tap * C + ci) * 4 + co] = acc[r];
+        }
+    }
+    __syncthreads();
+    f32x4* s_red = reinterpret_cast<f32x4*>(smem_ow);
+    s_red[tid] = bsum;
+    __syncthreads();
+    if (tid == 0) {
+        f32x4 t4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NHALO; ++q) t4 += s_red[q];
+        *reinterpret_cast<f32x4*>(part_b + (size_t)blockIdx.x * 4) = t4;
+    }
+#undef OW_BLOAD4
+}
+
+template <int C>
+static hipError_t launch_dec_out_wgrad_f32_inst(hipStream_t st, const float* a, const float* g, float* part, float* part_b, int N, int S,
+                                                int* nparts, int* nbias_parts)
+{
+    constexpr int KS = 2 / (C / 32);
+    constexpr size_t lds = (size_t)(C / 32) * 64 * 128 + (size_t)6 * 18 * 16;
+    int n_cu = 0;
+    if (hipError_t e = iod_cu_count(&n_cu); e != hipSuccess) return e;
+    const int ntiles = N * (S / 4) * (S / 16);
+    const int per_xcd = (ntiles + 7) / 8;
+    const int bpx = std::min(per_xcd, std::max(1, 4 * n_cu / 8));       // four persistent blocks per CU
+    const int blocks = std::min(8 * bpx, 1024);                         // (capacity of the partial-tile buffers)
+    hipLaunchKernelGGL((dec_out_wgrad_f32_kernel<C>), dim3(blocks), dim3(256), lds, st, a, g, part, part_b, S, ntiles);
+    *nparts = blocks * KS;
+    *nbias_parts = blocks;
+    return hipGetLastError();
+}
+
+// a: NHWC [N][S][S][c], g: [N][S][S][4]; part: [nparts][9][c][4], part_b: [nbias_parts][4]
+hipError_t launch_dec_out_wgrad_f32(hipStream_t st, const float* a, const float* g, float* part, float* part_b, int N, int S, int c,
+                                    int* nparts, int* nbias_parts)
+{
+    if (S % 16 != 0 || (size_t)S * S * c * 4 >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    if (c == 64) return launch_dec_out_wgrad_f32_inst<64>(st, a, g, part, part_b, N, S, nparts, nbias_parts);
+    if (c == 32) return launch_dec_out_wgrad_f32_inst<32>(st, a, g, part, part_b, N, S, nparts, nbias_parts);
+    return hipErrorInvalidValue;
+}

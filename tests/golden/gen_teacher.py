@@ -34,7 +34,7 @@ LONG_RUNS = {   # name: (family, K, T, B, max steps, keep-at, lr, stop-at sharpn
     'teacher_cfg1_long': ('dsprites', 4, 3, 4, 3000, (250, 500, 1000, 1500, 2000, 3000), 1e-3, 0.98),
     # Round 5: the headline architecture (CLEVR6 shapes: 128 x 128, 64 channels, K = 7, T = 5), one image, 300 Adam steps
     # (no early stop: this run reaches a mean max-mask of 0.99 by ITSELF at step 93 - binary masks without any sharpening - and is kept going)
-    'teacher_cfg3_long': ('clevr', 7, 5, 1, 300, (100, 200, 300), 1e-3, 2.0),
+    'teacher_cfg3_long': ('clevr', 7, 5, 1, 300, (300,), 1e-3, 2.0),
 }
 SEED_W, SEED_X, SEED_E = 11, 12, 1000
 

@@ -87,19 +87,19 @@ def test_dec_out_conv(C_, S, N):
     assert rel_err(out.cpu(), ref) < 2e-6
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2], ids=['tiles', 'rows', 'tiles_no_side_buffer'])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3], ids=['tiles', 'rows', 'tiles_no_side_buffer', 'rows_exact_fp32'])
 @pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 64, 5), (64, 128, 2), (32, 128, 3), (64, 64, 37), (32, 32, 70)])
 def test_dec_out_conv_split_fp16(C_, S, N, variant):
     """the split-fp16 output conv (GEMM + 9-tap sum): the tiled kernel and the round-5 row-streaming kernel (no halo recompute, LDS ring of
     four steps, strips cut at image boundaries: N = 37 / 70 give blocks whose row range spans two images) against ATen in fp64; the rows
     are given very different ranges so that a wrong per-row-block scale would show"""
     x = _rand(N, C_, S, S, seed=13)
-    if variant == 1:
+    if variant in (1, 3):
         x[:, :, S // 2:] *= 1e-3                                 # lower half of every image 1000x smaller: the row-streaming kernel scales per
                                                                  # row-block (the tiled kernels per tile incl. its halo: tile-relative precision)
     x[N // 2:] *= 50.0
     w = _rand(4, C_, 3, 3, seed=14, scale=0.1)
-    b = _rand(4, seed=15, scale=1e-5 if variant == 1 else 1.0)   # (a bias of order 1 would hide the small rows behind its own fp32 rounding)
+    b = _rand(4, seed=15, scale=1e-5 if variant in (1, 3) else 1.0)   # (a bias of order 1 would hide the small rows behind its own fp32 rounding)
     ref = nhwc(F.conv2d(x.double(), w.double(), b.double(), padding=1)).float()
     L = _lib.lib()
     xs, ws, bs = nhwc(x).to(DEV).contiguous(), w.to(DEV), b.to(DEV)
@@ -220,6 +220,29 @@ def test_conv_wgrad_exact_fp32(C_, S, N):
         gw = torch.zeros(C_, C_, 3, 3, device=DEV)
         gb = torch.zeros(C_, device=DEV)
         _lib.check(L.iodine_op_conv3x3_wgrad_f32(None, _lib.ptr(xs), _lib.ptr(ds), _lib.ptr(gw), _lib.ptr(gb), N, S, C_), None,
+                   'iodine_op_conv3x3_wgrad_f32')
+        torch.cuda.synchronize()
+        res.append((gw.cpu(), gb.cpu()))
+    assert rel_err(res[0][0], w.grad.float()) < 2e-6, rel_err(res[0][0], w.grad.float())
+    assert rel_err(res[0][1], b.grad.float()) < 2e-6, rel_err(res[0][1], b.grad.float())
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 5), (64, 128, 2), (32, 64, 3), (64, 16, 300)])
+def test_dec_out_wgrad_exact_fp32(C_, S, N):
+    """exact-fp32 weight / bias gradient of the output conv C -> 4 in GEMM form (dec_out_wgrad_f32_kernel) vs autograd in fp64"""
+    x = _rand(N, C_, S, S, seed=50).double()
+    d = _rand(N, 4, S, S, seed=51, scale=1e-2).double()
+    w = torch.zeros(4, C_, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(4, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x, w, b, padding=1) * d).sum().backward()
+    L = _lib.lib()
+    xs, ds = nhwc(x.float()).to(DEV).contiguous(), nhwc(d.float()).to(DEV).contiguous()
+    res = []
+    for _ in range(2):
+        gw = torch.zeros(4, C_, 3, 3, device=DEV)
+        gb = torch.zeros(4, device=DEV)
+        _lib.check(L.iodine_op_conv3x3_wgrad_f32(None, _lib.ptr(xs), _lib.ptr(ds), _lib.ptr(gw), _lib.ptr(gb), N, S, -C_), None,
                    'iodine_op_conv3x3_wgrad_f32')
         torch.cuda.synchronize()
         res.append((gw.cpu(), gb.cpu()))
