@@ -196,7 +196,9 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
     // + 16 in wl: element j is the A operand of the j-th v_mfma_f32_16x16x4_f32 over the fragment's 16 bytes)
     using wreg_t = std::conditional_t<F32, f32x4, f16x8>;
     wreg_t wh[NCHUNK][9], wl[NCHUNK][9];
-    {
+    // (round 5: filled in the prologue BEHIND the first stage's input loads, so that the block pays one exposed memory round trip at its
+    // start instead of two - at 64 x 64 images a block has only 8 - 12 tiles to amortise its prologue over)
+    auto load_weights = [&]() {
         const uint4* wp = wpk + (size_t)cg * NCHUNK * 9 * 2 * 64 + lane;
 #pragma unroll
         for (int c = 0; c < NCHUNK; ++c)
@@ -210,7 +212,7 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
         for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
             for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(wh[c][t]), "+v"(wl[c][t]));      // opaque: stay in registers
-    }
+    };
     float inv_w = 1.f;
     if constexpr (!F32) inv_w = wmeta[1];
     // (training row-sum form) step of torch.linspace(-1, 1, S), wave-uniform: computed once, kept in a scalar register
@@ -428,6 +430,7 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
     TP_DECL;
     // ---- prologue: stage 0 into buffer 0, stage 1 in flight ----
     issue_stage(0);
+    load_weights();                                          // (its own wait covers the stage-0 loads too: one round trip for both)
     vm_wait(integral_constant<int, 0>{});
     float cur_scale = 1.f;
     if constexpr (!F32) cur_scale = fresh_scale(wave_max_f32(lane < 36 ? tmv : 0.f));
