@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-HELPERS = (('dec_out_stream_f16x3_kernel', 'dec_out'), ('dec_out_bwd_fused_f16x3_kernel', 'dec_out_bwd'), ('dec_l0_cells_kernel', 'dec_l0'),
+HELPERS = (('dec_out_stream_f16x3_kernel', 'dec_out'), ('dec_out_rows_f16x3_kernel', 'dec_out'), ('dec_out_bwd_fused_f16x3_kernel', 'dec_out_bwd'), ('dec_l0_cells_kernel', 'dec_l0'),
            ('dec_out_dgrad_f16x3_kernel', 'dec_out_dgrad'), ('pixel_pass1_kernel', 'pixel_pass1'), ('pixel_pass2_kernel', 'pixel_pass2'),
            ('l0_rows_reduce_kernel', 'l0_reduce'), ('refine_head', 'refine_head'), ('conv3x3_s2_wgrad_f16x3_kernel', 'refine_wgrad'),
            ('refine_bwd01_kernel', 'refine_bwd01'), ('conv3x3_s2ws_f16x3_kernel', 'refine_conv'), ('refine_l0_fused_kernel', 'refine_l0f'))
@@ -82,7 +82,7 @@ def clocks(outdir, tag):
 
 def main():
     outdir = sys.argv[1]
-    tag = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith('-') else 'r03'
+    tag = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith('-') else 'r05'
     cfg = 'dsprites' if 'dsprites' in sys.argv[2:] else 'clevr6'
     from iodine_amd.build import source_digest
     # the GPU box has no .git: the commit is handed over in the environment (tools/round_profiles.sh, IODINE_COMMIT=$(git rev-parse HEAD))

@@ -6,7 +6,7 @@
 # Writes gpurun_out/pmc_<tag>/{FETCH_SIZE,WRITE_SIZE,SQ_VALU_MFMA_BUSY_CYCLES}/..., gpurun_out/<tag>_pmc.json (tools/pmc_to_json.py)
 # and gpurun_out/<tag>_kernel_traffic.md (tools/pmc_all_kernels.py); copy both to profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r05}
 shift || true
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Everything the round's measured record is made of, in one GPU-box call (run from the repo root through gpurun):
-#   IODINE_COMMIT=$(git rev-parse HEAD) gpurun -- "IODINE_COMMIT=$IODINE_COMMIT bash tools/round_profiles.sh r04"
+#   IODINE_COMMIT=$(git rev-parse HEAD) gpurun -- "IODINE_COMMIT=$IODINE_COMMIT bash tools/round_profiles.sh r05"
 #                                         -> gpurun_out/<tag>_*  (copy what should be judged into profiles/)
 # (the GPU box has no .git: the commit recorded in <tag>_pmc.json / roofline.traffic_source comes from IODINE_COMMIT)
-TAG=${1:-r04}
+TAG=${1:-r05}
 export IODINE_COMMIT=${IODINE_COMMIT:-unknown}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
@@ -25,6 +25,12 @@ for mode in train infer; do
   rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_$mode -- python $REPO/bench.py --mode $mode --steps 10 --warmup 2 --no-cpu-baseline --no-exact-fp32 --no-extra-configs --no-sustain > $OUT/${TAG}_prof_$mode.log 2>&1
   python $REPO/tools/rocpd_summary.py $(ls $OUT/${TAG}_prof_$mode/*/*.db | head -1) > $OUT/${TAG}_${mode}_kernel_stats.md
 done
+python $REPO/tools/step_timeline.py $(ls $OUT/${TAG}_prof_train/*/*.db | head -1) > $OUT/${TAG}_step_timeline.md 2>&1
+# the strict path (conv_precision 0: exact fp32 MFMA everywhere) as the headline line + its kernel trace
+python $REPO/bench.py --conv-precision 0 --steps 8 --warmup 2 --no-cpu-baseline --no-extra-configs --no-sustain > $OUT/${TAG}_bench_exact_fp32.json 2> /dev/null
+rm -rf $OUT/${TAG}_prof_fp32
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_fp32 -- python $REPO/bench.py --conv-precision 0 --steps 4 --warmup 1 --no-cpu-baseline --no-extra-configs --no-sustain > $OUT/${TAG}_prof_fp32.log 2>&1
+python $REPO/tools/rocpd_summary.py $(ls $OUT/${TAG}_prof_fp32/*/*.db | head -1) > $OUT/${TAG}_exact_fp32_train_kernel_stats.md
 # the per-GPU shard of BASELINE configs[4] (CLEVR-full shapes: K = 11, T = 7, 8 images per GPU)
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_cfg5 -- python $REPO/bench.py --slots 11 --iters 7 --batch 8 --steps 10 --warmup 2 --no-cpu-baseline --no-exact-fp32 --no-extra-configs --no-sustain > $OUT/${TAG}_prof_cfg5.log 2>&1
 python $REPO/tools/rocpd_summary.py $(ls $OUT/${TAG}_prof_cfg5/*/*.db | head -1) > $OUT/${TAG}_cfg5shard_train_kernel_stats.md
