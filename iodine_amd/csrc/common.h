@@ -343,7 +343,8 @@ hipError_t launch_gen_conv_dgrad(hipStream_t st, const float* dout, const float*
 size_t gen_wgrad_scratch_floats(int Ci, int Co, int k);
 hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* dout, float* scratch, int N, int Si, int Ci, int ldc,
                                  int Ci_dst, int Co, int k, int s, float alpha, float* gw, float* gb);
-hipError_t launch_gen_sum_pixels(hipStream_t st, const float* src, int N, int P, int C, int ld, int ldo, float* out);
+constexpr int GEN_SUM_SLICES = 64;    // pixel slices of launch_gen_sum_pixels (scratch: N * GEN_SUM_SLICES * C floats)
+hipError_t launch_gen_sum_pixels(hipStream_t st, const float* src, int N, int P, int C, int ld, int ldo, float* out, float* scratch);
 hipError_t launch_gen_identity(hipStream_t st, float* m, int rows, int L);
 hipError_t launch_ref_unsplit_grad(hipStream_t st, const float* g20, int O, float* gw);
 hipError_t launch_enc_join(hipStream_t st, const float* enck, const float* encs, float* enc, int N, int K, int P);

@@ -62,6 +62,7 @@ struct Buffers {               // workspace carve-up for one batch size / mode
     float* carry_c[2] = {nullptr, nullptr};
     std::vector<float*> rdpre;                 // gradient wrt refinement pre-activations, per layer
     float *bc = nullptr, *dbc = nullptr, *gen_scr = nullptr;   // generic path: materialised broadcast input, its gradient, wgrad partials
+    float* gen_sum = nullptr;                                   // generic decoder: pixel-slice partial sums of the broadcast input's gradient
 };
 
 }  // namespace
@@ -139,7 +140,9 @@ struct iodine_handle {
     float *ref_w17 = nullptr, *ref_g17 = nullptr;          // [Cr][17][kr * kr]
     // GENERIC fallback path (kernels_generic.hip): KERNEL_SIZE other than 3 or CONV_CHAN other than 32 / 64.  Weights re-packed to
     // [tap][ci][co]; the broadcast layer is materialised; nothing of the tuned conv kernels runs.
-    bool generic = false;
+    bool generic = false;                                  // the DECODER runs on the generic path
+    bool gen_ref = false;                                  // the REFINEMENT conv stack runs on the generic path (round 5: decided separately -
+                                                           // the reference's default ARCH has REF.KERNEL_SIZE 3 / 32 channels beside DEC.KERNEL_SIZE 5)
     int kd = 3, kr = 3;                                    // DEC / REF kernel sizes
     std::vector<float*> gen_wdec, gen_wref;                // [layer]: packed weights
     float *gen_wout = nullptr, *gen_b0 = nullptr, *gen_ident = nullptr;   // output conv pack, bias of decoder layer 0, [9 Cd][L] identity
@@ -441,11 +444,13 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
     if (h->generic) {
         b.bc = a.take<float>((size_t)N * P * (L + 2));
         b.dbc = a.take<float>((size_t)N * P * (L + 2));
-        if (mode == 1) {
-            size_t scr = std::max(gen_wgrad_scratch_floats(L + 2, Cd, h->kd), gen_wgrad_scratch_floats(Cd, Cd, h->kd));
-            scr = std::max(scr, std::max(gen_wgrad_scratch_floats(17, Cr, h->kr), gen_wgrad_scratch_floats(Cr, Cr, h->kr)));
-            b.gen_scr = a.take<float>(scr);
-        }
+        b.gen_sum = a.take<float>((size_t)N * GEN_SUM_SLICES * L);
+    }
+    if ((h->generic || h->gen_ref) && mode == 1) {
+        size_t scr = 0;
+        if (h->generic) scr = std::max(gen_wgrad_scratch_floats(L + 2, Cd, h->kd), gen_wgrad_scratch_floats(Cd, Cd, h->kd));
+        if (h->gen_ref) scr = std::max(scr, std::max(gen_wgrad_scratch_floats(17, Cr, h->kr), gen_wgrad_scratch_floats(Cr, Cr, h->kr)));
+        b.gen_scr = a.take<float>(scr);
     }
     b.bytes = (a.off + 255) & ~(size_t)255;
 }
@@ -578,7 +583,7 @@ int decoder_backward_generic(iodine_handle* h, hipStream_t st, int N, float trai
         }
     }
     HIPCHK(h, hipMemsetAsync(b.Rc, 0, sizeof(float) * (size_t)N * 9 * Cd, st));
-    HIPCHK(h, launch_gen_sum_pixels(st, b.dbc, N, h->P, L, L + 2, 9 * Cd, b.Rc));
+    HIPCHK(h, launch_gen_sum_pixels(st, b.dbc, N, h->P, L, L + 2, 9 * Cd, b.Rc, b.gen_sum));
     return IODINE_OK;
 }
 
@@ -750,7 +755,7 @@ bool refine_split_on(const iodine_handle* h);
 
 bool refine_f16_ok(const iodine_handle* h)
 {
-    if (h->generic || (h->Cr != 64 && h->Cr != 32)) return false;
+    if (h->gen_ref || (h->Cr != 64 && h->Cr != 32)) return false;
     int s = h->S;
     for (int l = 0; l < h->Dr; ++l) { if (s % 2 != 0) return false; s /= 2; }
     return true;
@@ -780,7 +785,7 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
     int s = h->S;
     const float* in = b.enc[i];
     for (int l = 0; l < h->Dr; ++l) {
-        if (h->generic) {
+        if (h->gen_ref) {
             PROF(h, st, "gen_conv", launch_gen_conv_fwd(st, in, h->gen_wref[l], h->ref_b[l], b.ract[i][l], N, s, l == 0 ? 17 : h->Cr,
                                                         l == 0 ? 20 : h->Cr, h->Cr, h->kr, 2, 1));
         } else if (l == 0 && l0f) {
@@ -896,7 +901,8 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     h->Cd = cfg->dec_conv_chan; h->Dd = cfg->dec_conv_layers; h->Cr = cfg->ref_conv_chan; h->Dr = cfg->ref_conv_layers;
     h->H = cfg->ref_mlp_units;
     h->kd = cfg->dec_kernel_size; h->kr = cfg->ref_kernel_size;
-    h->generic = h->kd != 3 || h->kr != 3 || (h->Cd != 32 && h->Cd != 64) || (h->Cr != 32 && h->Cr != 64) || h->S % 16 != 0;
+    h->generic = h->kd != 3 || (h->Cd != 32 && h->Cd != 64) || h->S % 16 != 0;
+    h->gen_ref = h->kr != 3 || (h->Cr != 32 && h->Cr != 64) || h->S % 16 != 0;
     {
         // image-shaped entries in CODE order (iodine.py:277-340) with their channel counts
         static const struct { unsigned bit; int first, count; } ent[10] = {
@@ -972,11 +978,15 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
         for (int l = 1; l < h->Dr; ++l) { ALLOC(h->ref_wsf[l], conv_ws_wpk_bytes(Cr) / 4); ALLOC(h->ref_wsf_meta[l], (size_t)4); }
     ALLOC(h->ref_w17, (size_t)Cr * 17 * h->kr * h->kr); ALLOC(h->ref_g17, (size_t)Cr * 17 * h->kr * h->kr);
     if (h->generic) {
-        const int kkd = h->kd * h->kd, kkr = h->kr * h->kr;
-        h->gen_wdec.assign(h->Dd, nullptr); h->gen_wref.assign(h->Dr, nullptr);
+        const int kkd = h->kd * h->kd;
+        h->gen_wdec.assign(h->Dd, nullptr);
         for (int l = 0; l < h->Dd; ++l) ALLOC(h->gen_wdec[l], (size_t)kkd * (l == 0 ? L + 2 : Cd) * Cd);
-        for (int l = 0; l < h->Dr; ++l) ALLOC(h->gen_wref[l], (size_t)kkr * (l == 0 ? 17 : Cr) * Cr);
         ALLOC(h->gen_wout, (size_t)kkd * Cd * 4); ALLOC(h->gen_b0, (size_t)Cd); ALLOC(h->gen_ident, (size_t)9 * Cd * L);
+    }
+    if (h->gen_ref) {
+        const int kkr = h->kr * h->kr;
+        h->gen_wref.assign(h->Dr, nullptr);
+        for (int l = 0; l < h->Dr; ++l) ALLOC(h->gen_wref[l], (size_t)kkr * (l == 0 ? 17 : Cr) * Cr);
     }
     ALLOC(h->ref_wk16, (size_t)9 * 2 * 2 * Cr * 4); ALLOC(h->ref_wsh16, (size_t)9 * 2 * 2 * Cr * 4);
     ALLOC(h->ref_wkmeta, (size_t)4); ALLOC(h->ref_wshmeta, (size_t)4);
@@ -1085,6 +1095,9 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         }
         HIPCHK(h, launch_gen_pack_weights(st, P("decoder.conv.weight"), 4, Cd, h->kd, h->gen_wout));
         HIPCHK(h, queue_copy(h->dec_out_b, P("decoder.conv.bias"), 4));
+        HIPCHK(h, launch_gen_identity(st, h->gen_ident, 9 * Cd, L));
+    }
+    if (h->gen_ref) {
         for (int l = 0; l < h->Dr; ++l) {
             const std::string base = "refine.mlc.layers." + std::to_string(l);
             const float* w = P(base + ".weight");
@@ -1095,8 +1108,8 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
             HIPCHK(h, launch_gen_pack_weights(st, w, Cr, l == 0 ? 17 : Cr, h->kr, h->gen_wref[l]));
             HIPCHK(h, queue_copy(h->ref_b[l], P(base + ".bias"), Cr));
         }
-        HIPCHK(h, launch_gen_identity(st, h->gen_ident, 9 * Cd, L));
-    } else {
+    }
+    if (!h->generic) {
     // decoder
     HIPCHK(h, launch_dec_l0_prepare(st, P("decoder.mlc.layers.0.weight"), P("decoder.mlc.layers.0.bias"), h->lin, Cd, L,
                                     h->S, h->wcls, h->wclsT, h->cmap));
@@ -1128,6 +1141,8 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     // split-fp16 GEMM-form packs of the output conv, forward and data gradient (one scale): two more jobs of the batched pack
     pj.push_back(PackJob{P("decoder.conv.weight"), h->dec_out_w16, h->dec_out_meta, 3, {Cd, 0, 0, 0, 0}});
     pj.push_back(PackJob{P("decoder.conv.weight"), h->dec_out_wb16, h->dec_out_meta, 4, {Cd, 1, 0, 0, 0}});
+    }   // !generic (decoder)
+    if (!h->gen_ref) {
     // refinement conv stack
     const bool ref_fp32 = h->precision == 0 || !refine_f16_ok(h);
     // first layer: the reference weight has n_in input channels (ARCH.ENCODING subset); the kernels see 17
@@ -1166,7 +1181,7 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         if (h->Dr >= 2 && refine_bwd01_ok(h->S, Cr))           // fused layer-1 / layer-0 backward: W1 as the transposed conv's A operand
             HIPCHK(h, pack_ws(P("refine.mlc.layers.1.weight"), Cr, 1, h->ref_w1ws_meta, h->ref_w1ws));
     }
-    }   // !generic
+    }   // !gen_ref
     auto copy_raw = [&](float* dst, const std::string& name) {
         return queue_copy(dst, P(name), h->params[param_index(h, name)].numel());
     };
@@ -1517,7 +1532,7 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
         HIPCHK(h, launch_pool_bwd(st, b.dpooled, b.ract[0][h->Dr - 1], b.rdpre[h->Dr - 1], NT, sl * sl, Cr));
         // round 4: the data gradient of layer 1 and the weight / bias gradient of layer 0 in ONE launch - d(pre-activation 0), the
         // largest tensor of this backward (T * N x 64 x 64 x 64 floats at cfg3), is produced and consumed on chip
-        const bool fuse01 = h->refine_bwd_fused && h->fwd_split && !h->generic && h->precision == 1 && refine_f16_ok(h) && h->Dr >= 2 &&
+        const bool fuse01 = h->refine_bwd_fused && h->fwd_split && !h->gen_ref && h->precision == 1 && refine_f16_ok(h) && h->Dr >= 2 &&
                             refine_bwd01_ok(h->S, Cr);
         for (int l = h->Dr - 1; l >= 0; --l) {
             const float* in = l == 0 ? b.enc[0] : b.ract[0][l - 1];
@@ -1529,7 +1544,7 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
             const bool gather0 = l == 0 && h->n_in < 17;
             float* gw_dst = gather0 ? h->ref_g17 : G(base + ".weight");
             if (gather0) HIPCHK(h, hipMemsetAsync(h->ref_g17, 0, (size_t)Cr * 17 * h->kr * h->kr * sizeof(float), st));
-            if (h->generic) {
+            if (h->gen_ref) {
                 PROF(h, st, "gen_conv", launch_gen_conv_wgrad(st, in, b.rdpre[l], b.gen_scr, NT, sz[l], ireal, cip, ireal, Cr, h->kr, 2, 1.f,
                                                               gw_dst, G(base + ".bias")));
             } else if (l == 0 && fuse01) {
@@ -1565,7 +1580,7 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
             }
             if (gather0) HIPCHK(h, launch_enc_gather_grad(st, h->ref_g17, Cr, h->n_in, h->enc_map, G(base + ".weight"), h->kr * h->kr));
             if (l > 0 && !(l == 1 && fuse01)) {
-                if (h->generic)
+                if (h->gen_ref)
                     PROF(h, st, "gen_conv", launch_gen_conv_dgrad(st, b.rdpre[l], h->gen_wref[l], b.ract[0][l - 1], b.rdpre[l - 1], NT, sz[l],
                                                                   Cr, Cr, Cr, h->kr, 2));
                 else if (h->precision == 1 && refine_f16_ok(h))
