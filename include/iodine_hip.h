@@ -222,7 +222,7 @@ int iodine_set_option(iodine_handle* h, const char* key, double value);
  * "pixel_pass1", "pixel_pass2", "refine_l0" (first refinement layer), "refine_l0f" (encoding + first refinement layer in one
  * kernel, option refine_l0_fused), "refine_conv" (the others), "refine_head", "refine_wgrad", "refine_dgrad", "refine_bwd01"
  * (fused layer-1 data gradient + layer-0 weight gradient, option refine_bwd_fused), "refine_bias_grad", "head_bwd", "gen_conv"
- * (every conv of the generic path).  "seen:<category>" returns in *launches the number of launches of <category> since the
+ * (the convs of the generic path), "gen_l0" (its spatial-broadcast layer: prefix-table forward, tap-sum backward).  "seen:<category>" returns in *launches the number of launches of <category> since the
  * last reset, bracketed or not (option profile_stride).  Synchronises on the recorded events.  Two more names report
  * the hipGraph bookkeeping of option "graph" in *launches: "graph_captures" (graphs instantiated) and "graph_replays". */
 int iodine_profile_read(iodine_handle* h, const char* category, double* total_ms, long long* launches, int reset);

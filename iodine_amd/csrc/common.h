@@ -334,8 +334,8 @@ hipError_t launch_enc_gather_grad(hipStream_t st, const float* g17, int O, int n
 
 // kernels_generic.hip: fallback fp32 convs for any odd kernel size / channel count (correctness path, see the file header)
 constexpr int GEN_WGRAD_SLICES = 64;
+constexpr int GEN_WGRAD_SLICES_MAX = 128;  // the row-staged form sizes its slices to the chip (two blocks per CU): scratch is sized for this many
 hipError_t launch_gen_pack_weights(hipStream_t st, const float* w, int Co, int Ci, int k, float* wt);
-hipError_t launch_gen_broadcast(hipStream_t st, const float* z, const float* lin, int N, int L, int S, float* bc);
 hipError_t launch_gen_conv_fwd(hipStream_t st, const float* in, const float* wt, const float* bias, float* out, int N, int Si, int Ci,
                                int ldc, int Co, int k, int s, int elu);
 hipError_t launch_gen_conv_dgrad(hipStream_t st, const float* dout, const float* wt, const float* aux, float* din, int N, int Si, int Ci,
@@ -343,8 +343,15 @@ hipError_t launch_gen_conv_dgrad(hipStream_t st, const float* dout, const float*
 size_t gen_wgrad_scratch_floats(int Ci, int Co, int k);
 hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* dout, float* scratch, int N, int Si, int Ci, int ldc,
                                  int Ci_dst, int Co, int k, int s, float alpha, float* gw, float* gb);
-constexpr int GEN_SUM_SLICES = 64;    // pixel slices of launch_gen_sum_pixels (scratch: N * GEN_SUM_SLICES * C floats)
-hipError_t launch_gen_sum_pixels(hipStream_t st, const float* src, int N, int P, int C, int ld, int ldo, float* out, float* scratch);
+// kernels_genl0.hip: the spatial-broadcast layer of the generic decoder without the broadcast tensor (prefix table of per-tap latent products
+// forward, tap-window sums of the gradient backward); any odd k <= GEN_L0_KMAX
+constexpr int GEN_L0_KMAX = 7;
+size_t gen_l0_scratch_floats(int N, int S, int Co, int k);
+hipError_t launch_gen_l0_coord(hipStream_t st, const float* wt0, const float* bias, const float* lin, int L, int S, int Co, int k, float* cterm);
+hipError_t launch_gen_l0_fwd(hipStream_t st, const float* z, const float* wt0, const float* cterm, float* scratch, float* out, int N, int L, int S,
+                             int Co, int k);
+hipError_t launch_gen_l0_bwd(hipStream_t st, const float* dpre, const float* z, const float* wt0, const float* lin, float* scratch, int N, int L,
+                             int S, int Co, int k, float alpha, float* gw, float* gb, float* dz, int ld);
 hipError_t launch_gen_identity(hipStream_t st, float* m, int rows, int L);
 hipError_t launch_ref_unsplit_grad(hipStream_t st, const float* g20, int O, float* gw);
 hipError_t launch_enc_join(hipStream_t st, const float* enck, const float* encs, float* enc, int N, int K, int P);

@@ -61,8 +61,7 @@ struct Buffers {               // workspace carve-up for one batch size / mode
     float* carry_h[2] = {nullptr, nullptr};
     float* carry_c[2] = {nullptr, nullptr};
     std::vector<float*> rdpre;                 // gradient wrt refinement pre-activations, per layer
-    float *bc = nullptr, *dbc = nullptr, *gen_scr = nullptr;   // generic path: materialised broadcast input, its gradient, wgrad partials
-    float* gen_sum = nullptr;                                   // generic decoder: pixel-slice partial sums of the broadcast input's gradient
+    float *gen_scr = nullptr, *gen_l0 = nullptr;                // generic path: wgrad partials; layer-0 scratch (kernels_genl0.hip)
 };
 
 }  // namespace
@@ -145,7 +144,7 @@ struct iodine_handle {
                                                            // the reference's default ARCH has REF.KERNEL_SIZE 3 / 32 channels beside DEC.KERNEL_SIZE 5)
     int kd = 3, kr = 3;                                    // DEC / REF kernel sizes
     std::vector<float*> gen_wdec, gen_wref;                // [layer]: packed weights
-    float *gen_wout = nullptr, *gen_b0 = nullptr, *gen_ident = nullptr;   // output conv pack, bias of decoder layer 0, [9 Cd][L] identity
+    float *gen_wout = nullptr, *gen_cterm = nullptr, *gen_ident = nullptr;   // output conv pack, [P][Cd] bias + coordinate term of decoder layer 0, [9 Cd][L] identity
     std::vector<float*> gacc;                   // one per parameter, reference shapes (slices of gacc_arena)
     float* gacc_arena = nullptr;
     size_t gacc_total = 0;
@@ -442,9 +441,7 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
         for (int l = 0; l < h->Dr; ++l) { s = ref_out_size(s); b.rdpre[l] = a.take<float>((size_t)T * N * s * s * Cr); }
     }
     if (h->generic) {
-        b.bc = a.take<float>((size_t)N * P * (L + 2));
-        b.dbc = a.take<float>((size_t)N * P * (L + 2));
-        b.gen_sum = a.take<float>((size_t)N * GEN_SUM_SLICES * L);
+        b.gen_l0 = a.take<float>(gen_l0_scratch_floats(N, h->S, Cd, h->kd));   // row / tap sums, prefix table of the broadcast layer
     }
     if ((h->generic || h->gen_ref) && mode == 1) {
         size_t scr = 0;
@@ -502,12 +499,12 @@ int decoder_forward(iodine_handle* h, hipStream_t st, int N, const float* z, flo
     Buffers& b = h->buf;
     if (!out) out = b.dec_out;
     if (h->generic) {
-        // fallback: materialised broadcast input, every layer a generic fp32 conv (kernels_generic.hip)
-        HIPCHK(h, launch_gen_broadcast(st, z, h->lin, N, h->L, h->S, b.bc));
-        const float* in = b.bc;
-        for (int l = 0; l < h->Dd; ++l) {
-            PROF(h, st, "gen_conv", launch_gen_conv_fwd(st, in, h->gen_wdec[l], l == 0 ? h->gen_b0 : h->dec_b[l], b.act[l], N, h->S,
-                                                        l == 0 ? h->L + 2 : h->Cd, l == 0 ? h->L + 2 : h->Cd, h->Cd, h->kd, 1, 1));
+        // fallback: the broadcast layer from the prefix table of its per-tap latent products (kernels_genl0.hip: the broadcast tensor is
+        // never built), every other layer a generic fp32 conv (kernels_generic.hip)
+        PROF(h, st, "gen_l0", launch_gen_l0_fwd(st, z, h->gen_wdec[0], h->gen_cterm, b.gen_l0, b.act[0], N, h->L, h->S, h->Cd, h->kd));
+        const float* in = b.act[0];
+        for (int l = 1; l < h->Dd; ++l) {
+            PROF(h, st, "gen_conv", launch_gen_conv_fwd(st, in, h->gen_wdec[l], h->dec_b[l], b.act[l], N, h->S, h->Cd, h->Cd, h->Cd, h->kd, 1, 1));
             in = b.act[l];
         }
         PROF(h, st, "gen_conv", launch_gen_conv_fwd(st, in, h->gen_wout, h->dec_out_b, out, N, h->S, h->Cd, h->Cd, 4, h->kd, 1, 0));
@@ -555,9 +552,9 @@ int reduce_wgrad(iodine_handle* h, hipStream_t st, int nparts, int ci_pad, int c
 // With train_alpha != 0 the decoder weight gradients of this pass are accumulated on the way with that factor
 // (= -w_i / B): they are what the outer loss.backward() (train.py:63) would compute for this decoder pass.
 // the same on the generic fallback path: plain chain of data gradients (and, in training, weight gradients with the pass factor);
-// the gradient wrt z is the pixel sum of the broadcast input's gradient, left in the first L entries of every row of buf.Rc
-// (dz_latent multiplies that by the identity in h->gen_ident)
-int decoder_backward_generic(iodine_handle* h, hipStream_t st, int N, float train_alpha)
+// the broadcast layer's weight gradient and the gradient wrt z come from the tap-window sums of its pre-activation gradient
+// (kernels_genl0.hip); dz is left in the first L entries of every row of buf.Rc (dz_latent multiplies that by the identity in h->gen_ident)
+int decoder_backward_generic(iodine_handle* h, hipStream_t st, int N, float train_alpha, int it)
 {
     Buffers& b = h->buf;
     const int Cd = h->Cd, Dd = h->Dd, L = h->L, S = h->S, k = h->kd;
@@ -567,23 +564,17 @@ int decoder_backward_generic(iodine_handle* h, hipStream_t st, int N, float trai
     if (train_alpha != 0.f)
         PROF(h, st, "gen_conv", launch_gen_conv_wgrad(st, b.act[Dd - 1], b.g, b.gen_scr, N, S, Cd, Cd, Cd, 4, k, 1, train_alpha,
                                                       G("decoder.conv.weight"), G("decoder.conv.bias")));
-    for (int l = Dd - 1; l >= 0; --l) {
+    for (int l = Dd - 1; l > 0; --l) {
         const std::string base = "decoder.mlc.layers." + std::to_string(l);
-        const float* in = l == 0 ? b.bc : b.act[l - 1];
-        const int ci = l == 0 ? L + 2 : Cd;
         if (train_alpha != 0.f)
-            PROF(h, st, "gen_conv", launch_gen_conv_wgrad(st, in, b.dpre[cur], b.gen_scr, N, S, ci, ci, ci, Cd, k, 1, train_alpha,
+            PROF(h, st, "gen_conv", launch_gen_conv_wgrad(st, b.act[l - 1], b.dpre[cur], b.gen_scr, N, S, Cd, Cd, Cd, Cd, k, 1, train_alpha,
                                                           G(base + ".weight"), G(base + ".bias")));
-        if (l > 0) {
-            PROF(h, st, "gen_conv", launch_gen_conv_dgrad(st, b.dpre[cur], h->gen_wdec[l], b.act[l - 1], b.dpre[cur ^ 1], N, S, Cd, Cd, Cd, k, 1));
-            cur ^= 1;
-        } else {
-            // only the L latent channels of the broadcast input carry a gradient that is needed
-            PROF(h, st, "gen_conv", launch_gen_conv_dgrad(st, b.dpre[cur], h->gen_wdec[0], nullptr, b.dbc, N, S, L, L + 2, Cd, k, 1));
-        }
+        PROF(h, st, "gen_conv", launch_gen_conv_dgrad(st, b.dpre[cur], h->gen_wdec[l], b.act[l - 1], b.dpre[cur ^ 1], N, S, Cd, Cd, Cd, k, 1));
+        cur ^= 1;
     }
     HIPCHK(h, hipMemsetAsync(b.Rc, 0, sizeof(float) * (size_t)N * 9 * Cd, st));
-    HIPCHK(h, launch_gen_sum_pixels(st, b.dbc, N, h->P, L, L + 2, 9 * Cd, b.Rc, b.gen_sum));
+    PROF(h, st, "gen_l0", launch_gen_l0_bwd(st, b.dpre[cur], b.z[it], h->gen_wdec[0], h->lin, b.gen_l0, N, L, S, Cd, k, train_alpha,
+                                            G("decoder.mlc.layers.0.weight"), G("decoder.mlc.layers.0.bias"), b.Rc, 9 * Cd));
     return IODINE_OK;
 }
 
@@ -591,7 +582,7 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
 {
     Buffers& b = h->buf;
     const int Cd = h->Cd, Dd = h->Dd;
-    if (h->generic) { *dpre0 = nullptr; return decoder_backward_generic(h, st, N, train_alpha); }
+    if (h->generic) { *dpre0 = nullptr; return decoder_backward_generic(h, st, N, train_alpha, it); }
     int cur = 0, nparts = 0, ncop = 0, nb = 0, rc;
     bool fused_l0 = false;
     // training: one pass over the last hidden activation gives the data gradient AND the weight / bias gradient
@@ -981,7 +972,7 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
         const int kkd = h->kd * h->kd;
         h->gen_wdec.assign(h->Dd, nullptr);
         for (int l = 0; l < h->Dd; ++l) ALLOC(h->gen_wdec[l], (size_t)kkd * (l == 0 ? L + 2 : Cd) * Cd);
-        ALLOC(h->gen_wout, (size_t)kkd * Cd * 4); ALLOC(h->gen_b0, (size_t)Cd); ALLOC(h->gen_ident, (size_t)9 * Cd * L);
+        ALLOC(h->gen_wout, (size_t)kkd * Cd * 4); ALLOC(h->gen_cterm, (size_t)h->P * Cd); ALLOC(h->gen_ident, (size_t)9 * Cd * L);
     }
     if (h->gen_ref) {
         const int kkr = h->kr * h->kr;
@@ -1091,8 +1082,10 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         for (int l = 0; l < h->Dd; ++l) {
             const std::string base = "decoder.mlc.layers." + std::to_string(l);
             HIPCHK(h, launch_gen_pack_weights(st, P(base + ".weight"), Cd, l == 0 ? L + 2 : Cd, h->kd, h->gen_wdec[l]));
-            HIPCHK(h, queue_copy(l == 0 ? h->gen_b0 : h->dec_b[l], P(base + ".bias"), Cd));
+            if (l > 0) HIPCHK(h, queue_copy(h->dec_b[l], P(base + ".bias"), Cd));
         }
+        // bias + the conv of the two coordinate channels of the broadcast layer: the same map for every slot-image
+        HIPCHK(h, launch_gen_l0_coord(st, h->gen_wdec[0], P("decoder.mlc.layers.0.bias"), h->lin, L, h->S, Cd, h->kd, h->gen_cterm));
         HIPCHK(h, launch_gen_pack_weights(st, P("decoder.conv.weight"), 4, Cd, h->kd, h->gen_wout));
         HIPCHK(h, queue_copy(h->dec_out_b, P("decoder.conv.bias"), 4));
         HIPCHK(h, launch_gen_identity(st, h->gen_ident, 9 * Cd, L));

@@ -7,8 +7,8 @@
 // weight slice per 16 output channels, 16 x 16 pixel tiles, v_mfma_f32_16x16x4_f32; weight gradient on v_mfma_f32_32x32x2_f32) whenever
 // the weight slice fits LDS - 5 x 5 x 64 channels does, 7 x 7 up to 32 channels.  Everything else (stride 2 = the refinement stack,
 // larger slices) runs on the scalar kernels right below: one thread per output element, plain fp32 FMAs in a fixed order, written for
-// correctness.  All of it is deterministic.  The spatial-broadcast layer is MATERIALISED here ([N][P][L+2]) and convolved like any
-// other layer; its gradient wrt z is the pixel sum of the data gradient.  Every shipped / benchmarked configuration stays on the
+// correctness.  All of it is deterministic.  The spatial-broadcast layer (decoder layer 0) has its own kernels (kernels_genl0.hip: the broadcast
+// tensor is never built; until round 5 it was materialised as [N][P][L+2] and convolved like any other layer).  Every shipped / benchmarked configuration stays on the
 // tuned path (iodine_api.cpp: `generic` is false for KERNEL_SIZE 3 with 32 / 64 channels).  Measured (MI355X, CLEVR shapes with
 // DEC.KERNEL_SIZE 5, batch 4): training step 4977 -> 206 ms, reconstruct 2317 -> 96 ms against the scalar tier.
 //
@@ -27,19 +27,6 @@ __global__ void gen_pack_weights_kernel(const float* __restrict__ w, int Co, int
     if (idx >= Co * Ci * kk) return;
     const int co = idx % Co, ci = (idx / Co) % Ci, tap = idx / (Co * Ci);
     wt[idx] = w[((size_t)co * Ci + ci) * kk + tap];
-}
-
-// bc[n][p][0..L-1] = z[n], bc[n][p][L] = x coordinate, bc[n][p][L+1] = y coordinate (SpatialBroadcast, iodine.py:505-540)
-__global__ void gen_broadcast_kernel(const float* __restrict__ z, const float* __restrict__ lin, int L, int S, size_t total,
-                                     float* __restrict__ bc)
-{
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = (int)(idx % (L + 2));
-    const size_t px = idx / (L + 2);
-    const int p = (int)(px % ((size_t)S * S));
-    const size_t n = px / ((size_t)S * S);
-    bc[idx] = c < L ? z[n * L + c] : (c == L ? lin[p % S] : lin[p / S]);
 }
 
 // out[n][oy][ox][co] = act(bias[co] + sum_{tap, ci} in[n][oy*s + ky - pad][ox*s + kx - pad][ci] * wt[tap][ci][co])
@@ -143,48 +130,6 @@ __global__ void gen_conv_wgrad_reduce_kernel(const float* __restrict__ part, int
     if (ci < Ci_dst) gw[((size_t)co * Ci_dst + ci) * kk + tap] += alpha * acc;
 }
 
-// out[n][c] = sum_p src[n][p][c] for c < C (fixed order), row stride ld of src, row stride ldo of out
-// out[n][c] = sum over the pixels of src[n][p][c] (c < C, row stride ld).  Round 5: two stages - GEN_SUM_SLICES pixel slices per slot-image, each a
-// block whose threads walk (channel, pixel sub-slice) with four independent partial sums, then a fixed-order sum over the slices (the one-block-per-
-// slot-image form read 120 MB with 28 blocks of 64 threads: 1.56 ms per call at the CLEVR shapes, 6 calls per training step).
-__global__ __launch_bounds__(256) void gen_sum_pixels_kernel(const float* __restrict__ src, int P, int C, int ld, float* __restrict__ scratch)
-{
-    __shared__ float s_part[256];
-    const int n = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
-    const int per = (P + GEN_SUM_SLICES - 1) / GEN_SUM_SLICES, p0 = sl * per, p1 = min(P, p0 + per);
-    const int CL = C < 256 ? C : 256;                        // channels per pass; 256 / CL pixel sub-slices (CL a divisor of 256 or the tail is idle)
-    const int nsub = 256 / CL > 0 ? 256 / CL : 1;
-    for (int c0 = 0; c0 < C; c0 += CL) {
-        const int c = c0 + tid % CL, sub = tid / CL;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        if (sub < nsub && c < C) {
-            const float* sp = src + (size_t)n * P * ld + c;
-            int p = p0 + sub;
-            for (; p + 3 * nsub < p1; p += 4 * nsub) {
-                a0 += sp[(size_t)p * ld]; a1 += sp[(size_t)(p + nsub) * ld]; a2 += sp[(size_t)(p + 2 * nsub) * ld]; a3 += sp[(size_t)(p + 3 * nsub) * ld];
-            }
-            for (; p < p1; p += nsub) a0 += sp[(size_t)p * ld];
-        }
-        s_part[tid] = (a0 + a1) + (a2 + a3);
-        __syncthreads();
-        if (tid < CL && c0 + tid < C) {
-            float t = 0.f;
-            for (int q = 0; q < nsub; ++q) t += s_part[q * CL + tid];
-            scratch[((size_t)n * GEN_SUM_SLICES + sl) * C + c0 + tid] = t;
-        }
-        __syncthreads();
-    }
-}
-
-__global__ void gen_sum_slices_kernel(const float* __restrict__ scratch, int C, int ldo, float* __restrict__ out)
-{
-    const int n = blockIdx.x, c = blockIdx.y * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float t = 0.f;
-    for (int sl = 0; sl < GEN_SUM_SLICES; ++sl) t += scratch[((size_t)n * GEN_SUM_SLICES + sl) * C + c];
-    out[(size_t)n * ldo + c] = t;
-}
-
 // rows [rows][L] identity-embedded in [rows][L] zero matrix of height `rows`: the "class-sum to latent" matrix of dz_latent when
 // the gradient wrt z already sits in the first L entries of every row
 __global__ void gen_identity_kernel(float* __restrict__ m, int rows, int L)
@@ -193,6 +138,7 @@ __global__ void gen_identity_kernel(float* __restrict__ m, int rows, int L)
     if (idx >= rows * L) return;
     m[idx] = (idx / L) == (idx % L) ? 1.f : 0.f;
 }
+
 
 
 // =====================================================================================================================================
@@ -208,18 +154,19 @@ __global__ void gen_identity_kernel(float* __restrict__ m, int rows, int L)
 //   W(tap, k, n) = wt[tapidx * sT + k * sK + n * sN]:  forward tapidx = tap, (sT, sK, sN) = (Ci Co, Co, 1) on the pack [tap][ci][co];
 //   data gradient: the correlation with the flipped kernel, tapidx = KS^2 - 1 - tap, reduction over co, (sT, sK, sN) = (ldi Co, 1, Co).
 // =====================================================================================================================================
-template <int KS>
+template <int KS, int CCH>                                     // CCH: reduction channels per staged chunk (8, or 4 where 8 does not fit the LDS)
 __global__ __launch_bounds__(256)
 void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
                           const float* __restrict__ aux, float* __restrict__ out, int S, int Ck, int ldin, int Cn, int ldout,
                           int flip, int sT, int sK, int sN, int elu, int ncg, int tiles, int ntiles)
 {
     constexpr int KK = KS * KS, PAD = KS / 2, TW = 16 + KS - 1, NPX = TW * TW;
-    constexpr int NLD = (NPX * 4 + 255) / 256;
+    constexpr int NH = CCH / 4;                               // MFMA k-steps per tap and chunk (one barrier per chunk)
+    constexpr int NLD = (NPX * CCH + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float smem_g[];
-    const int Ckp = (Ck + 3) & ~3, nchunk = Ckp >> 2;
+    const int Ckp = (Ck + CCH - 1) / CCH * CCH, nchunk = Ckp / CCH;
     float* s_w = smem_g;                                      // [KK][Ckp][16]
-    float* s_in = smem_g + (size_t)KK * Ckp * 16;             // [2][NPX][4]
+    float* s_in = smem_g + (size_t)KK * Ckp * 16;             // [2][NPX][CCH]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int cg = blockIdx.x % ncg, pb = blockIdx.x / ncg, nb = gridDim.x / ncg;
     if (pb >= nb) return;                                     // (grid = ncg * nb exactly; defensive)
@@ -240,9 +187,9 @@ void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict_
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int e = tid + 256 * i;
-                const int px = e >> 2, k = e & 3;
-                const int gy = ty * 16 - PAD + px / TW, gx = tx * 16 - PAD + px % TW, ch = c * 4 + k;
-                const bool ok = e < NPX * 4 && (unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S && ch < Ck;
+                const int px = e / CCH, k = e % CCH;
+                const int gy = ty * 16 - PAD + px / TW, gx = tx * 16 - PAD + px % TW, ch = c * CCH + k;
+                const bool ok = e < NPX * CCH && (unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S && ch < Ck;
                 rin[i] = ok ? in_n[((size_t)gy * S + gx) * ldin + ch] : 0.f;
             }
         };
@@ -250,7 +197,7 @@ void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict_
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int e = tid + 256 * i;
-                if (e < NPX * 4) s_in[buf * NPX * 4 + e] = rin[i];
+                if (e < NPX * CCH) s_in[buf * NPX * CCH + e] = rin[i];
             }
         };
         f32x4 acc[4];
@@ -262,15 +209,27 @@ void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict_
         __syncthreads();
         for (int c = 0; c < nchunk; ++c) {
             if (c + 1 < nchunk) fetch(c + 1);                 // in flight under this chunk's MFMAs
-            const float* si = s_in + (c & 1) * NPX * 4;
-            const float* sw = s_w + (size_t)(c * 4 + kq) * 16 + m;
-            for (int tap = 0; tap < KK; ++tap) {
-                const int ky = tap / KS, kx = tap % KS;
-                const float b = sw[(size_t)tap * Ckp * 16];
+            const float* si = s_in + (c & 1) * NPX * CCH;
+            // Round 5: all operands of a k-step are fetched FIRST - the KK weight values of this lane and the (4 + KS - 1) x KS input values
+            // its four tile rows share between their taps (40 + 25 LDS reads at KS = 5 instead of 100 + 25, none of them in front of the
+            // MFMA that needs it) - then the 4 KK MFMAs issue back to back; and a chunk is 8 channels = two such k-steps per barrier.  One wave
+            // per SIMD (the weight slice fills the LDS) cannot hide a read-then-multiply chain or a barrier behind another wave: the rolled
+            // 4-channel loop ran at 41 % of the fp32 matrix peak.
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float a = si[((4 * wv + r + ky) * TW + m + kx) * 4 + kq];
-                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[r], 0, 0, 0);
+            for (int hh = 0; hh < NH; ++hh) {
+                const float* sw = s_w + (size_t)(c * CCH + 4 * hh + kq) * 16 + m;
+                float bw[KK], av[4 + KS - 1][KS];
+#pragma unroll
+                for (int tap = 0; tap < KK; ++tap) bw[tap] = sw[(size_t)tap * Ckp * 16];
+#pragma unroll
+                for (int rr = 0; rr < 4 + KS - 1; ++rr)
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) av[rr][kx] = si[((4 * wv + rr) * TW + m + kx) * CCH + 4 * hh + kq];
+#pragma unroll
+                for (int tap = 0; tap < KK; ++tap) {
+                    const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + ky][kx], bw[tap], acc[r], 0, 0, 0);
                 }
             }
             if (c + 1 < nchunk) commit((c + 1) & 1);
@@ -359,31 +318,159 @@ void gen_wgrad_mfma_kernel(const float* __restrict__ in, const float* __restrict
     }
 }
 
+// Round 5: the same weight gradient with the operands staged ONCE per kernel ROW.  The kernel above gives every tap its own blocks, each
+// streaming both tensors from global memory again (KS^2 = 25 passes over `in` and `dout` at KS = 5: 5.9 GB of L2 / HBM traffic per launch at
+// the CLEVR shapes with 28 slot-images, and the load -> 8 MFMAs -> load chain hides its latency only through occupancy: 34 % of the fp32 matrix
+// peak).  Here a block owns one kernel row ky and one row slice; per image row it stages the input row y + ky - PAD (S + 2 PAD pixels, zero
+// margins) and the gradient row y as planes of 32 channels in LDS - the next row is fetched into registers while the current one is multiplied -
+// and its four waves ((ci tile, co tile) pairs) issue the KS taps kx of that row from it: KS accumulators of 32 x 32 per wave, 5 MFMAs per two
+// LDS reads.  Channel counts and row strides that are multiples of 4 (float4 staging), rows that fit the LDS; everything else keeps the kernel above.
+template <int KS>
+__global__ __launch_bounds__(256, 2)
+void gen_wgrad_rows_kernel(const float* __restrict__ in, const float* __restrict__ dout, float* __restrict__ part, int N, int S, int Ci,
+                           int ldc, int Co, int nslice)
+{
+    constexpr int KK = KS * KS, PAD = KS / 2;
+    constexpr int MAXV = 16;                                   // float4 per thread and staged row pair (launcher: fits)
+    extern __shared__ __attribute__((aligned(16))) float smem_gw[];
+    const int ky = blockIdx.x % KS, slice = (blockIdx.x / KS) % nslice, pgrp = blockIdx.x / (KS * nslice);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, kh = lane >> 5;
+    const int nit = (Ci + 31) / 32, nct = (Co + 31) / 32, npair = nit * nct;
+    const int Wp = S + 2 * PAD + 1, Sd = S + 1;               // staged pixels per row (+1: the pixel pair of an odd S reads a zero)
+    float* s_a = smem_gw;                                      // [nit][Wp][32]
+    float* s_d = smem_gw + (size_t)nit * Wp * 32;              // [nct][Sd][32]
+    const int pair = pgrp * 4 + wv;
+    const bool wave_on = pair < npair;
+    const int cit = wave_on ? pair / nct : 0, cot = wave_on ? pair % nct : 0;
+    const int co = cot * 32 + li;
+    const bool cov = co < Co;
+    const int per = KK * Ci * Co + Co;
+    const long long R = (long long)N * S;
+    const long long r0 = R * slice / nslice, r1 = R * (slice + 1) / nslice;
+    // zero the planes once: channel pads, pixel margins and the extra pixel stay zero (staging only writes real elements)
+    for (int e = tid; e < (nit * Wp + nct * Sd) * 32; e += 256) smem_gw[e] = 0.f;
+
+    const int A4 = (Ci + 3) / 4, D4 = Co / 4;                 // float4 per pixel (Ci rounded up: the row stride covers the pad channels)
+    const int na = S * A4, nd = S * D4;                       // float4 of a staged row (real pixels only)
+    float4 rv[MAXV];
+    auto fetch = [&](long long row) {
+        const int y = (int)(row % S);
+        const long long n = row / S;
+        const int iy = y + ky - PAD;
+        const bool rowv = (unsigned)iy < (unsigned)S;
+        const float* ip = in + ((size_t)n * S + (rowv ? iy : 0)) * S * (size_t)ldc;
+        const float* dp = dout + ((size_t)n * S + y) * S * (size_t)Co;
+        int tv = tid;
+        asm volatile("" : "+v"(tv));                           // (the element -> (pixel, quad) arithmetic is recomputed per row: hoisted it spills)
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int e = tv + 256 * k;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < na) { if (rowv) v = *reinterpret_cast<const float4*>(ip + (size_t)(e / A4) * ldc + (e % A4) * 4); }
+            else if (e < na + nd) { const int f = e - na; v = *reinterpret_cast<const float4*>(dp + (size_t)(f / D4) * Co + (f % D4) * 4); }
+            rv[k] = v;
+        }
+    };
+    auto commit = [&]() {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int e = tv + 256 * k;
+            if (e < na) { const int x = e / A4, c4 = e % A4; *reinterpret_cast<float4*>(s_a + ((size_t)(c4 >> 3) * Wp + x + PAD) * 32 + (c4 & 7) * 4) = rv[k]; }
+            else if (e < na + nd) { const int f = e - na, x = f / D4, c4 = f % D4; *reinterpret_cast<float4*>(s_d + ((size_t)(c4 >> 3) * Sd + x) * 32 + (c4 & 7) * 4) = rv[k]; }
+        }
+    };
+    f32x16 acc[KS];
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = ky == 0 && cit == 0 && wave_on;
+    if (r0 < r1) fetch(r0);
+    __syncthreads();                                           // planes zeroed
+    for (long long row = r0; row < r1; ++row) {
+        commit();
+        __syncthreads();
+        if (row + 1 < r1) fetch(row + 1);                      // in flight under this row's MFMAs
+        const int iy = (int)(row % S) + ky - PAD;
+        if (wave_on && ((unsigned)iy < (unsigned)S || do_bias)) {
+            const float* ap = s_a + ((size_t)cit * Wp + kh) * 32 + li;
+            const float* dp = s_d + ((size_t)cot * Sd + kh) * 32 + li;
+#pragma unroll 4
+            for (int x0 = 0; x0 < S; x0 += 2) {
+                const float b = dp[(size_t)x0 * 32];
+                float a[KS];
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) a[kx] = ap[(size_t)(x0 + kx) * 32];
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kx], b, acc[kx], 0, 0, 0);
+                bsum += b;
+            }
+        }
+        __syncthreads();                                       // every wave is done with the planes
+    }
+    if (!wave_on) return;
+    float* pw = part + (size_t)slice * per;
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int cr = cit * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+            if (cr < Ci && cov) pw[((size_t)(ky * KS + kx) * Ci + cr) * Co + co] = acc[kx][q];
+        }
+    if (do_bias) {
+        bsum += __shfl_xor(bsum, 32);
+        if (kh == 0 && cov) pw[(size_t)KK * Ci * Co + co] = bsum;
+    }
+}
+
+// LDS bytes of gen_wgrad_rows_kernel, 0 = the shape does not qualify (float4 staging, at most 16 float4 per thread and row, <= 80 KB: two blocks per CU)
+inline size_t gen_wgrad_rows_lds(int S, int Ci, int ldc, int Co, int k)
+{
+    if (Co % 4 != 0 || ldc % 4 != 0 || ((Ci + 3) & ~3) > ldc) return 0;
+    if ((size_t)S * ((Ci + 3) / 4 + Co / 4) > (size_t)16 * 256) return 0;
+    const size_t b = ((size_t)((Ci + 31) / 32) * (S + 2 * (k / 2) + 1) + (size_t)((Co + 31) / 32) * (S + 1)) * 32 * sizeof(float);
+    return b <= 80 * 1024 ? b : 0;
+}
+
 inline unsigned gen_blocks(size_t total) { return (unsigned)((total + 255) / 256); }
 
-// LDS bytes of the MFMA form: weight slice + two halo chunks; 0 = does not apply (stride 2, or the slice does not fit)
-inline size_t gen_mfma_lds(int k, int Ck, int s)
+// LDS bytes of the MFMA form with chunks of cch channels: weight slice + two halo chunks; 0 = does not apply (stride 2, or the slice does not fit)
+inline size_t gen_mfma_lds_cch(int k, int Ck, int s, int cch)
 {
     if (s != 1 || (k != 3 && k != 5 && k != 7)) return 0;
-    const int Ckp = (Ck + 3) & ~3, TW = 16 + k - 1;
-    const size_t b = ((size_t)k * k * Ckp * 16 + (size_t)2 * TW * TW * 4) * sizeof(float);
+    const int Ckp = (Ck + cch - 1) / cch * cch, TW = 16 + k - 1;
+    const size_t b = ((size_t)k * k * Ckp * 16 + (size_t)2 * TW * TW * cch) * sizeof(float);
     return b <= 160 * 1024 ? b : 0;
+}
+// (the 8-channel form where it fits, else the 4-channel form, else 0 = the scalar kernels)
+inline size_t gen_mfma_lds(int k, int Ck, int s) { const size_t b = gen_mfma_lds_cch(k, Ck, s, 8); return b ? b : gen_mfma_lds_cch(k, Ck, s, 4); }
+
+template <int KS, int CCH>
+hipError_t gen_mfma_launch_cch(hipStream_t st, const float* in, const float* wt, const float* bias, const float* aux, float* out, int N, int S,
+                               int Ck, int ldin, int Cn, int ldout, int flip, int sT, int sK, int sN, int elu, size_t lds)
+{
+    static std::atomic<unsigned> attr_devs{0};
+    if (hipError_t e = iod_set_max_lds((const void*)gen_conv_mfma_kernel<KS, CCH>, 160 * 1024, attr_devs); e != hipSuccess) return e;
+    int n_cu = 0;
+    if (hipError_t e = iod_cu_count(&n_cu); e != hipSuccess) return e;
+    const int ncg = (Cn + 15) / 16, tiles = (S + 15) / 16, ntiles = N * tiles * tiles;
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int nb = std::max(1, std::min(ntiles, per_cu * n_cu / ncg));
+    hipLaunchKernelGGL((gen_conv_mfma_kernel<KS, CCH>), dim3(ncg * nb), dim3(256), lds, st, in, wt, bias, aux, out, S, Ck, ldin, Cn, ldout, flip,
+                       sT, sK, sN, elu, ncg, tiles, ntiles);
+    return hipGetLastError();
 }
 
 template <int KS>
 hipError_t gen_mfma_launch(hipStream_t st, const float* in, const float* wt, const float* bias, const float* aux, float* out, int N, int S,
                            int Ck, int ldin, int Cn, int ldout, int flip, int sT, int sK, int sN, int elu, size_t lds)
 {
-    static std::atomic<unsigned> attr_devs{0};
-    if (hipError_t e = iod_set_max_lds((const void*)gen_conv_mfma_kernel<KS>, 160 * 1024, attr_devs); e != hipSuccess) return e;
-    int n_cu = 0;
-    if (hipError_t e = iod_cu_count(&n_cu); e != hipSuccess) return e;
-    const int ncg = (Cn + 15) / 16, tiles = (S + 15) / 16, ntiles = N * tiles * tiles;
-    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
-    const int nb = std::max(1, std::min(ntiles, per_cu * n_cu / ncg));
-    hipLaunchKernelGGL((gen_conv_mfma_kernel<KS>), dim3(ncg * nb), dim3(256), lds, st, in, wt, bias, aux, out, S, Ck, ldin, Cn, ldout, flip,
-                       sT, sK, sN, elu, ncg, tiles, ntiles);
-    return hipGetLastError();
+    if (gen_mfma_lds_cch(KS, Ck, 1, 8) == lds)
+        return gen_mfma_launch_cch<KS, 8>(st, in, wt, bias, aux, out, N, S, Ck, ldin, Cn, ldout, flip, sT, sK, sN, elu, lds);
+    return gen_mfma_launch_cch<KS, 4>(st, in, wt, bias, aux, out, N, S, Ck, ldin, Cn, ldout, flip, sT, sK, sN, elu, lds);
 }
 
 
@@ -392,13 +479,6 @@ hipError_t gen_mfma_launch(hipStream_t st, const float* in, const float* wt, con
 hipError_t launch_gen_pack_weights(hipStream_t st, const float* w, int Co, int Ci, int k, float* wt)
 {
     hipLaunchKernelGGL(gen_pack_weights_kernel, dim3(gen_blocks((size_t)Co * Ci * k * k)), dim3(256), 0, st, w, Co, Ci, k * k, wt);
-    return hipGetLastError();
-}
-
-hipError_t launch_gen_broadcast(hipStream_t st, const float* z, const float* lin, int N, int L, int S, float* bc)
-{
-    const size_t total = (size_t)N * S * S * (L + 2);
-    hipLaunchKernelGGL(gen_broadcast_kernel, dim3(gen_blocks(total)), dim3(256), 0, st, z, lin, L, S, total, bc);
     return hipGetLastError();
 }
 
@@ -432,7 +512,7 @@ hipError_t launch_gen_conv_dgrad(hipStream_t st, const float* dout, const float*
     return hipGetLastError();
 }
 
-size_t gen_wgrad_scratch_floats(int Ci, int Co, int k) { return (size_t)GEN_WGRAD_SLICES * ((size_t)k * k * Ci * Co + Co); }
+size_t gen_wgrad_scratch_floats(int Ci, int Co, int k) { return (size_t)GEN_WGRAD_SLICES_MAX * ((size_t)k * k * Ci * Co + Co); }
 
 hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* dout, float* scratch, int N, int Si, int Ci, int ldc,
                                  int Ci_dst, int Co, int k, int s, float alpha, float* gw, float* gb)
@@ -441,6 +521,27 @@ hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* d
     const size_t per = (size_t)k * k * Ci * Co + Co;
     if (s == 1 && (k == 3 || k == 5 || k == 7)) {
         const int npair = ((Ci + 31) / 32) * ((Co + 31) / 32), ngrp = (npair + 3) / 4;
+        if (const size_t lds = gen_wgrad_rows_lds(Si, Ci, ldc, Co, k)) {       // operands staged once per kernel row (round 5)
+            // as many row slices as fill the chip with two blocks per CU (k x nsl x ngrp blocks; 64 slices left a third of the slots empty)
+            int n_cu = 0;
+            if (hipError_t e = iod_cu_count(&n_cu); e != hipSuccess) return e;
+            const int nsl = std::max(1, std::min(GEN_WGRAD_SLICES_MAX, 2 * n_cu / (k * ngrp)));
+            const dim3 grid_r((unsigned)(k * nsl * ngrp));
+            static std::atomic<unsigned> d3{0}, d5{0}, d7{0};
+            if (k == 3) {
+                if (hipError_t e = iod_set_max_lds((const void*)gen_wgrad_rows_kernel<3>, 80 * 1024, d3); e != hipSuccess) return e;
+                hipLaunchKernelGGL((gen_wgrad_rows_kernel<3>), grid_r, dim3(256), lds, st, in, dout, scratch, N, Si, Ci, ldc, Co, nsl);
+            } else if (k == 5) {
+                if (hipError_t e = iod_set_max_lds((const void*)gen_wgrad_rows_kernel<5>, 80 * 1024, d5); e != hipSuccess) return e;
+                hipLaunchKernelGGL((gen_wgrad_rows_kernel<5>), grid_r, dim3(256), lds, st, in, dout, scratch, N, Si, Ci, ldc, Co, nsl);
+            } else {
+                if (hipError_t e = iod_set_max_lds((const void*)gen_wgrad_rows_kernel<7>, 80 * 1024, d7); e != hipSuccess) return e;
+                hipLaunchKernelGGL((gen_wgrad_rows_kernel<7>), grid_r, dim3(256), lds, st, in, dout, scratch, N, Si, Ci, ldc, Co, nsl);
+            }
+            hipLaunchKernelGGL(gen_conv_wgrad_reduce_kernel, dim3(gen_blocks(per)), dim3(256), 0, st, scratch, nsl, Ci, Ci_dst, Co,
+                               k * k, alpha, gw, gb);
+            return hipGetLastError();
+        }
         const dim3 grid((unsigned)(k * k * GEN_WGRAD_SLICES * ngrp));
         if (k == 3) hipLaunchKernelGGL((gen_wgrad_mfma_kernel<3>), grid, dim3(256), 0, st, in, dout, scratch, N, Si, Ci, ldc, Co, GEN_WGRAD_SLICES);
         else if (k == 5) hipLaunchKernelGGL((gen_wgrad_mfma_kernel<5>), grid, dim3(256), 0, st, in, dout, scratch, N, Si, Ci, ldc, Co, GEN_WGRAD_SLICES);
@@ -453,14 +554,6 @@ hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* d
                        So, Ci, ldc, Co, k, s, GEN_WGRAD_SLICES);
     hipLaunchKernelGGL(gen_conv_wgrad_reduce_kernel, dim3(gen_blocks(per)), dim3(256), 0, st, scratch, GEN_WGRAD_SLICES, Ci, Ci_dst, Co,
                        k * k, alpha, gw, gb);
-    return hipGetLastError();
-}
-
-hipError_t launch_gen_sum_pixels(hipStream_t st, const float* src, int N, int P, int C, int ld, int ldo, float* out, float* scratch)
-{
-    if (!scratch) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gen_sum_pixels_kernel, dim3(N, GEN_SUM_SLICES), dim3(256), 0, st, src, P, C, ld, scratch);
-    hipLaunchKernelGGL(gen_sum_slices_kernel, dim3(N, (C + 63) / 64), dim3(64), 0, st, scratch, C, ldo, out);
     return hipGetLastError();
 }
 
