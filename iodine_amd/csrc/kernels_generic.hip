@@ -154,21 +154,32 @@ __global__ void gen_identity_kernel(float* __restrict__ m, int rows, int L)
 //   W(tap, k, n) = wt[tapidx * sT + k * sK + n * sN]:  forward tapidx = tap, (sT, sK, sN) = (Ci Co, Co, 1) on the pack [tap][ci][co];
 //   data gradient: the correlation with the flipped kernel, tapidx = KS^2 - 1 - tap, reduction over co, (sT, sK, sN) = (ldi Co, 1, Co).
 // =====================================================================================================================================
-template <int KS, int CCH>                                     // CCH: reduction channels per staged chunk (8, or 4 where 8 does not fit the LDS)
+template <int KS, int CCH>                                     // CCH: reduction channels per staged chunk (16, 8 or 4: the largest that fits the LDS)
 __global__ __launch_bounds__(256)
 void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
                           const float* __restrict__ aux, float* __restrict__ out, int S, int Ck, int ldin, int Cn, int ldout,
                           int flip, int sT, int sK, int sN, int elu, int ncg, int tiles, int ntiles)
 {
     constexpr int KK = KS * KS, PAD = KS / 2, TW = 16 + KS - 1, NPX = TW * TW;
+    // Round 5: the staged chunk is CHANNEL-major, one plane of NPXP floats per channel with NPXP = 16 (mod 32): the 16 pixels x 4 channels a
+    // wave reads per operand are 16 consecutive words in each of 4 planes that start 16 banks apart - conflict-free (the pixel-major
+    // [pixel][8 channels] layout was a 4-way bank conflict on every input operand read, with one wave per SIMD nothing hides it).
+    constexpr int NPXP = (NPX + 15) / 32 * 32 + 16;
     constexpr int NH = CCH / 4;                               // MFMA k-steps per tap and chunk (one barrier per chunk)
-    constexpr int NLD = (NPX * CCH + 255) / 256;
+    constexpr int NQ = CCH / 4;                               // channel quads per pixel: staged with 16-byte loads
+    constexpr int NLD = (NPX * NQ + 255) / 256;
+    constexpr int RR = 4 + KS - 1;                            // input rows the four tile rows of a wave share
     extern __shared__ __attribute__((aligned(16))) float smem_g[];
     const int Ckp = (Ck + CCH - 1) / CCH * CCH, nchunk = Ckp / CCH;
     float* s_w = smem_g;                                      // [KK][Ckp][16]
-    float* s_in = smem_g + (size_t)KK * Ckp * 16;             // [2][NPX][CCH]
+    float* s_in = smem_g + (size_t)KK * Ckp * 16;             // [2][CCH][NPXP]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int cg = blockIdx.x % ncg, pb = blockIdx.x / ncg, nb = gridDim.x / ncg;
+    // block -> (channel group, tile sequence).  Blocks b, b + 8, b + 16 ... share an XCD: the ncg blocks that need the same input tile at
+    // the same time are put on ONE XCD (one L2 fetches the tile) whenever the counts divide; otherwise consecutive blocks take the groups.
+    int cg, pb;
+    const int nb = gridDim.x / ncg;
+    if (nb % 8 == 0) { const int x = blockIdx.x & 7, j = blockIdx.x >> 3; cg = j % ncg; pb = (j / ncg) * 8 + x; }
+    else { cg = blockIdx.x % ncg; pb = blockIdx.x / ncg; }
     if (pb >= nb) return;                                     // (grid = ncg * nb exactly; defensive)
     // ---- this block's weight slice -> LDS, once ----
     for (int e = tid; e < KK * Ckp * 16; e += 256) {
@@ -179,25 +190,37 @@ void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict_
         s_w[e] = v;
     }
     const int m = lane & 15, kq = lane >> 4;
-    float rin[NLD];
+    const int co0 = cg * 16 + 4 * kq;                         // the four output channels of this lane (D rows 4 kq + v, column = pixel m)
+    float bv[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bv[v] = (bias && co0 + v < Cn) ? bias[co0 + v] : 0.f;
+    const bool vec_out = (ldout & 3) == 0 && co0 + 3 < Cn;
+    float4 rin[NLD];
     for (int t = pb; t < ntiles; t += nb) {
         const int tx = t % tiles, ty = (t / tiles) % tiles, n = t / (tiles * tiles);
         const float* in_n = in + (size_t)n * S * S * ldin;
         auto fetch = [&](int c) {
+            int tv = tid;
+            asm volatile("" : "+v"(tv));                       // (element -> (pixel, quad) arithmetic recomputed per chunk, not kept in registers)
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                const int e = tid + 256 * i;
-                const int px = e / CCH, k = e % CCH;
-                const int gy = ty * 16 - PAD + px / TW, gx = tx * 16 - PAD + px % TW, ch = c * CCH + k;
-                const bool ok = e < NPX * CCH && (unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S && ch < Ck;
-                rin[i] = ok ? in_n[((size_t)gy * S + gx) * ldin + ch] : 0.f;
+                const int e = tv + 256 * i;
+                const int px = e / NQ, q = e % NQ;
+                const int gy = ty * 16 - PAD + px / TW, gx = tx * 16 - PAD + px % TW, ch = c * CCH + 4 * q;
+                const bool ok = e < NPX * NQ && (unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S && ch < Ck;
+                rin[i] = ok ? *reinterpret_cast<const float4*>(in_n + ((size_t)gy * S + gx) * ldin + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
         auto commit = [&](int buf) {
+            int tv = tid;
+            asm volatile("" : "+v"(tv));
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                const int e = tid + 256 * i;
-                if (e < NPX * CCH) s_in[buf * NPX * CCH + e] = rin[i];
+                const int e = tv + 256 * i;
+                if (e < NPX * NQ) {
+                    float* d = s_in + (size_t)(buf * CCH + 4 * (e % NQ)) * NPXP + e / NQ;
+                    d[0] = rin[i].x; d[NPXP] = rin[i].y; d[2 * NPXP] = rin[i].z; d[3 * NPXP] = rin[i].w;
+                }
             }
         };
         f32x4 acc[4];
@@ -209,49 +232,81 @@ void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict_
         __syncthreads();
         for (int c = 0; c < nchunk; ++c) {
             if (c + 1 < nchunk) fetch(c + 1);                 // in flight under this chunk's MFMAs
-            const float* si = s_in + (c & 1) * NPX * CCH;
-            // Round 5: all operands of a k-step are fetched FIRST - the KK weight values of this lane and the (4 + KS - 1) x KS input values
-            // its four tile rows share between their taps (40 + 25 LDS reads at KS = 5 instead of 100 + 25, none of them in front of the
-            // MFMA that needs it) - then the 4 KK MFMAs issue back to back; and a chunk is 8 channels = two such k-steps per barrier.  One wave
-            // per SIMD (the weight slice fills the LDS) cannot hide a read-then-multiply chain or a barrier behind another wave: the rolled
-            // 4-channel loop ran at 41 % of the fp32 matrix peak.
+            const float* si = s_in + (size_t)(c & 1) * CCH * NPXP + (size_t)kq * NPXP + (4 * wv) * TW + m;
+            const float* sw = s_w + (size_t)(c * CCH + kq) * 16 + m;
+            // All operands of a k-step (4 channels) are register-resident before its 4 KK MFMAs issue back to back: the KK weight values of
+            // this lane and the (4 + KS - 1) x KS input values its four tile rows share between their taps (40 + 25 LDS reads at KS = 5).
+            // Two operand sets: the reads of k-step h + 1 are issued before the MFMAs of k-step h, so that only the first k-step after a
+            // barrier waits for the LDS.  One wave per SIMD (the weight slice fills the LDS) cannot hide a read-then-multiply chain behind
+            // another wave.
+            auto ld = [&](int hh, float (&bw)[KK], float (&av)[RR][KS]) {
 #pragma unroll
-            for (int hh = 0; hh < NH; ++hh) {
-                const float* sw = s_w + (size_t)(c * CCH + 4 * hh + kq) * 16 + m;
-                float bw[KK], av[4 + KS - 1][KS];
+                for (int tap = 0; tap < KK; ++tap) bw[tap] = sw[(size_t)tap * Ckp * 16 + hh * 64];
 #pragma unroll
-                for (int tap = 0; tap < KK; ++tap) bw[tap] = sw[(size_t)tap * Ckp * 16];
+                for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
-                for (int rr = 0; rr < 4 + KS - 1; ++rr)
-#pragma unroll
-                    for (int kx = 0; kx < KS; ++kx) av[rr][kx] = si[((4 * wv + rr) * TW + m + kx) * CCH + 4 * hh + kq];
+                    for (int kx = 0; kx < KS; ++kx) av[rr][kx] = si[hh * 4 * NPXP + rr * TW + kx];
+            };
+            auto mm = [&](const float (&bw)[KK], const float (&av)[RR][KS]) {
 #pragma unroll
                 for (int tap = 0; tap < KK; ++tap) {
                     const int ky = tap / KS, kx = tap % KS;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + ky][kx], bw[tap], acc[r], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[tap], av[r + ky][kx], acc[r], 0, 0, 0);
+                }
+            };
+            // (hipcc's scheduler, left alone, sinks every read to just in front of its first use - a full LDS latency in front of every few
+            // MFMAs; the group barriers pin the pattern "two MFMAs of this k-step, one LDS read of the next")
+            auto interleave = [&]() {
+#pragma unroll
+                for (int i = 0; i < 2 * KK; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            float bwA[KK], avA[RR][KS], bwB[KK], avB[RR][KS];
+            ld(0, bwA, avA);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int hh = 0; hh < NH; hh += 2) {
+                if (hh + 1 < NH) ld(hh + 1, bwB, avB);
+                mm(bwA, avA);
+                interleave();
+                if (hh + 1 < NH) {
+                    if (hh + 2 < NH) ld(hh + 2, bwA, avA);
+                    mm(bwB, avB);
+                    interleave();
                 }
             }
             if (c + 1 < nchunk) commit((c + 1) & 1);
             __syncthreads();
         }
-        // D[pixel column 4 kq + i][channel m] of tile row 4 wv + r
-        const int co = cg * 16 + m;
-        if (co < Cn) {
-            const float bv = bias ? bias[co] : 0.f;
+        // D[channel 4 kq + v][pixel column m] of tile row 4 wv + r: one 16-byte store per lane and row
+        const int x = tx * 16 + m;
+        if (x < S && co0 < Cn) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int y = ty * 16 + 4 * wv + r;
                 if (y >= S) continue;
+                const size_t o = (((size_t)n * S + y) * S + x) * ldout + co0;
+                float v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int x = tx * 16 + 4 * kq + i;
-                    if (x >= S) continue;
-                    const size_t o = (((size_t)n * S + y) * S + x) * ldout + co;
-                    float v = acc[r][i] + bv;
-                    if (elu) v = gen_elu(v);
-                    if (aux) { const float a = aux[o]; v *= a > 0.f ? 1.f : a + 1.f; }
-                    out[o] = v;
+                for (int j = 0; j < 4; ++j) { v[j] = acc[r][j] + bv[j]; if (elu) v[j] = gen_elu(v[j]); }
+                if (vec_out) {
+                    if (aux) {
+                        const float4 a = *reinterpret_cast<const float4*>(aux + o);
+                        v[0] *= a.x > 0.f ? 1.f : a.x + 1.f; v[1] *= a.y > 0.f ? 1.f : a.y + 1.f;
+                        v[2] *= a.z > 0.f ? 1.f : a.z + 1.f; v[3] *= a.w > 0.f ? 1.f : a.w + 1.f;
+                    }
+                    *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (co0 + j >= Cn) continue;
+                        if (aux) { const float a = aux[o + j]; v[j] *= a > 0.f ? 1.f : a + 1.f; }
+                        out[o + j] = v[j];
+                    }
                 }
             }
         }
@@ -437,16 +492,29 @@ inline size_t gen_wgrad_rows_lds(int S, int Ci, int ldc, int Co, int k)
 
 inline unsigned gen_blocks(size_t total) { return (unsigned)((total + 255) / 256); }
 
-// LDS bytes of the MFMA form with chunks of cch channels: weight slice + two halo chunks; 0 = does not apply (stride 2, or the slice does not fit)
+// LDS bytes of the MFMA form with chunks of cch channels: weight slice + two channel-major halo chunks; 0 = does not apply (stride 2, or the
+// slice does not fit)
 inline size_t gen_mfma_lds_cch(int k, int Ck, int s, int cch)
 {
     if (s != 1 || (k != 3 && k != 5 && k != 7)) return 0;
-    const int Ckp = (Ck + cch - 1) / cch * cch, TW = 16 + k - 1;
-    const size_t b = ((size_t)k * k * Ckp * 16 + (size_t)2 * TW * TW * cch) * sizeof(float);
+    const int Ckp = (Ck + cch - 1) / cch * cch, TW = 16 + k - 1, NPXP = (TW * TW + 15) / 32 * 32 + 16;
+    const size_t b = ((size_t)k * k * Ckp * 16 + (size_t)2 * NPXP * cch) * sizeof(float);
     return b <= 160 * 1024 ? b : 0;
 }
-// (the 8-channel form where it fits, else the 4-channel form, else 0 = the scalar kernels)
-inline size_t gen_mfma_lds(int k, int Ck, int s) { const size_t b = gen_mfma_lds_cch(k, Ck, s, 8); return b ? b : gen_mfma_lds_cch(k, Ck, s, 4); }
+// chunk width: the smallest of 4 / 8 / 16 that covers the reduction channels, stepping down while the LDS does not fit; 0 = the scalar kernels
+inline int gen_mfma_cch(int k, int Ck, int s)
+{
+    int cch = Ck <= 4 ? 4 : Ck <= 8 ? 8 : 16;
+    while (cch >= 4 && !gen_mfma_lds_cch(k, Ck, s, cch)) cch >>= 1;
+    return cch >= 4 ? cch : 0;
+}
+// (16-byte staging: channel count and channel stride of the input must be multiples of 4)
+inline size_t gen_mfma_lds(int k, int Ck, int ldin, int s)
+{
+    if ((Ck & 3) || (ldin & 3)) return 0;
+    const int cch = gen_mfma_cch(k, Ck, s);
+    return cch ? gen_mfma_lds_cch(k, Ck, s, cch) : 0;
+}
 
 template <int KS, int CCH>
 hipError_t gen_mfma_launch_cch(hipStream_t st, const float* in, const float* wt, const float* bias, const float* aux, float* out, int N, int S,
@@ -468,9 +536,11 @@ template <int KS>
 hipError_t gen_mfma_launch(hipStream_t st, const float* in, const float* wt, const float* bias, const float* aux, float* out, int N, int S,
                            int Ck, int ldin, int Cn, int ldout, int flip, int sT, int sK, int sN, int elu, size_t lds)
 {
-    if (gen_mfma_lds_cch(KS, Ck, 1, 8) == lds)
-        return gen_mfma_launch_cch<KS, 8>(st, in, wt, bias, aux, out, N, S, Ck, ldin, Cn, ldout, flip, sT, sK, sN, elu, lds);
-    return gen_mfma_launch_cch<KS, 4>(st, in, wt, bias, aux, out, N, S, Ck, ldin, Cn, ldout, flip, sT, sK, sN, elu, lds);
+    switch (gen_mfma_cch(KS, Ck, 1)) {
+    case 16: return gen_mfma_launch_cch<KS, 16>(st, in, wt, bias, aux, out, N, S, Ck, ldin, Cn, ldout, flip, sT, sK, sN, elu, lds);
+    case 8: return gen_mfma_launch_cch<KS, 8>(st, in, wt, bias, aux, out, N, S, Ck, ldin, Cn, ldout, flip, sT, sK, sN, elu, lds);
+    default: return gen_mfma_launch_cch<KS, 4>(st, in, wt, bias, aux, out, N, S, Ck, ldin, Cn, ldout, flip, sT, sK, sN, elu, lds);
+    }
 }
 
 
@@ -485,7 +555,7 @@ hipError_t launch_gen_pack_weights(hipStream_t st, const float* w, int Co, int C
 hipError_t launch_gen_conv_fwd(hipStream_t st, const float* in, const float* wt, const float* bias, float* out, int N, int Si, int Ci,
                                int ldc, int Co, int k, int s, int elu)
 {
-    if (const size_t lds = gen_mfma_lds(k, Ci, s)) {
+    if (const size_t lds = gen_mfma_lds(k, Ci, ldc, s)) {
         // [tap][ci][co] pack: W(tap, k = ci, n = co)
         if (k == 3) return gen_mfma_launch<3>(st, in, wt, bias, nullptr, out, N, Si, Ci, ldc, Co, Co, 0, Ci * Co, Co, 1, elu, lds);
         if (k == 5) return gen_mfma_launch<5>(st, in, wt, bias, nullptr, out, N, Si, Ci, ldc, Co, Co, 0, Ci * Co, Co, 1, elu, lds);
@@ -500,7 +570,7 @@ hipError_t launch_gen_conv_fwd(hipStream_t st, const float* in, const float* wt,
 hipError_t launch_gen_conv_dgrad(hipStream_t st, const float* dout, const float* wt, const float* aux, float* din, int N, int Si, int Ci,
                                  int ldi, int Co, int k, int s)
 {
-    if (const size_t lds = gen_mfma_lds(k, Co, s)) {
+    if (const size_t lds = gen_mfma_lds(k, Co, Co, s)) {
         // correlation of dout with the flipped kernel: reduction over co, W(tap, k = co, n = ci) = wt[(KK - 1 - tap)][ci][co]
         if (k == 3) return gen_mfma_launch<3>(st, dout, wt, nullptr, aux, din, N, Si, Co, Co, Ci, ldi, 1, ldi * Co, 1, Co, 0, lds);
         if (k == 5) return gen_mfma_launch<5>(st, dout, wt, nullptr, aux, din, N, Si, Co, Co, Ci, ldi, 1, ldi * Co, 1, Co, 0, lds);
