@@ -334,6 +334,7 @@ hipError_t launch_enc_gather_grad(hipStream_t st, const float* g17, int O, int n
 
 // kernels_generic.hip: fallback fp32 convs for any odd kernel size / channel count (correctness path, see the file header)
 constexpr int GEN_WGRAD_SLICES = 64;
+constexpr int GEN_WGRAD_OUT_SLICES_MAX = 512;   // row slices of the 4-output-channel GEMM form (one per resident block)
 constexpr int GEN_WGRAD_SLICES_MAX = 128;  // the row-staged form sizes its slices to the chip (two blocks per CU): scratch is sized for this many
 hipError_t launch_gen_pack_weights(hipStream_t st, const float* w, int Co, int Ci, int k, float* wt);
 hipError_t launch_gen_conv_fwd(hipStream_t st, const float* in, const float* wt, const float* bias, float* out, int N, int Si, int Ci,

@@ -445,7 +445,7 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
     }
     if ((h->generic || h->gen_ref) && mode == 1) {
         size_t scr = 0;
-        if (h->generic) scr = std::max(gen_wgrad_scratch_floats(L + 2, Cd, h->kd), gen_wgrad_scratch_floats(Cd, Cd, h->kd));
+        if (h->generic) scr = std::max(gen_wgrad_scratch_floats(Cd, 4, h->kd), gen_wgrad_scratch_floats(Cd, Cd, h->kd));
         if (h->gen_ref) scr = std::max(scr, std::max(gen_wgrad_scratch_floats(17, Cr, h->kr), gen_wgrad_scratch_floats(Cr, Cr, h->kr)));
         b.gen_scr = a.take<float>(scr);
     }

@@ -116,15 +116,24 @@ __global__ void gen_conv_wgrad_partial_kernel(const float* __restrict__ in, cons
     part[idx] = acc;
 }
 
-// gw[co][ci_dst][tap] += alpha * sum_slice partial (OIHW, ci < Ci_dst kept), gb[co] += alpha * sum_slice partial bias
-__global__ void gen_conv_wgrad_reduce_kernel(const float* __restrict__ part, int nslice, int Ci, int Ci_dst, int Co, int kk, float alpha,
-                                             float* __restrict__ gw, float* __restrict__ gb)
+// gw[co][ci_dst][tap] += alpha * sum_slice partial (OIHW, ci < Ci_dst kept), gb[co] += alpha * sum_slice partial bias.  A block of 256 threads
+// reduces 32 consecutive elements: eight thread groups take every eighth slice, their partial sums are added in a fixed order (one thread per
+// element walking 512 slices was 0.12 ms for the output conv's 13 MB of partials).
+__global__ __launch_bounds__(256) void gen_conv_wgrad_reduce_kernel(const float* __restrict__ part, int nslice, int Ci, int Ci_dst, int Co, int kk,
+                                                                    float alpha, float* __restrict__ gw, float* __restrict__ gb)
 {
+    __shared__ float red[8][32];
     const int per = kk * Ci * Co + Co;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= per) return;
+    const int el = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
     float acc = 0.f;
-    for (int sl = 0; sl < nslice; ++sl) acc += part[(size_t)sl * per + e];
+    if (e < per)
+        for (int sl = sg; sl < nslice; sl += 8) acc += part[(size_t)sl * per + e];
+    red[sg][el] = acc;
+    __syncthreads();
+    if (sg != 0 || e >= per) return;
+#pragma unroll
+    for (int g2 = 1; g2 < 8; ++g2) acc += red[g2][el];
     if (e >= kk * Ci * Co) { if (gb) gb[e - kk * Ci * Co] += alpha * acc; return; }
     const int co = e % Co, ci = (e / Co) % Ci, tap = e / (Co * Ci);
     if (ci < Ci_dst) gw[((size_t)co * Ci_dst + ci) * kk + tap] += alpha * acc;
@@ -154,6 +163,10 @@ __global__ void gen_identity_kernel(float* __restrict__ m, int rows, int L)
 //   W(tap, k, n) = wt[tapidx * sT + k * sK + n * sN]:  forward tapidx = tap, (sT, sK, sN) = (Ci Co, Co, 1) on the pack [tap][ci][co];
 //   data gradient: the correlation with the flipped kernel, tapidx = KS^2 - 1 - tap, reduction over co, (sT, sK, sN) = (ldi Co, 1, Co).
 // =====================================================================================================================================
+#ifdef IODINE_TILE_PROF
+__device__ unsigned g_gen_prof[TP_MAXBLK * 8];
+#endif
+
 template <int KS, int CCH>                                     // CCH: reduction channels per staged chunk (16, 8 or 4: the largest that fits the LDS)
 __global__ __launch_bounds__(256)
 void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
@@ -172,7 +185,7 @@ void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float smem_g[];
     const int Ckp = (Ck + CCH - 1) / CCH * CCH, nchunk = Ckp / CCH;
     float* s_w = smem_g;                                      // [KK][Ckp][16]
-    float* s_in = smem_g + (size_t)KK * Ckp * 16;             // [2][CCH][NPXP]
+    float* s_in = smem_g + (size_t)KK * Ckp * 16;             // [2][CCH][NPXP] + a dump area of 3 NPXP + 1 words (see commit)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // block -> (channel group, tile sequence).  Blocks b, b + 8, b + 16 ... share an XCD: the ncg blocks that need the same input tile at
     // the same time are put on ONE XCD (one L2 fetches the tile) whenever the counts divide; otherwise consecutive blocks take the groups.
@@ -181,13 +194,19 @@ void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict_
     if (nb % 8 == 0) { const int x = blockIdx.x & 7, j = blockIdx.x >> 3; cg = j % ncg; pb = (j / ncg) * 8 + x; }
     else { cg = blockIdx.x % ncg; pb = blockIdx.x / ncg; }
     if (pb >= nb) return;                                     // (grid = ncg * nb exactly; defensive)
-    // ---- this block's weight slice -> LDS, once ----
-    for (int e = tid; e < KK * Ckp * 16; e += 256) {
-        const int n = e & 15, k = (e >> 4) % Ckp, tap = (e >> 4) / Ckp;
-        const int co = cg * 16 + n;
-        float v = 0.f;
-        if (k < Ck && co < Cn) v = wt[(size_t)(flip ? KK - 1 - tap : tap) * sT + (size_t)k * sK + (size_t)co * sN];
-        s_w[e] = v;
+    TP_DECL;
+    // ---- this block's weight slice -> LDS, once ([tap][reduction channel][16]: element e = row * 16 + n, row = tap * Ckp + k) ----
+    {
+        const int n = tid & 15, co = cg * 16 + n;
+        int k = tid >> 4, tap = 0;
+        while (k >= Ckp) { k -= Ckp; ++tap; }
+        for (int e = tid; e < KK * Ckp * 16; e += 256) {
+            float v = 0.f;
+            if (k < Ck && co < Cn) v = wt[(size_t)(flip ? KK - 1 - tap : tap) * sT + (size_t)k * sK + (size_t)co * sN];
+            s_w[e] = v;
+            k += 16;
+            while (k >= Ckp) { k -= Ckp; ++tap; }
+        }
     }
     const int m = lane & 15, kq = lane >> 4;
     const int co0 = cg * 16 + 4 * kq;                         // the four output channels of this lane (D rows 4 kq + v, column = pixel m)
@@ -195,122 +214,167 @@ void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict_
 #pragma unroll
     for (int v = 0; v < 4; ++v) bv[v] = (bias && co0 + v < Cn) ? bias[co0 + v] : 0.f;
     const bool vec_out = (ldout & 3) == 0 && co0 + 3 < Cn;
+    // ---- staging table of this thread, the same for every tile: element i = 16 bytes (channel quad q of halo pixel (py, px)) ----
+    // One wave per SIMD: every VALU instruction of the staging code is exposed, so the (pixel, quad) arithmetic is done once per kernel, the
+    // bounds mask once per tile, and a chunk's loads are an add and a predicated 16-byte load each (it was 1.6 k cycles per chunk, 12 %).
+    int rel[NLD], pyx[NLD], lw[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 256 * i, px = e / NQ, q = e % NQ, py = px / TW, pxx = px % TW;
+        rel[i] = (py * S + pxx) * ldin + 4 * q;
+        pyx[i] = e < NPX * NQ ? (py | pxx << 8 | q << 16) : (255 | 255 << 8);   // (255: never inside)
+        lw[i] = 4 * q * NPXP + px;
+    }
     float4 rin[NLD];
-    for (int t = pb; t < ntiles; t += nb) {
+    // tile being fetched: element offset of its halo origin, bounds mask of the staging table
+    long long f_base = 0;
+    unsigned f_mask = 0;
+    auto setup_fetch = [&](int t) {
         const int tx = t % tiles, ty = (t / tiles) % tiles, n = t / (tiles * tiles);
-        const float* in_n = in + (size_t)n * S * S * ldin;
-        auto fetch = [&](int c) {
-            int tv = tid;
-            asm volatile("" : "+v"(tv));                       // (element -> (pixel, quad) arithmetic recomputed per chunk, not kept in registers)
+        const int gy0 = ty * 16 - PAD, gx0 = tx * 16 - PAD;
+        f_base = (((long long)n * S + gy0) * S + gx0) * ldin;
+        f_mask = 0;
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int e = tv + 256 * i;
-                const int px = e / NQ, q = e % NQ;
-                const int gy = ty * 16 - PAD + px / TW, gx = tx * 16 - PAD + px % TW, ch = c * CCH + 4 * q;
-                const bool ok = e < NPX * NQ && (unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S && ch < Ck;
-                rin[i] = ok ? *reinterpret_cast<const float4*>(in_n + ((size_t)gy * S + gx) * ldin + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        };
-        auto commit = [&](int buf) {
-            int tv = tid;
-            asm volatile("" : "+v"(tv));
+        for (int i = 0; i < NLD; ++i) {
+            const int gy = gy0 + (pyx[i] & 255), gx = gx0 + ((pyx[i] >> 8) & 255);
+            if ((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S) f_mask |= 1u << i;
+        }
+    };
+    auto fetch = [&](int c) {
+        const float* src = in + f_base + c * CCH;
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int e = tv + 256 * i;
-                if (e < NPX * NQ) {
-                    float* d = s_in + (size_t)(buf * CCH + 4 * (e % NQ)) * NPXP + e / NQ;
-                    d[0] = rin[i].x; d[NPXP] = rin[i].y; d[2 * NPXP] = rin[i].z; d[3 * NPXP] = rin[i].w;
-                }
-            }
-        };
-        f32x4 acc[4];
+        for (int i = 0; i < NLD; ++i) {
+            const bool ok = (f_mask >> i & 1) && c * CCH + 4 * (pyx[i] >> 16) < Ck;
+            rin[i] = ok ? *reinterpret_cast<const float4*>(src + rel[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](int buf) {
+        float* dst = s_in + (size_t)buf * CCH * NPXP;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();                                      // weights staged / previous tile's last chunk consumed
+        for (int i = 0; i < NLD; ++i) {
+            // (branch-free: the threads past the end of the table write to a dump area behind the buffers - a branch would split the
+            // scheduling region the writes are interleaved with the MFMAs in)
+            float* d = (i < NLD - 1 || tid + 256 * i < NPX * NQ) ? dst + lw[i] : s_in + (size_t)2 * CCH * NPXP;
+            d[0] = rin[i].x; d[NPXP] = rin[i].y; d[2 * NPXP] = rin[i].z; d[3 * NPXP] = rin[i].w;
+        }
+    };
+    f32x4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int t = pb, c = 0, buf = 0;
+    TP_STAMP(0);
+    if (t < ntiles) {                                         // (uniform over the block)
+        setup_fetch(t);
         fetch(0);
         commit(0);
-        __syncthreads();
-        for (int c = 0; c < nchunk; ++c) {
-            if (c + 1 < nchunk) fetch(c + 1);                 // in flight under this chunk's MFMAs
-            const float* si = s_in + (size_t)(c & 1) * CCH * NPXP + (size_t)kq * NPXP + (4 * wv) * TW + m;
-            const float* sw = s_w + (size_t)(c * CCH + kq) * 16 + m;
-            // All operands of a k-step (4 channels) are register-resident before its 4 KK MFMAs issue back to back: the KK weight values of
-            // this lane and the (4 + KS - 1) x KS input values its four tile rows share between their taps (40 + 25 LDS reads at KS = 5).
-            // Two operand sets: the reads of k-step h + 1 are issued before the MFMAs of k-step h, so that only the first k-step after a
-            // barrier waits for the LDS.  One wave per SIMD (the weight slice fills the LDS) cannot hide a read-then-multiply chain behind
-            // another wave.
-            auto ld = [&](int hh, float (&bw)[KK], float (&av)[RR][KS]) {
+    }
+    __syncthreads();                                          // weights and the first chunk staged
+    TP_STAMP(1);
+    // one flat sequence of (tile, chunk) items: the next item's chunk - of the NEXT tile after a tile's last chunk - is in flight under this
+    // item's MFMAs and is written to the other LDS buffer between the MFMAs of the item's last k-step
+    while (t < ntiles) {
+        const bool last_chunk = c + 1 == nchunk;
+        const int tn = last_chunk ? t + nb : t, cn = last_chunk ? 0 : c + 1;
+        if (tn < ntiles) {
+            if (last_chunk) setup_fetch(tn);
+            fetch(cn);
+        }
+        TP_STAMP(2);
+        const float* si = s_in + (size_t)buf * CCH * NPXP + (size_t)kq * NPXP + (4 * wv) * TW + m;
+        const float* sw = s_w + (size_t)(c * CCH + kq) * 16 + m;
+        // All operands of a k-step (4 channels) are register-resident before its 4 KK MFMAs issue back to back: the KK weight values of
+        // this lane and the (4 + KS - 1) x KS input values its four tile rows share between their taps (40 + 25 LDS reads at KS = 5).
+        // Two operand sets: the reads of k-step h + 1 are issued between the MFMAs of k-step h, so that only the first k-step after a
+        // barrier waits for the LDS.  One wave per SIMD (the weight slice fills the LDS) cannot hide a read-then-multiply chain behind
+        // another wave.
+        auto ld = [&](int hh, float (&bw)[KK], float (&av)[RR][KS]) {
 #pragma unroll
-                for (int tap = 0; tap < KK; ++tap) bw[tap] = sw[(size_t)tap * Ckp * 16 + hh * 64];
+            for (int tap = 0; tap < KK; ++tap) bw[tap] = sw[(size_t)tap * Ckp * 16 + hh * 64];
 #pragma unroll
-                for (int rr = 0; rr < RR; ++rr)
+            for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
-                    for (int kx = 0; kx < KS; ++kx) av[rr][kx] = si[hh * 4 * NPXP + rr * TW + kx];
-            };
-            auto mm = [&](const float (&bw)[KK], const float (&av)[RR][KS]) {
+                for (int kx = 0; kx < KS; ++kx) av[rr][kx] = si[hh * 4 * NPXP + rr * TW + kx];
+        };
+        auto mm = [&](const float (&bw)[KK], const float (&av)[RR][KS]) {
 #pragma unroll
-                for (int tap = 0; tap < KK; ++tap) {
-                    const int ky = tap / KS, kx = tap % KS;
+            for (int tap = 0; tap < KK; ++tap) {
+                const int ky = tap / KS, kx = tap % KS;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[tap], av[r + ky][kx], acc[r], 0, 0, 0);
-                }
-            };
-            // (hipcc's scheduler, left alone, sinks every read to just in front of its first use - a full LDS latency in front of every few
-            // MFMAs; the group barriers pin the pattern "two MFMAs of this k-step, one LDS read of the next")
-            auto interleave = [&]() {
+                for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[tap], av[r + ky][kx], acc[r], 0, 0, 0);
+            }
+        };
+        // (hipcc's scheduler, left alone, sinks every read to just in front of its first use - a full LDS latency in front of every few
+        // MFMAs; the group barriers pin the pattern "MFMAs of this k-step, one LDS access of the next k-step / the next chunk")
+        auto kstep = [&](auto hh_c, float (&bw)[KK], float (&av)[RR][KS], float (&bwn)[KK], float (&avn)[RR][KS]) {
+            constexpr int hh = decltype(hh_c)::value;
+            if constexpr (hh + 1 < NH) {
+                ld(hh + 1, bwn, avn);
+                mm(bw, av);
 #pragma unroll
-                for (int i = 0; i < 2 * KK; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                for (int i = 0; i < KK + RR * KS; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            float bwA[KK], avA[RR][KS], bwB[KK], avB[RR][KS];
-            ld(0, bwA, avA);
+            } else {
+                commit(buf ^ 1);                              // (no next item: stale registers into a buffer nobody reads again)
+                mm(bw, av);
+#pragma unroll
+                for (int i = 0; i < 4 * NLD; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
+        };
+        float bwA[KK], avA[RR][KS], bwB[KK], avB[RR][KS];
+        ld(0, bwA, avA);
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(std::integral_constant<int, 0>{}, bwA, avA, bwB, avB);
+        if constexpr (NH > 1) kstep(std::integral_constant<int, 1>{}, bwB, avB, bwA, avA);
+        if constexpr (NH > 2) {
+            kstep(std::integral_constant<int, 2>{}, bwA, avA, bwB, avB);
+            kstep(std::integral_constant<int, 3>{}, bwB, avB, bwA, avA);
+        }
+        TP_STAMP(3);
+        __syncthreads();
+        TP_STAMP(5);
+        if (last_chunk) {
+            // D[channel 4 kq + v][pixel column m] of tile row 4 wv + r: one 16-byte store per lane and row
+            const int tx = t % tiles, ty = (t / tiles) % tiles, n = t / (tiles * tiles);
+            const int x = tx * 16 + m;
+            if (x < S && co0 < Cn) {
 #pragma unroll
-            for (int hh = 0; hh < NH; hh += 2) {
-                if (hh + 1 < NH) ld(hh + 1, bwB, avB);
-                mm(bwA, avA);
-                interleave();
-                if (hh + 1 < NH) {
-                    if (hh + 2 < NH) ld(hh + 2, bwA, avA);
-                    mm(bwB, avB);
-                    interleave();
+                for (int r = 0; r < 4; ++r) {
+                    const int y = ty * 16 + 4 * wv + r;
+                    if (y >= S) continue;
+                    const size_t o = (((size_t)n * S + y) * S + x) * ldout + co0;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = acc[r][j] + bv[j]; if (elu) v[j] = elu1_fast(v[j]); }
+                    if (vec_out) {
+                        if (aux) {
+                            const float4 a = *reinterpret_cast<const float4*>(aux + o);
+                            v[0] *= elu1_grad_from_out(a.x); v[1] *= elu1_grad_from_out(a.y);
+                            v[2] *= elu1_grad_from_out(a.z); v[3] *= elu1_grad_from_out(a.w);
+                        }
+                        *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (co0 + j >= Cn) continue;
+                            if (aux) v[j] *= elu1_grad_from_out(aux[o + j]);
+                            out[o + j] = v[j];
+                        }
+                    }
                 }
             }
-            if (c + 1 < nchunk) commit((c + 1) & 1);
-            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            TP_STAMP(6);
         }
-        // D[channel 4 kq + v][pixel column m] of tile row 4 wv + r: one 16-byte store per lane and row
-        const int x = tx * 16 + m;
-        if (x < S && co0 < Cn) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = ty * 16 + 4 * wv + r;
-                if (y >= S) continue;
-                const size_t o = (((size_t)n * S + y) * S + x) * ldout + co0;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] = acc[r][j] + bv[j]; if (elu) v[j] = gen_elu(v[j]); }
-                if (vec_out) {
-                    if (aux) {
-                        const float4 a = *reinterpret_cast<const float4*>(aux + o);
-                        v[0] *= a.x > 0.f ? 1.f : a.x + 1.f; v[1] *= a.y > 0.f ? 1.f : a.y + 1.f;
-                        v[2] *= a.z > 0.f ? 1.f : a.z + 1.f; v[3] *= a.w > 0.f ? 1.f : a.w + 1.f;
-                    }
-                    *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (co0 + j >= Cn) continue;
-                        if (aux) { const float a = aux[o + j]; v[j] *= a > 0.f ? 1.f : a + 1.f; }
-                        out[o + j] = v[j];
-                    }
-                }
-            }
-        }
+        t = tn; c = cn; buf ^= 1;
     }
+    TP_FLUSH(g_gen_prof);
 }
 
 // Weight gradient, stride 1: dW[tap][ci][co] = sum_px in[px + tap][ci] * dout[px][co] as D[32 ci x 32 co] += A[32 x 2 px] B[2 px x 32]
@@ -373,6 +437,12 @@ void gen_wgrad_mfma_kernel(const float* __restrict__ in, const float* __restrict
     }
 }
 
+constexpr int GEN_ROWS_MAXV = 16, GEN_ROWS_U = 4;
+// geometry of gen_wgrad_rows_kernel's staged rows: operand blocks of GEN_ROWS_U pixel pairs, an even number of them per row
+__host__ __device__ inline int gen_rows_nblk(int S) { const int nb = ((S + 1) / 2 + GEN_ROWS_U - 1) / GEN_ROWS_U; return (nb + 1) & ~1; }
+__host__ __device__ inline int gen_rows_wp(int S, int k) { const int w = 2 * GEN_ROWS_U * gen_rows_nblk(S) + k - 1 + 1; return w > S + 2 * (k / 2) + 1 ? w : S + 2 * (k / 2) + 1; }
+__host__ __device__ inline int gen_rows_sd(int S) { const int w = 2 * GEN_ROWS_U * gen_rows_nblk(S) + 1; return w > S + 1 ? w : S + 1; }
+
 // Round 5: the same weight gradient with the operands staged ONCE per kernel ROW.  The kernel above gives every tap its own blocks, each
 // streaming both tensors from global memory again (KS^2 = 25 passes over `in` and `dout` at KS = 5: 5.9 GB of L2 / HBM traffic per launch at
 // the CLEVR shapes with 28 slot-images, and the load -> 8 MFMAs -> load chain hides its latency only through occupancy: 34 % of the fp32 matrix
@@ -386,14 +456,18 @@ void gen_wgrad_rows_kernel(const float* __restrict__ in, const float* __restrict
                            int ldc, int Co, int nslice)
 {
     constexpr int KK = KS * KS, PAD = KS / 2;
-    constexpr int MAXV = 16;                                   // float4 per thread and staged row pair (launcher: fits)
+    constexpr int MAXV = GEN_ROWS_MAXV;                        // 16-byte loads per thread and staged row pair (launcher: fits)
+    constexpr int U = GEN_ROWS_U;                              // pixel pairs per operand block: 2 U + KS - 1 input values + U gradient values feed U KS MFMAs
+    constexpr int NAW = 2 * U + KS - 1;
     extern __shared__ __attribute__((aligned(16))) float smem_gw[];
     const int ky = blockIdx.x % KS, slice = (blockIdx.x / KS) % nslice, pgrp = blockIdx.x / (KS * nslice);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, kh = lane >> 5;
     const int nit = (Ci + 31) / 32, nct = (Co + 31) / 32, npair = nit * nct;
-    const int Wp = S + 2 * PAD + 1, Sd = S + 1;               // staged pixels per row (+1: the pixel pair of an odd S reads a zero)
+    const int nblk = gen_rows_nblk(S);                         // operand blocks per row (even: two register sets alternate)
+    const int Wp = gen_rows_wp(S, KS), Sd = gen_rows_sd(S);    // staged pixels per row (zero margins; the last block may run past the row)
     float* s_a = smem_gw;                                      // [nit][Wp][32]
-    float* s_d = smem_gw + (size_t)nit * Wp * 32;              // [nct][Sd][32]
+    float* s_d = smem_gw + (size_t)nit * Wp * 32;              // [nct][Sd][32], then a 16-byte dump slot
+    const int dump = (nit * Wp + nct * Sd) * 32;
     const int pair = pgrp * 4 + wv;
     const bool wave_on = pair < npair;
     const int cit = wave_on ? pair / nct : 0, cot = wave_on ? pair % nct : 0;
@@ -402,12 +476,29 @@ void gen_wgrad_rows_kernel(const float* __restrict__ in, const float* __restrict
     const int per = KK * Ci * Co + Co;
     const long long R = (long long)N * S;
     const long long r0 = R * slice / nslice, r1 = R * (slice + 1) / nslice;
-    // zero the planes once: channel pads, pixel margins and the extra pixel stay zero (staging only writes real elements)
-    for (int e = tid; e < (nit * Wp + nct * Sd) * 32; e += 256) smem_gw[e] = 0.f;
+    // zero the planes once: channel pads, pixel margins and the pixels past the row stay zero (staging only writes real elements)
+    for (int e = tid; e < dump + 4; e += 256) smem_gw[e] = 0.f;
 
-    const int A4 = (Ci + 3) / 4, D4 = Co / 4;                 // float4 per pixel (Ci rounded up: the row stride covers the pad channels)
-    const int na = S * A4, nd = S * D4;                       // float4 of a staged row (real pixels only)
-    float4 rv[MAXV];
+    // staging table of this thread (the same for every row): entries [0, kA) are 16-byte pieces of the input row, [kA, kA + kD) of the gradient
+    // row; byte offset within the row (0x80000000 = none: the buffer load returns zeros) and LDS word offset (none: the dump slot).  A row is then
+    // MAXV buffer loads without any address arithmetic, and a row outside the image an empty buffer.
+    const int A4 = (Ci + 3) / 4, D4 = Co / 4;                 // 16-byte pieces per pixel (Ci rounded up: the row stride covers the pad channels)
+    const int na = S * A4, nd = S * D4, kA = (na + 255) / 256;
+    unsigned voff[MAXV];
+    int loff[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        voff[k] = 0x80000000u; loff[k] = dump;
+        if (k < kA) {
+            const int e = tid + 256 * k, x = e / A4, c4 = e % A4;
+            if (e < na) { voff[k] = (unsigned)((x * ldc + c4 * 4) * 4); loff[k] = ((c4 >> 3) * Wp + x + PAD) * 32 + (c4 & 7) * 4; }
+        } else {
+            const int f = tid + 256 * (k - kA), x = f / D4, c4 = f % D4;
+            if (f < nd) { voff[k] = (unsigned)((x * Co + c4 * 4) * 4); loff[k] = nit * Wp * 32 + ((c4 >> 3) * Sd + x) * 32 + (c4 & 7) * 4; }
+        }
+    }
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    u32x4_ rv[MAXV];
     auto fetch = [&](long long row) {
         const int y = (int)(row % S);
         const long long n = row / S;
@@ -415,26 +506,17 @@ void gen_wgrad_rows_kernel(const float* __restrict__ in, const float* __restrict
         const bool rowv = (unsigned)iy < (unsigned)S;
         const float* ip = in + ((size_t)n * S + (rowv ? iy : 0)) * S * (size_t)ldc;
         const float* dp = dout + ((size_t)n * S + y) * S * (size_t)Co;
-        int tv = tid;
-        asm volatile("" : "+v"(tv));                           // (the element -> (pixel, quad) arithmetic is recomputed per row: hoisted it spills)
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ip), 0, rowv ? S * ldc * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dp), 0, S * Co * 4, 0x00020000);
 #pragma unroll
         for (int k = 0; k < MAXV; ++k) {
-            const int e = tv + 256 * k;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < na) { if (rowv) v = *reinterpret_cast<const float4*>(ip + (size_t)(e / A4) * ldc + (e % A4) * 4); }
-            else if (e < na + nd) { const int f = e - na; v = *reinterpret_cast<const float4*>(dp + (size_t)(f / D4) * Co + (f % D4) * 4); }
-            rv[k] = v;
+            if (k < kA) rv[k] = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)voff[k], 0, 0);    // (uniform branch)
+            else rv[k] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)voff[k], 0, 0);
         }
     };
     auto commit = [&]() {
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
 #pragma unroll
-        for (int k = 0; k < MAXV; ++k) {
-            const int e = tv + 256 * k;
-            if (e < na) { const int x = e / A4, c4 = e % A4; *reinterpret_cast<float4*>(s_a + ((size_t)(c4 >> 3) * Wp + x + PAD) * 32 + (c4 & 7) * 4) = rv[k]; }
-            else if (e < na + nd) { const int f = e - na, x = f / D4, c4 = f % D4; *reinterpret_cast<float4*>(s_d + ((size_t)(c4 >> 3) * Sd + x) * 32 + (c4 & 7) * 4) = rv[k]; }
-        }
+        for (int k = 0; k < MAXV; ++k) *reinterpret_cast<u32x4_*>(smem_gw + loff[k]) = rv[k];
     };
     f32x16 acc[KS];
 #pragma unroll
@@ -443,6 +525,32 @@ void gen_wgrad_rows_kernel(const float* __restrict__ in, const float* __restrict
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
     float bsum = 0.f;
     const bool do_bias = ky == 0 && cit == 0 && wave_on;
+    const float* ap = s_a + ((size_t)cit * Wp + kh) * 32 + li;
+    const float* dpl = s_d + ((size_t)cot * Sd + kh) * 32 + li;
+    // operands of block bq: gradient values of its U pixel pairs, input values of the 2 U + KS - 1 pixels they touch (tap kx of pair u: aw[2 u + kx])
+    auto ld = [&](int bq, float (&aw)[NAW], float (&bw)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) bw[u] = dpl[(size_t)(2 * U * bq + 2 * u) * 32];
+#pragma unroll
+        for (int j = 0; j < NAW; ++j) aw[j] = ap[(size_t)(2 * U * bq + j) * 32];
+    };
+    auto mm = [&](const float (&aw)[NAW], const float (&bw)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[2 * u + kx], bw[u], acc[kx], 0, 0, 0);
+            bsum += bw[u];
+        }
+    };
+    // (the group barriers pin "one MFMA of this block, one LDS read of the next": left alone, hipcc puts every read right in front of its use)
+    auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < NAW + U; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     if (r0 < r1) fetch(r0);
     __syncthreads();                                           // planes zeroed
     for (long long row = r0; row < r1; ++row) {
@@ -451,17 +559,16 @@ void gen_wgrad_rows_kernel(const float* __restrict__ in, const float* __restrict
         if (row + 1 < r1) fetch(row + 1);                      // in flight under this row's MFMAs
         const int iy = (int)(row % S) + ky - PAD;
         if (wave_on && ((unsigned)iy < (unsigned)S || do_bias)) {
-            const float* ap = s_a + ((size_t)cit * Wp + kh) * 32 + li;
-            const float* dp = s_d + ((size_t)cot * Sd + kh) * 32 + li;
-#pragma unroll 4
-            for (int x0 = 0; x0 < S; x0 += 2) {
-                const float b = dp[(size_t)x0 * 32];
-                float a[KS];
-#pragma unroll
-                for (int kx = 0; kx < KS; ++kx) a[kx] = ap[(size_t)(x0 + kx) * 32];
-#pragma unroll
-                for (int kx = 0; kx < KS; ++kx) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kx], b, acc[kx], 0, 0, 0);
-                bsum += b;
+            float awA[NAW], bwA[U], awB[NAW], bwB[U];
+            ld(0, awA, bwA);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int bq = 0; bq < nblk; bq += 2) {
+                ld(bq + 1, awB, bwB);
+                mm(awA, bwA);
+                interleave();
+                ld(bq + 2, awA, bwA);                          // (past the last block: never multiplied; LDS reads past the allocation return 0)
+                mm(awB, bwB);
+                interleave();
             }
         }
         __syncthreads();                                       // every wave is done with the planes
@@ -481,12 +588,141 @@ void gen_wgrad_rows_kernel(const float* __restrict__ in, const float* __restrict
     }
 }
 
+// Round 5: weight gradient of a conv with FOUR output channels (the decoder's output conv, iodine.py:422,435) in GEMM form:
+//     dW[tap][ci][co] = sum_q in[q][ci] * g[q - (tap - centre)][co]        rows ci, columns j = tap * 4 + co (4 KS^2 of them), K = pixels
+// The tap shift sits on the 4-channel gradient g - a KS-row window with zero margins, 10 KB of LDS at S = 128 - and the wide operand needs no
+// halo: 4 KS^2 / 32 column tiles x Ci / 32 row tiles = 8 MFMAs (v_mfma_f32_32x32x2_f32) per pixel pair at 5 x 5 x 64, where the row-staged
+// kernel above, with its 4 output channels padded to a 32-wide tile, issues 50 (0.81 ms per launch at the CLEVR shapes for 6 GFLOP).
+// A block owns a slice of image rows; per row it stages the input row (planes of 32 channels) and the KS gradient rows around it, the next row in
+// flight in registers; its four waves share the (row tile, column tile) pairs, NP per wave.  Partial tiles in the layout of
+// gen_conv_wgrad_reduce_kernel; the bias partial comes from the centre tap's columns (g itself).
+template <int KS, int NP>
+__global__ __launch_bounds__(256, 2)
+void gen_wgrad_out_kernel(const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ part, int N, int S, int Ci, int ldc,
+                          int nslice)
+{
+    constexpr int KK = KS * KS, PAD = KS / 2, NJ = 4 * KK, NCT = (NJ + 31) / 32, Co = 4;
+    constexpr int MAXV = 16;
+    extern __shared__ __attribute__((aligned(16))) float smem_go[];
+    const int slice = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, kh = lane >> 5;
+    const int nit = (Ci + 31) / 32, npair = nit * NCT;
+    const int Wa = S + 1, Wg = S + 2 * PAD + 2;
+    float* s_a = smem_go;                                      // [nit][Wa][32]
+    float* s_g = smem_go + (size_t)nit * Wa * 32;              // [KS][Wg][4]
+    const int per = KK * Ci * Co + Co;
+    const long long R = (long long)N * S;
+    const long long r0 = R * slice / nslice, r1 = R * (slice + 1) / nslice;
+    for (int e = tid; e < nit * Wa * 32 + KS * Wg * 4; e += 256) smem_go[e] = 0.f;
+
+    const int A4 = Ci / 4;
+    const int na = S * A4, ng = KS * S;
+    float4 rv[MAXV];
+    auto fetch = [&](long long row) {
+        const int y = (int)(row % S);
+        const long long n = row / S;
+        const float* ip = in + ((size_t)n * S + y) * S * (size_t)ldc;
+        const float* gp = g + (size_t)n * S * S * 4;
+        int tv = tid;
+        asm volatile("" : "+v"(tv));                           // (element arithmetic recomputed per row: hoisted it spills)
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int e = tv + 256 * k;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < na) v = *reinterpret_cast<const float4*>(ip + (size_t)(e / A4) * ldc + (e % A4) * 4);
+            else if (e < na + ng) {
+                const int f = e - na, r = f / S, x = f - r * S, yy = y - PAD + r;
+                if ((unsigned)yy < (unsigned)S) v = *reinterpret_cast<const float4*>(gp + ((size_t)yy * S + x) * 4);
+            }
+            rv[k] = v;
+        }
+    };
+    auto commit = [&]() {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int e = tv + 256 * k;
+            if (e < na) { const int x = e / A4, c4 = e % A4; *reinterpret_cast<float4*>(s_a + ((size_t)(c4 >> 3) * Wa + x) * 32 + (c4 & 7) * 4) = rv[k]; }
+            else if (e < na + ng) { const int f = e - na, r = f / S, x = f - r * S; *reinterpret_cast<float4*>(s_g + ((size_t)r * Wg + x + PAD) * 4) = rv[k]; }
+        }
+    };
+    // the pairs of this wave: p = wv + 4 i -> (row tile cit, column tile ct); column j = ct * 32 + li = tap * 4 + co reads the gradient at
+    // staged row KS - 1 - ky, staged column x + 2 PAD - kx (columns past 4 KS^2 read tap 0 and are never written)
+    int aoff[NP], boff[NP];
+    bool pon[NP], jok[NP];
+    f32x16 acc[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = wv + 4 * i;
+        pon[i] = p < npair;
+        const int cit = pon[i] ? p / NCT : 0, ct = pon[i] ? p % NCT : 0, j = ct * 32 + li;
+        jok[i] = j < NJ;
+        const int tap = jok[i] ? j >> 2 : 0, ky = tap / KS, kx = tap % KS;
+        aoff[i] = (cit * Wa + kh) * 32 + li;
+        boff[i] = ((KS - 1 - ky) * Wg + 2 * PAD - kx + kh) * 4 + (j & 3);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+    }
+    // bias: the wave that owns (row tile 0, the column tile of the centre tap)
+    constexpr int JC = 4 * (KK / 2);
+    const bool bias_wave = wv == (JC / 32) % 4;
+    constexpr int BI = (JC / 32) / 4;                          // index of that pair in its wave
+    const bool bias_lane = bias_wave && (li >> 2) == (JC % 32) / 4;
+    float bsum = 0.f;
+    if (r0 < r1) fetch(r0);
+    __syncthreads();                                           // planes zeroed
+    for (long long row = r0; row < r1; ++row) {
+        commit();
+        __syncthreads();
+        if (row + 1 < r1) fetch(row + 1);                      // in flight under this row's MFMAs
+#pragma unroll 2
+        for (int x0 = 0; x0 < S; x0 += 2) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                if (!pon[i]) continue;                         // (uniform per wave)
+                const float a = s_a[aoff[i] + x0 * 32], b = s_g[boff[i] + x0 * 4];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                if (i == BI && bias_lane) bsum += b;
+            }
+        }
+        __syncthreads();                                       // every wave is done with the planes
+    }
+    float* pw = part + (size_t)slice * per;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (!pon[i] || !jok[i]) continue;
+        const int p = wv + 4 * i, cit = p / NCT, j = (p % NCT) * 32 + li;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int cr = cit * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+            if (cr < Ci) pw[((size_t)(j >> 2) * Ci + cr) * Co + (j & 3)] = acc[i][q];
+        }
+    }
+    // (the pair (row tile 0, centre column tile) is pair index JC / 32 < 4 NP: row tile 0 comes first)
+    bsum += __shfl_xor(bsum, 32);
+    if (bias_lane && kh == 0) pw[(size_t)KK * Ci * Co + (li & 3)] = bsum;
+}
+
+// LDS bytes of gen_wgrad_out_kernel, 0 = does not qualify (four output channels, 16-byte staging, <= 16 float4 per thread and row, <= 80 KB)
+inline size_t gen_wgrad_out_lds(int S, int Ci, int ldc, int Co, int k)
+{
+    if (Co != 4 || (Ci & 3) || (ldc & 3)) return 0;
+    if ((size_t)S * (Ci / 4 + k) > (size_t)16 * 256) return 0;
+    const int npair = ((Ci + 31) / 32) * ((4 * k * k + 31) / 32);
+    if (npair > 32) return 0;                                  // (at most 8 pairs per wave)
+    const size_t b = ((size_t)((Ci + 31) / 32) * (S + 1) * 32 + (size_t)k * (S + 2 * (k / 2) + 2) * 4) * sizeof(float);
+    return b <= 80 * 1024 ? b : 0;
+}
+
 // LDS bytes of gen_wgrad_rows_kernel, 0 = the shape does not qualify (float4 staging, at most 16 float4 per thread and row, <= 80 KB: two blocks per CU)
 inline size_t gen_wgrad_rows_lds(int S, int Ci, int ldc, int Co, int k)
 {
     if (Co % 4 != 0 || ldc % 4 != 0 || ((Ci + 3) & ~3) > ldc) return 0;
-    if ((size_t)S * ((Ci + 3) / 4 + Co / 4) > (size_t)16 * 256) return 0;
-    const size_t b = ((size_t)((Ci + 31) / 32) * (S + 2 * (k / 2) + 1) + (size_t)((Co + 31) / 32) * (S + 1)) * 32 * sizeof(float);
+    const int na = S * ((Ci + 3) / 4), nd = S * (Co / 4);
+    if ((na + 255) / 256 + (nd + 255) / 256 > GEN_ROWS_MAXV) return 0;
+    if ((size_t)S * ldc * 4 >= ((size_t)1 << 31) || (size_t)S * Co * 4 >= ((size_t)1 << 31)) return 0;   // (32-bit buffer offsets)
+    const size_t b = ((size_t)((Ci + 31) / 32) * gen_rows_wp(S, k) + (size_t)((Co + 31) / 32) * gen_rows_sd(S)) * 32 * sizeof(float) + 16;
     return b <= 80 * 1024 ? b : 0;
 }
 
@@ -498,13 +734,13 @@ inline size_t gen_mfma_lds_cch(int k, int Ck, int s, int cch)
 {
     if (s != 1 || (k != 3 && k != 5 && k != 7)) return 0;
     const int Ckp = (Ck + cch - 1) / cch * cch, TW = 16 + k - 1, NPXP = (TW * TW + 15) / 32 * 32 + 16;
-    const size_t b = ((size_t)k * k * Ckp * 16 + (size_t)2 * NPXP * cch) * sizeof(float);
+    const size_t b = ((size_t)k * k * Ckp * 16 + (size_t)2 * NPXP * cch + 3 * NPXP + 4) * sizeof(float);
     return b <= 160 * 1024 ? b : 0;
 }
 // chunk width: the smallest of 4 / 8 / 16 that covers the reduction channels, stepping down while the LDS does not fit; 0 = the scalar kernels
 inline int gen_mfma_cch(int k, int Ck, int s)
 {
-    int cch = Ck <= 4 ? 4 : Ck <= 8 ? 8 : 16;
+    int cch = Ck <= 4 ? 4 : (Ck <= 8 || k == 7) ? 8 : 16;    // (7 x 7: two operand sets of 119 registers - 8-channel chunks keep it free of spills)
     while (cch >= 4 && !gen_mfma_lds_cch(k, Ck, s, cch)) cch >>= 1;
     return cch >= 4 ? cch : 0;
 }
@@ -514,6 +750,33 @@ inline size_t gen_mfma_lds(int k, int Ck, int ldin, int s)
     if ((Ck & 3) || (ldin & 3)) return 0;
     const int cch = gen_mfma_cch(k, Ck, s);
     return cch ? gen_mfma_lds_cch(k, Ck, s, cch) : 0;
+}
+
+inline int npair_out(int Ci, int k) { return ((Ci + 31) / 32) * ((4 * k * k + 31) / 32); }
+
+template <int KS, int NP>
+hipError_t gen_wgrad_out_launch_np(hipStream_t st, const float* in, const float* g, float* part, int N, int S, int Ci, int ldc, int nsl, size_t lds)
+{
+    static std::atomic<unsigned> attr_devs{0};
+    if (hipError_t e = iod_set_max_lds((const void*)gen_wgrad_out_kernel<KS, NP>, 80 * 1024, attr_devs); e != hipSuccess) return e;
+    hipLaunchKernelGGL((gen_wgrad_out_kernel<KS, NP>), dim3(nsl), dim3(256), lds, st, in, g, part, N, S, Ci, ldc, nsl);
+    return hipGetLastError();
+}
+template <int KS>
+hipError_t gen_wgrad_out_launch_ks(hipStream_t st, const float* in, const float* g, float* part, int N, int S, int Ci, int ldc, int nsl, int np4,
+                                   size_t lds)
+{
+    if (np4 <= 1) return gen_wgrad_out_launch_np<KS, 1>(st, in, g, part, N, S, Ci, ldc, nsl, lds);
+    if (np4 <= 2) return gen_wgrad_out_launch_np<KS, 2>(st, in, g, part, N, S, Ci, ldc, nsl, lds);
+    if (np4 <= 4) return gen_wgrad_out_launch_np<KS, 4>(st, in, g, part, N, S, Ci, ldc, nsl, lds);
+    return gen_wgrad_out_launch_np<KS, 8>(st, in, g, part, N, S, Ci, ldc, nsl, lds);
+}
+inline hipError_t gen_wgrad_out_launch(hipStream_t st, const float* in, const float* g, float* part, int N, int S, int Ci, int ldc, int k, int nsl,
+                                       int np4, size_t lds)
+{
+    if (k == 3) return gen_wgrad_out_launch_ks<3>(st, in, g, part, N, S, Ci, ldc, nsl, np4, lds);
+    if (k == 5) return gen_wgrad_out_launch_ks<5>(st, in, g, part, N, S, Ci, ldc, nsl, np4, lds);
+    return gen_wgrad_out_launch_ks<7>(st, in, g, part, N, S, Ci, ldc, nsl, np4, lds);
 }
 
 template <int KS, int CCH>
@@ -529,6 +792,21 @@ hipError_t gen_mfma_launch_cch(hipStream_t st, const float* in, const float* wt,
     const int nb = std::max(1, std::min(ntiles, per_cu * n_cu / ncg));
     hipLaunchKernelGGL((gen_conv_mfma_kernel<KS, CCH>), dim3(ncg * nb), dim3(256), lds, st, in, wt, bias, aux, out, S, Ck, ldin, Cn, ldout, flip,
                        sT, sK, sN, elu, ncg, tiles, ntiles);
+#ifdef IODINE_TILE_PROF
+    if (getenv("IODINE_GEN_PROF")) {
+        const int nbk = std::min(ncg * nb, TP_MAXBLK);
+        std::vector<unsigned> hp((size_t)nbk * 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(g_gen_prof), hp.size() * sizeof(unsigned));
+        static const char* names[8] = {"weights/loop", "tile prologue", "fetch issue", "k-steps", "commit", "barrier", "epilogue", "-"};
+        double sum[8] = {0}, tot = 0;
+        for (int b2 = 0; b2 < nbk; ++b2) for (int i = 0; i < 8; ++i) sum[i] += hp[(size_t)b2 * 8 + i];
+        for (int i = 0; i < 8; ++i) tot += sum[i] / nbk;
+        fprintf(stderr, "[gen prof k%d cch%d Ck%d Cn%d] ticks per block (%d tiles), total %.0f:", KS, CCH, Ck, Cn, (ntiles + nb - 1) / nb, tot);
+        for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.0f |", names[i], sum[i] / nbk);
+        fprintf(stderr, "\n");
+    }
+#endif
     return hipGetLastError();
 }
 
@@ -537,7 +815,9 @@ hipError_t gen_mfma_launch(hipStream_t st, const float* in, const float* wt, con
                            int Ck, int ldin, int Cn, int ldout, int flip, int sT, int sK, int sN, int elu, size_t lds)
 {
     switch (gen_mfma_cch(KS, Ck, 1)) {
-    case 16: return gen_mfma_launch_cch<KS, 16>(st, in, wt, bias, aux, out, N, S, Ck, ldin, Cn, ldout, flip, sT, sK, sN, elu, lds);
+    case 16:
+        if constexpr (KS < 7) return gen_mfma_launch_cch<KS, 16>(st, in, wt, bias, aux, out, N, S, Ck, ldin, Cn, ldout, flip, sT, sK, sN, elu, lds);
+        return hipErrorInvalidValue;
     case 8: return gen_mfma_launch_cch<KS, 8>(st, in, wt, bias, aux, out, N, S, Ck, ldin, Cn, ldout, flip, sT, sK, sN, elu, lds);
     default: return gen_mfma_launch_cch<KS, 4>(st, in, wt, bias, aux, out, N, S, Ck, ldin, Cn, ldout, flip, sT, sK, sN, elu, lds);
     }
@@ -582,7 +862,11 @@ hipError_t launch_gen_conv_dgrad(hipStream_t st, const float* dout, const float*
     return hipGetLastError();
 }
 
-size_t gen_wgrad_scratch_floats(int Ci, int Co, int k) { return (size_t)GEN_WGRAD_SLICES_MAX * ((size_t)k * k * Ci * Co + Co); }
+// (the GEMM form of a 4-output-channel conv takes one slice per resident block: up to GEN_WGRAD_OUT_SLICES_MAX small partials)
+size_t gen_wgrad_scratch_floats(int Ci, int Co, int k)
+{
+    return (size_t)(Co == 4 ? GEN_WGRAD_OUT_SLICES_MAX : GEN_WGRAD_SLICES_MAX) * ((size_t)k * k * Ci * Co + Co);
+}
 
 hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* dout, float* scratch, int N, int Si, int Ci, int ldc,
                                  int Ci_dst, int Co, int k, int s, float alpha, float* gw, float* gb)
@@ -591,6 +875,17 @@ hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* d
     const size_t per = (size_t)k * k * Ci * Co + Co;
     if (s == 1 && (k == 3 || k == 5 || k == 7)) {
         const int npair = ((Ci + 31) / 32) * ((Co + 31) / 32), ngrp = (npair + 3) / 4;
+        if (const size_t lds = gen_wgrad_out_lds(Si, Ci, ldc, Co, k)) {        // four output channels: GEMM form, the taps on the gradient
+            int n_cu = 0;
+            if (hipError_t e = iod_cu_count(&n_cu); e != hipSuccess) return e;
+            const long long R = (long long)N * Si;
+            const int nsl = (int)std::max<long long>(1, std::min<long long>(std::min(GEN_WGRAD_OUT_SLICES_MAX, 2 * n_cu), R));
+            const int np4 = (npair_out(Ci, k) + 3) / 4;
+            if (hipError_t e = gen_wgrad_out_launch(st, in, dout, scratch, N, Si, Ci, ldc, k, nsl, np4, lds); e != hipSuccess) return e;
+            hipLaunchKernelGGL(gen_conv_wgrad_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, scratch, nsl, Ci, Ci_dst, Co,
+                               k * k, alpha, gw, gb);
+            return hipGetLastError();
+        }
         if (const size_t lds = gen_wgrad_rows_lds(Si, Ci, ldc, Co, k)) {       // operands staged once per kernel row (round 5)
             // as many row slices as fill the chip with two blocks per CU (k x nsl x ngrp blocks; 64 slices left a third of the slots empty)
             int n_cu = 0;
@@ -608,7 +903,7 @@ hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* d
                 if (hipError_t e = iod_set_max_lds((const void*)gen_wgrad_rows_kernel<7>, 80 * 1024, d7); e != hipSuccess) return e;
                 hipLaunchKernelGGL((gen_wgrad_rows_kernel<7>), grid_r, dim3(256), lds, st, in, dout, scratch, N, Si, Ci, ldc, Co, nsl);
             }
-            hipLaunchKernelGGL(gen_conv_wgrad_reduce_kernel, dim3(gen_blocks(per)), dim3(256), 0, st, scratch, nsl, Ci, Ci_dst, Co,
+            hipLaunchKernelGGL(gen_conv_wgrad_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, scratch, nsl, Ci, Ci_dst, Co,
                                k * k, alpha, gw, gb);
             return hipGetLastError();
         }
@@ -616,13 +911,13 @@ hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* d
         if (k == 3) hipLaunchKernelGGL((gen_wgrad_mfma_kernel<3>), grid, dim3(256), 0, st, in, dout, scratch, N, Si, Ci, ldc, Co, GEN_WGRAD_SLICES);
         else if (k == 5) hipLaunchKernelGGL((gen_wgrad_mfma_kernel<5>), grid, dim3(256), 0, st, in, dout, scratch, N, Si, Ci, ldc, Co, GEN_WGRAD_SLICES);
         else hipLaunchKernelGGL((gen_wgrad_mfma_kernel<7>), grid, dim3(256), 0, st, in, dout, scratch, N, Si, Ci, ldc, Co, GEN_WGRAD_SLICES);
-        hipLaunchKernelGGL(gen_conv_wgrad_reduce_kernel, dim3(gen_blocks(per)), dim3(256), 0, st, scratch, GEN_WGRAD_SLICES, Ci, Ci_dst, Co,
+        hipLaunchKernelGGL(gen_conv_wgrad_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, scratch, GEN_WGRAD_SLICES, Ci, Ci_dst, Co,
                            k * k, alpha, gw, gb);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(gen_conv_wgrad_partial_kernel, dim3(gen_blocks(per * GEN_WGRAD_SLICES)), dim3(256), 0, st, in, dout, scratch, N, Si,
                        So, Ci, ldc, Co, k, s, GEN_WGRAD_SLICES);
-    hipLaunchKernelGGL(gen_conv_wgrad_reduce_kernel, dim3(gen_blocks(per)), dim3(256), 0, st, scratch, GEN_WGRAD_SLICES, Ci, Ci_dst, Co,
+    hipLaunchKernelGGL(gen_conv_wgrad_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, scratch, GEN_WGRAD_SLICES, Ci, Ci_dst, Co,
                        k * k, alpha, gw, gb);
     return hipGetLastError();
 }
