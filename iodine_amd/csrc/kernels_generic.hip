@@ -215,59 +215,133 @@ void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict_
     for (int v = 0; v < 4; ++v) bv[v] = (bias && co0 + v < Cn) ? bias[co0 + v] : 0.f;
     const bool vec_out = (ldout & 3) == 0 && co0 + 3 < Cn;
     // ---- staging table of this thread, the same for every tile: element i = 16 bytes (channel quad q of halo pixel (py, px)) ----
-    // One wave per SIMD: every VALU instruction of the staging code is exposed, so the (pixel, quad) arithmetic is done once per kernel, the
-    // bounds mask once per tile, and a chunk's loads are an add and a predicated 16-byte load each (it was 1.6 k cycles per chunk, 12 %).
+    // One wave per SIMD: every instruction that is not issued in the shadow of an MFMA is exposed.  So the (pixel, quad) arithmetic is done
+    // once per kernel, the bounds once per tile (byte offsets into the slot-image, 0x80000000 = outside: the buffer load returns zeros), and a
+    // chunk's loads are one select and one buffer load each, issued BETWEEN the MFMAs of the chunk's first k-step (hand-placed with
+    // sched_group_barrier); so are the LDS writes of the staged chunk (last k-step) and the previous tile's epilogue (first k-step).
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
     int rel[NLD], pyx[NLD], lw[NLD];
+    const int q4 = 4 * (tid % NQ);                            // first channel of this thread's quad within a chunk (256 % NQ == 0: the same for every i)
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int e = tid + 256 * i, px = e / NQ, q = e % NQ, py = px / TW, pxx = px % TW;
-        rel[i] = (py * S + pxx) * ldin + 4 * q;
-        pyx[i] = e < NPX * NQ ? (py | pxx << 8 | q << 16) : (255 | 255 << 8);   // (255: never inside)
-        lw[i] = 4 * q * NPXP + px;
+        const int e = tid + 256 * i, px = e / NQ, py = px / TW, pxx = px % TW;
+        rel[i] = ((py * S + pxx) * ldin + q4) * 4;
+        pyx[i] = e < NPX * NQ ? (py | pxx << 8) : (255 | 255 << 8);             // (255: never inside)
+        lw[i] = e < NPX * NQ ? q4 * NPXP + px : 2 * CCH * NPXP;                  // (threads past the end of the table: the dump area)
     }
-    float4 rin[NLD];
-    // tile being fetched: element offset of its halo origin, bounds mask of the staging table
-    long long f_base = 0;
-    unsigned f_mask = 0;
+    u32x4_ rin[NLD];
+    unsigned tvo[NLD];                                         // tile being fetched: byte offsets of the table's elements
+    __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, 0, 0x00020000);
+    const int img_bytes = S * S * ldin * 4;
     auto setup_fetch = [&](int t) {
         const int tx = t % tiles, ty = (t / tiles) % tiles, n = t / (tiles * tiles);
         const int gy0 = ty * 16 - PAD, gx0 = tx * 16 - PAD;
-        f_base = (((long long)n * S + gy0) * S + gx0) * ldin;
-        f_mask = 0;
+        const bool live = t < ntiles;
+        rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (size_t)(live ? n : 0) * S * S * ldin), 0, live ? img_bytes : 0, 0x00020000);
+        const int tile_off = (gy0 * S + gx0) * ldin * 4;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int gy = gy0 + (pyx[i] & 255), gx = gx0 + ((pyx[i] >> 8) & 255);
-            if ((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S) f_mask |= 1u << i;
+            const int gy = gy0 + (pyx[i] & 255), gx = gx0 + (pyx[i] >> 8);
+            tvo[i] = ((unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S) ? (unsigned)(tile_off + rel[i]) : 0x80000000u;
         }
     };
     auto fetch = [&](int c) {
-        const float* src = in + f_base + c * CCH;
+        const bool qok = c * CCH + q4 < Ck;                   // (a reduction channel count that is not a multiple of the chunk: zeros)
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const bool ok = (f_mask >> i & 1) && c * CCH + 4 * (pyx[i] >> 16) < Ck;
-            rin[i] = ok ? *reinterpret_cast<const float4*>(src + rel[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < NLD; ++i) rin[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(qok ? tvo[i] : 0x80000000u), c * CCH * 4, 0);
     };
     auto commit = [&](int buf) {
         float* dst = s_in + (size_t)buf * CCH * NPXP;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            // (branch-free: the threads past the end of the table write to a dump area behind the buffers - a branch would split the
-            // scheduling region the writes are interleaved with the MFMAs in)
-            float* d = (i < NLD - 1 || tid + 256 * i < NPX * NQ) ? dst + lw[i] : s_in + (size_t)2 * CCH * NPXP;
-            d[0] = rin[i].x; d[NPXP] = rin[i].y; d[2 * NPXP] = rin[i].z; d[3 * NPXP] = rin[i].w;
+            float* d = dst + lw[i];
+            d[0] = __uint_as_float(rin[i].x); d[NPXP] = __uint_as_float(rin[i].y);
+            d[2 * NPXP] = __uint_as_float(rin[i].z); d[3 * NPXP] = __uint_as_float(rin[i].w);
         }
     };
     f32x4 acc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- deferred epilogue: the finished tile's accumulators, store offsets and (data gradient) the activation-derivative operand; the
+    // arithmetic and the stores are issued between the MFMAs of the next tile's first k-step (block's first tile: every offset is "outside") ----
+    const bool vec_all = (ldout & 3) == 0 && (Cn & 3) == 0;   // 16-byte stores for every lane (else: the plain epilogue at the end of the tile)
+    constexpr bool DEFER = NH > 1 && KS < 7;                  // (7 x 7: the two operand sets leave no registers for it - plain order, no spills)
+    f32x4 res[4];
+    u32x4_ ax[4];
+    unsigned evo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { res[r] = f32x4{0.f, 0.f, 0.f, 0.f}; ax[r] = u32x4_{0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u}; evo[r] = 0x80000000u; }
+    __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000);
+    const int out_bytes = S * S * ldout * 4;
+    auto epilogue_math = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = res[r][j] + bv[j];
+                const float ev = elu1_fast(v[j]);
+                v[j] = elu ? ev : v[j];
+                v[j] *= elu1_grad_from_out(__uint_as_float(ax[r][j]));
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                                                   rs_out, (int)evo[r], 0, 0);
+        }
+    };
+    // plain epilogue (channel counts / strides without 16-byte stores, and the kernels with one k-step per chunk)
+    auto epilogue_now = [&](int t) {
+        const int tx = t % tiles, ty = (t / tiles) % tiles, n = t / (tiles * tiles);
+        const int x = tx * 16 + m;
+        if (x < S && co0 < Cn) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = ty * 16 + 4 * wv + r;
+                if (y >= S) continue;
+                const size_t o = (((size_t)n * S + y) * S + x) * ldout + co0;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = acc[r][j] + bv[j]; if (elu) v[j] = elu1_fast(v[j]); }
+                if (vec_out) {
+                    if (aux) {
+                        const float4 a = *reinterpret_cast<const float4*>(aux + o);
+                        v[0] *= elu1_grad_from_out(a.x); v[1] *= elu1_grad_from_out(a.y);
+                        v[2] *= elu1_grad_from_out(a.z); v[3] *= elu1_grad_from_out(a.w);
+                    }
+                    *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (co0 + j >= Cn) continue;
+                        if (aux) v[j] *= elu1_grad_from_out(aux[o + j]);
+                        out[o + j] = v[j];
+                    }
+                }
+            }
+        }
+    };
+    // end of a tile on the deferred path: accumulators -> res, store offsets, the derivative operand's loads (issued here, consumed an item later)
+    auto retire_tile = [&](int t) {
+        const int tx = t % tiles, ty = (t / tiles) % tiles, n = t / (tiles * tiles);
+        const int x = tx * 16 + m;
+        rs_out = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)n * S * S * ldout, 0, out_bytes, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = ty * 16 + 4 * wv + r;
+            evo[r] = (x < S && y < S && co0 < Cn) ? (unsigned)(((y * S + x) * ldout + co0) * 4) : 0x80000000u;
+            res[r] = acc[r];
+            acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (aux) {                                            // (uniform)
+            const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aux + (size_t)n * S * S * ldout), 0, out_bytes, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ax[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, (int)evo[r], 0, 0);
+        }
+    };
     int t = pb, c = 0, buf = 0;
     TP_STAMP(0);
-    if (t < ntiles) {                                         // (uniform over the block)
-        setup_fetch(t);
-        fetch(0);
-        commit(0);
-    }
+    setup_fetch(t);
+    fetch(0);
+    commit(0);
     __syncthreads();                                          // weights and the first chunk staged
     TP_STAMP(1);
     // one flat sequence of (tile, chunk) items: the next item's chunk - of the NEXT tile after a tile's last chunk - is in flight under this
@@ -275,18 +349,15 @@ void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict_
     while (t < ntiles) {
         const bool last_chunk = c + 1 == nchunk;
         const int tn = last_chunk ? t + nb : t, cn = last_chunk ? 0 : c + 1;
-        if (tn < ntiles) {
-            if (last_chunk) setup_fetch(tn);
-            fetch(cn);
-        }
+        if (last_chunk) setup_fetch(tn);                      // (past the last tile: an empty buffer, every load returns zeros)
+        if constexpr (!DEFER) fetch(cn);
         TP_STAMP(2);
         const float* si = s_in + (size_t)buf * CCH * NPXP + (size_t)kq * NPXP + (4 * wv) * TW + m;
         const float* sw = s_w + (size_t)(c * CCH + kq) * 16 + m;
         // All operands of a k-step (4 channels) are register-resident before its 4 KK MFMAs issue back to back: the KK weight values of
         // this lane and the (4 + KS - 1) x KS input values its four tile rows share between their taps (40 + 25 LDS reads at KS = 5).
         // Two operand sets: the reads of k-step h + 1 are issued between the MFMAs of k-step h, so that only the first k-step after a
-        // barrier waits for the LDS.  One wave per SIMD (the weight slice fills the LDS) cannot hide a read-then-multiply chain behind
-        // another wave.
+        // barrier waits for the LDS.
         auto ld = [&](int hh, float (&bw)[KK], float (&av)[RR][KS]) {
 #pragma unroll
             for (int tap = 0; tap < KK; ++tap) bw[tap] = sw[(size_t)tap * Ckp * 16 + hh * 64];
@@ -304,19 +375,27 @@ void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict_
             }
         };
         // (hipcc's scheduler, left alone, sinks every read to just in front of its first use - a full LDS latency in front of every few
-        // MFMAs; the group barriers pin the pattern "MFMAs of this k-step, one LDS access of the next k-step / the next chunk")
-        auto kstep = [&](auto hh_c, float (&bw)[KK], float (&av)[RR][KS], float (&bwn)[KK], float (&avn)[RR][KS]) {
+        // MFMAs; the group barriers pin "one MFMA, one LDS access / memory instruction / a few VALU instructions")
+        auto kstep = [&](auto hh_c, auto epi_c, float (&bw)[KK], float (&av)[RR][KS], float (&bwn)[KK], float (&avn)[RR][KS]) {
             constexpr int hh = decltype(hh_c)::value;
+            constexpr bool EPI = decltype(epi_c)::value;      // first k-step of a tile's first chunk: the previous tile's epilogue rides along
+            constexpr int NRD = KK + RR * KS;
             if constexpr (hh + 1 < NH) {
                 ld(hh + 1, bwn, avn);
+                if constexpr (hh == 0 && DEFER) fetch(cn);
+                if constexpr (EPI) epilogue_math();
                 mm(bw, av);
+                // per MFMA (32 cycles = 8 issue slots): one LDS read of the next k-step, then the chunk's loads, and at most 3 VALU instructions
 #pragma unroll
-                for (int i = 0; i < KK + RR * KS; ++i) {
+                for (int i = 0; i < 4 * KK; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (hh == 0 && DEFER && i >= 8 && i < 8 + NLD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (hh == 0 && DEFER) __builtin_amdgcn_sched_group_barrier(0x002, EPI ? 3 : 1, 0);
+                    if (EPI && i >= 4 * KK - 4) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
                 }
             } else {
-                commit(buf ^ 1);                              // (no next item: stale registers into a buffer nobody reads again)
+                commit(buf ^ 1);                              // (no next item: zeros into a buffer nobody reads again)
                 mm(bw, av);
 #pragma unroll
                 for (int i = 0; i < 4 * NLD; ++i) {
@@ -329,51 +408,28 @@ void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict_
         float bwA[KK], avA[RR][KS], bwB[KK], avB[RR][KS];
         ld(0, bwA, avA);
         __builtin_amdgcn_sched_barrier(0);
-        kstep(std::integral_constant<int, 0>{}, bwA, avA, bwB, avB);
-        if constexpr (NH > 1) kstep(std::integral_constant<int, 1>{}, bwB, avB, bwA, avA);
+        if (DEFER && c == 0) kstep(std::integral_constant<int, 0>{}, std::true_type{}, bwA, avA, bwB, avB);
+        else kstep(std::integral_constant<int, 0>{}, std::false_type{}, bwA, avA, bwB, avB);
+        if constexpr (NH > 1) kstep(std::integral_constant<int, 1>{}, std::false_type{}, bwB, avB, bwA, avA);
         if constexpr (NH > 2) {
-            kstep(std::integral_constant<int, 2>{}, bwA, avA, bwB, avB);
-            kstep(std::integral_constant<int, 3>{}, bwB, avB, bwA, avA);
+            kstep(std::integral_constant<int, 2>{}, std::false_type{}, bwA, avA, bwB, avB);
+            kstep(std::integral_constant<int, 3>{}, std::false_type{}, bwB, avB, bwA, avA);
         }
         TP_STAMP(3);
         __syncthreads();
         TP_STAMP(5);
         if (last_chunk) {
-            // D[channel 4 kq + v][pixel column m] of tile row 4 wv + r: one 16-byte store per lane and row
-            const int tx = t % tiles, ty = (t / tiles) % tiles, n = t / (tiles * tiles);
-            const int x = tx * 16 + m;
-            if (x < S && co0 < Cn) {
+            if (DEFER && vec_all) retire_tile(t);
+            else {
+                epilogue_now(t);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int y = ty * 16 + 4 * wv + r;
-                    if (y >= S) continue;
-                    const size_t o = (((size_t)n * S + y) * S + x) * ldout + co0;
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] = acc[r][j] + bv[j]; if (elu) v[j] = elu1_fast(v[j]); }
-                    if (vec_out) {
-                        if (aux) {
-                            const float4 a = *reinterpret_cast<const float4*>(aux + o);
-                            v[0] *= elu1_grad_from_out(a.x); v[1] *= elu1_grad_from_out(a.y);
-                            v[2] *= elu1_grad_from_out(a.z); v[3] *= elu1_grad_from_out(a.w);
-                        }
-                        *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (co0 + j >= Cn) continue;
-                            if (aux) v[j] *= elu1_grad_from_out(aux[o + j]);
-                            out[o + j] = v[j];
-                        }
-                    }
-                }
+                for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
             TP_STAMP(6);
         }
         t = tn; c = cn; buf ^= 1;
     }
+    if constexpr (DEFER) epilogue_math();                      // the block's last tile
     TP_FLUSH(g_gen_prof);
 }
 
