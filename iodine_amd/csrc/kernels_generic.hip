@@ -10,7 +10,8 @@
 // correctness.  All of it is deterministic.  The spatial-broadcast layer (decoder layer 0) has its own kernels (kernels_genl0.hip: the broadcast
 // tensor is never built; until round 5 it was materialised as [N][P][L+2] and convolved like any other layer).  Every shipped / benchmarked configuration stays on the
 // tuned path (iodine_api.cpp: `generic` is false for KERNEL_SIZE 3 with 32 / 64 channels).  Measured (MI355X, CLEVR shapes with
-// DEC.KERNEL_SIZE 5, batch 4): training step 4977 -> 206 ms, reconstruct 2317 -> 96 ms against the scalar tier.
+// DEC.KERNEL_SIZE 5, batch 4): training step 4977 -> 206 ms, reconstruct 2317 -> 96 ms against the scalar tier (round 4); 48.7 / 30.6 ms
+// after round 5 (what each kernel below gained and where its remaining time goes).
 //
 // Layouts: activations NHWC with a channel stride `ldc` >= Ci (the 17-of-20 refinement input); weights re-packed at set_params to
 // [tap = ky * k + kx][ci][co] (co fastest: coalesced over the threads of a pixel); stride s in {1, 2}, padding k / 2.
@@ -156,10 +157,11 @@ __global__ void gen_identity_kernel(float* __restrict__ m, int rows, int L)
 // odd kernel size whose weight slice fits LDS, any channel counts and image sizes (bounds are checked per element).  The scalar kernels
 // above stay for stride 2 (refinement stack, 3.6 % of the FLOPs) and for slices that do not fit (KERNEL_SIZE 7 with >= 36 channels).
 //
-// Forward / data gradient (one kernel): implicit GEMM, M = 16 pixels of a tile row, N = 16 output channels, K = 4 channels of one tap.
+// Forward / data gradient (one kernel): implicit GEMM, M = 16 output channels, N = 16 pixels of a tile row, K = 4 channels of one tap.
 // A persistent block owns ONE group of 16 output channels and keeps its whole weight slice [tap][reduction channel][16] in LDS
 // (KS^2 x C x 64 B: 102 KB for 5 x 5 x 64) for all the tiles it processes - the weights are what a 5 x 5 conv re-reads most; the input
-// halo of a 16 x 16 tile is staged per 4-channel chunk (double-buffered, one barrier per chunk = per 100 MFMAs of a wave).
+// halo of a 16 x 16 tile is staged per chunk of 16 / 8 / 4 channels as channel-major planes (double-buffered, one barrier per chunk = per
+// 400 MFMAs of a wave at 5 x 5 with 16-channel chunks).
 //   W(tap, k, n) = wt[tapidx * sT + k * sK + n * sN]:  forward tapidx = tap, (sT, sK, sN) = (Ci Co, Co, 1) on the pack [tap][ci][co];
 //   data gradient: the correlation with the flipped kernel, tapidx = KS^2 - 1 - tap, reduction over co, (sT, sK, sN) = (ldi Co, 1, Co).
 // =====================================================================================================================================

@@ -198,6 +198,20 @@ def test_generic_path_configurations(what):
     _step_vs_oracle(arch, params, x, eps)
 
 
+@pytest.mark.parametrize('what', ['dec5_clevr_128px', 'dec7_chan32_64px', 'dec5_chan48_72px'])
+def test_generic_decoder_at_full_image_sizes(what):
+    """the generic decoder kernels at sizes where their persistent / multi-chunk / multi-slice structure is exercised (the CLEVR shapes with
+    DEC.KERNEL_SIZE 5: 64 tiles per slot-image, four 16-channel chunks, XCD-grouped blocks, the deferred epilogue, the row-staged and GEMM-form
+    weight gradients with their row slices; 7 x 7 on the MFMA kernels; a size that is not a multiple of 16 with a channel count that is not a
+    multiple of the chunk) - few slots and one refinement iteration keep the oracle at seconds"""
+    arch, B = dict(dec5_clevr_128px=(dataclasses.replace(O.tiny_arch(slots=3, iters=1, img_size=128), dec_kernel=5, dec_chan=64, dec_layers=4, ref_chan=64,
+                                                        ref_layers=4, dim_latent=64), 2),
+                   dec7_chan32_64px=(dataclasses.replace(O.tiny_arch(slots=2, iters=1, img_size=64), dec_kernel=7, dec_chan=32, dec_layers=3), 2),
+                   dec5_chan48_72px=(dataclasses.replace(O.tiny_arch(slots=2, iters=2, img_size=72), dec_kernel=5, dec_chan=48, dec_layers=3), 1))[what]
+    params, x, eps = _case(arch, B, seed=31)
+    _step_vs_oracle(arch, params, x, eps)
+
+
 def test_reference_default_arch():
     """lib/config/defaults.py:35-100 verbatim - ITERS 5, SLOTS 7, SIGMA 0.13, DIM_LATENT 128, IMG_SIZE 32, REF 32 x 3 (k 3, stride 2),
     MLP 256, DEC 64 x 5 with KERNEL_SIZE 5, ENCODING without 'coordinate': the configuration a user of the reference gets without a
