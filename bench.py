@@ -630,7 +630,8 @@ def main():
             b5 = 4
             x5 = torch.from_numpy(synth.make_images(b5, 128, seed=0)).to(device)
             rec = dict(workload=f'CLEVR6 128x128 shapes with DEC.KERNEL_SIZE 5 (64 channels), K=7, T=5, batch {b5}, 1 GPU', steps=2,
-                       path='generic path (kernels_generic.hip): exact-fp32 MFMA decoder convs (16x16x4 / 32x32x2), scalar stride-2 refinement convs')
+                       path='generic decoder (kernels_generic.hip, kernels_genl0.hip): exact-fp32 MFMA convs (16x16x4 / 32x32x2), broadcast layer from per-tap '
+                            'latent products; tuned refinement kernels (REF.KERNEL_SIZE 3)')
             for md in ('train', 'infer'):
                 st5, _ = make_step(m5, x5, md)
                 st5()

@@ -198,16 +198,24 @@ void gen_conv_mfma_kernel(const float* __restrict__ in, const float* __restrict_
     if (pb >= nb) return;                                     // (grid = ncg * nb exactly; defensive)
     TP_DECL;
     // ---- this block's weight slice -> LDS, once ([tap][reduction channel][16]: element e = row * 16 + n, row = tap * Ckp + k) ----
+    // (eight loads in flight per thread: a load -> store loop pays the full memory latency a hundred times, 4 % of the kernel)
     {
         const int n = tid & 15, co = cg * 16 + n;
         int k = tid >> 4, tap = 0;
         while (k >= Ckp) { k -= Ckp; ++tap; }
-        for (int e = tid; e < KK * Ckp * 16; e += 256) {
-            float v = 0.f;
-            if (k < Ck && co < Cn) v = wt[(size_t)(flip ? KK - 1 - tap : tap) * sT + (size_t)k * sK + (size_t)co * sN];
-            s_w[e] = v;
-            k += 16;
-            while (k >= Ckp) { k -= Ckp; ++tap; }
+        const int ne = KK * Ckp * 16;
+        for (int e0 = tid; e0 < ne; e0 += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = 0.f;
+                if (e0 + 256 * j < ne && k < Ck && co < Cn) v[j] = wt[(size_t)(flip ? KK - 1 - tap : tap) * sT + (size_t)k * sK + (size_t)co * sN];
+                k += 16;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) if (k >= Ckp) { k -= Ckp; ++tap; }       // (Ckp >= 4: at most four rows of the table per step)
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (e0 + 256 * j < ne) s_w[e0 + 256 * j] = v[j];
         }
     }
     const int m = lane & 15, kq = lane >> 4;

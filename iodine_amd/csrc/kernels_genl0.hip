@@ -44,33 +44,44 @@ __global__ void gen_l0_coord_kernel(const float* __restrict__ wt, const float* _
     cterm[idx] = v;
 }
 
-// one block per slot-image: U[tap][co] (global scratch, read back by the same block), then the prefix table PS[(k + 1)^2][co]
-__global__ __launch_bounds__(256) void gen_l0_prefix_kernel(const float* __restrict__ z, const float* __restrict__ wt, int L, int Co, int k,
-                                                            float* __restrict__ u, float* __restrict__ ps)
+// U[n][tap][co] = sum_ci wt[tap][ci][co] z[n][ci]: one thread per output, two partial sums
+__global__ __launch_bounds__(256) void gen_l0_u_kernel(const float* __restrict__ z, const float* __restrict__ wt, int N, int L, int Co, int k,
+                                                       float* __restrict__ u)
 {
-    const int n = blockIdx.x, KK = k * k, Ci = L + 2, k1 = k + 1;
-    const float* zn = z + (size_t)n * L;
-    float* un = u + (size_t)n * KK * Co;
-    for (int e = threadIdx.x; e < KK * Co; e += 256) {
-        const int tap = e / Co, co = e % Co;
-        const float* w = wt + (size_t)tap * Ci * Co + co;
-        float s0 = 0.f, s1 = 0.f;
-        int ci = 0;
-        for (; ci + 1 < L; ci += 2) { s0 = fmaf(w[(size_t)ci * Co], zn[ci], s0); s1 = fmaf(w[(size_t)(ci + 1) * Co], zn[ci + 1], s1); }
-        if (ci < L) s0 = fmaf(w[(size_t)ci * Co], zn[ci], s0);
-        un[e] = s0 + s1;
-    }
-    __syncthreads();
+    const int KK = k * k, Ci = L + 2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * KK * Co) return;
+    const int co = (int)(idx % Co), tap = (int)((idx / Co) % KK);
+    const float* zn = z + (idx / ((size_t)Co * KK)) * L;
+    const float* w = wt + (size_t)tap * Ci * Co + co;
+    float s0 = 0.f, s1 = 0.f;
+    int ci = 0;
+    for (; ci + 1 < L; ci += 2) { s0 = fmaf(w[(size_t)ci * Co], zn[ci], s0); s1 = fmaf(w[(size_t)(ci + 1) * Co], zn[ci + 1], s1); }
+    if (ci < L) s0 = fmaf(w[(size_t)ci * Co], zn[ci], s0);
+    u[idx] = s0 + s1;
+}
+
+// PS[n][a][b][co] = sum_{ky < a, kx < b} U[n][ky][kx][co], a, b = 0 .. k: one thread per (n, co)
+__global__ __launch_bounds__(256) void gen_l0_prefix_kernel(const float* __restrict__ u, int N, int Co, int k, float* __restrict__ ps)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, k1 = k + 1;
+    if (idx >= N * Co) return;
+    const int n = idx / Co, co = idx % Co;
+    const float* un = u + (size_t)n * k * k * Co;
     float* pn = ps + (size_t)n * k1 * k1 * Co;
-    for (int co = threadIdx.x; co < Co; co += 256) {
-        for (int b = 0; b <= k; ++b) pn[(size_t)b * Co + co] = 0.f;
-        for (int a = 1; a <= k; ++a) {
-            pn[(size_t)a * k1 * Co + co] = 0.f;
-            float row = 0.f;
-            for (int b = 1; b <= k; ++b) {
-                row += un[(size_t)((a - 1) * k + b - 1) * Co + co];
-                pn[((size_t)a * k1 + b) * Co + co] = pn[((size_t)(a - 1) * k1 + b) * Co + co] + row;
-            }
+    float prev[KMAX];                                          // PS row a - 1, columns 1 .. k
+#pragma unroll
+    for (int b = 0; b < KMAX; ++b) prev[b] = 0.f;
+    for (int b = 0; b <= k; ++b) pn[(size_t)b * Co + co] = 0.f;
+    for (int a = 1; a <= k; ++a) {
+        pn[(size_t)a * k1 * Co + co] = 0.f;
+        float row = 0.f;
+#pragma unroll
+        for (int b = 1; b <= KMAX; ++b) {
+            if (b > k) break;
+            row += un[(size_t)((a - 1) * k + b - 1) * Co + co];
+            prev[b - 1] += row;
+            pn[((size_t)a * k1 + b) * Co + co] = prev[b - 1];
         }
     }
 }
@@ -241,7 +252,8 @@ hipError_t launch_gen_l0_fwd(hipStream_t st, const float* z, const float* wt0, c
     if (k > KMAX || k % 2 == 0) return hipErrorInvalidValue;
     float* u = scratch + (size_t)N * S * 2 * k * Co + (size_t)3 * N * k * k * Co;
     float* ps = u + (size_t)N * k * k * Co;
-    hipLaunchKernelGGL(gen_l0_prefix_kernel, dim3(N), dim3(256), 0, st, z, wt0, L, Co, k, u, ps);
+    hipLaunchKernelGGL(gen_l0_u_kernel, dim3(nblk((size_t)N * k * k * Co)), dim3(256), 0, st, z, wt0, N, L, Co, k, u);
+    hipLaunchKernelGGL(gen_l0_prefix_kernel, dim3(nblk((size_t)N * Co)), dim3(256), 0, st, u, N, Co, k, ps);
     if (Co % 4 == 0) {
         const size_t total = (size_t)N * S * S * (Co / 4);
         hipLaunchKernelGGL((gen_l0_fwd_kernel<4>), dim3(nblk(total)), dim3(256), 0, st, ps, cterm, S, Co, k, total, out);
