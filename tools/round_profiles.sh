@@ -36,5 +36,9 @@ rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_cfg5 -- python $REPO/bench.
 python $REPO/tools/rocpd_summary.py $(ls $OUT/${TAG}_prof_cfg5/*/*.db | head -1) > $OUT/${TAG}_cfg5shard_train_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_ds -- python $REPO/bench.py --config dsprites --steps 10 --warmup 2 --no-cpu-baseline --no-exact-fp32 --no-extra-configs --no-sustain > $OUT/${TAG}_prof_ds.log 2>&1
 python $REPO/tools/rocpd_summary.py $(ls $OUT/${TAG}_prof_ds/*/*.db | head -1) > $OUT/${TAG}_dsprites_train_kernel_stats.md
+# the reference's default decoder kernel size on the generic path (CLEVR shapes with DEC.KERNEL_SIZE 5, batch 4: configs.default_dec_kernel5)
+rm -rf $OUT/${TAG}_prof_k5
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_k5 -- python $REPO/tools/experiments/k5_prof.py > $OUT/${TAG}_prof_k5.log 2>&1
+python $REPO/tools/rocpd_summary.py $(ls $OUT/${TAG}_prof_k5/*/*.db | head -1) > $OUT/${TAG}_dec_kernel5_train_kernel_stats.md
 cd $REPO
 ls $OUT | grep $TAG
