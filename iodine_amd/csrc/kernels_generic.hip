@@ -167,6 +167,7 @@ __global__ void gen_identity_kernel(float* __restrict__ m, int rows, int L)
 // =====================================================================================================================================
 #ifdef IODINE_TILE_PROF
 __device__ unsigned g_gen_prof[TP_MAXBLK * 8];
+__device__ unsigned g_genw_prof[TP_MAXBLK * 8];
 #endif
 
 template <int KS, int CCH>                                     // CCH: reduction channels per staged chunk (16, 8 or 4: the largest that fits the LDS)
@@ -617,12 +618,17 @@ void gen_wgrad_rows_kernel(const float* __restrict__ in, const float* __restrict
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    TP_DECL;
     if (r0 < r1) fetch(r0);
     __syncthreads();                                           // planes zeroed
+    TP_STAMP(0);
     for (long long row = r0; row < r1; ++row) {
         commit();
+        TP_STAMP(1);
         __syncthreads();
+        TP_STAMP(2);
         if (row + 1 < r1) fetch(row + 1);                      // in flight under this row's MFMAs
+        TP_STAMP(3);
         const int iy = (int)(row % S) + ky - PAD;
         if (wave_on && ((unsigned)iy < (unsigned)S || do_bias)) {
             float awA[NAW], bwA[U], awB[NAW], bwB[U];
@@ -637,8 +643,11 @@ void gen_wgrad_rows_kernel(const float* __restrict__ in, const float* __restrict
                 interleave();
             }
         }
+        TP_STAMP(4);
         __syncthreads();                                       // every wave is done with the planes
+        TP_STAMP(5);
     }
+    TP_FLUSH(g_genw_prof);
     if (!wave_on) return;
     float* pw = part + (size_t)slice * per;
 #pragma unroll
@@ -965,6 +974,21 @@ hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* d
             } else if (k == 5) {
                 if (hipError_t e = iod_set_max_lds((const void*)gen_wgrad_rows_kernel<5>, 80 * 1024, d5); e != hipSuccess) return e;
                 hipLaunchKernelGGL((gen_wgrad_rows_kernel<5>), grid_r, dim3(256), lds, st, in, dout, scratch, N, Si, Ci, ldc, Co, nsl);
+#ifdef IODINE_TILE_PROF
+                if (getenv("IODINE_GEN_PROF")) {
+                    const int nbk = std::min((int)grid_r.x, TP_MAXBLK);
+                    std::vector<unsigned> hp((size_t)nbk * 8);
+                    (void)hipStreamSynchronize(st);
+                    (void)hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(g_genw_prof), hp.size() * sizeof(unsigned));
+                    static const char* names[8] = {"prologue", "commit", "barrier 1", "fetch issue", "MFMA blocks", "barrier 2", "-", "-"};
+                    double sum[8] = {0}, tot = 0;
+                    for (int b2 = 0; b2 < nbk; ++b2) for (int i = 0; i < 8; ++i) sum[i] += hp[(size_t)b2 * 8 + i];
+                    for (int i = 0; i < 8; ++i) tot += sum[i] / nbk;
+                    fprintf(stderr, "[gen wgrad rows prof] ticks per block (%d slices), total %.0f:", nsl, tot);
+                    for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.0f |", names[i], sum[i] / nbk);
+                    fprintf(stderr, "\n");
+                }
+#endif
             } else {
                 if (hipError_t e = iod_set_max_lds((const void*)gen_wgrad_rows_kernel<7>, 80 * 1024, d7); e != hipSuccess) return e;
                 hipLaunchKernelGGL((gen_wgrad_rows_kernel<7>), grid_r, dim3(256), lds, st, in, dout, scratch, N, Si, Ci, ldc, Co, nsl);
