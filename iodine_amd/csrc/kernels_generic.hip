@@ -751,7 +751,6 @@ void gen_wgrad_out_kernel(const float* __restrict__ in, const float* __restrict_
         commit();
         __syncthreads();
         if (row + 1 < r1) fetch(row + 1);                      // in flight under this row's MFMAs
-#pragma unroll 2
         for (int x0 = 0; x0 < S; x0 += 2) {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
