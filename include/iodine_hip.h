@@ -237,7 +237,8 @@ void iodine_linspace_host(int n, float* out);
  * ELU'(aux), 2 none; transpose_flip=1 computes the data-gradient conv), mode 1: strided gather kernel (bias+ELU),
  * mode 2: stride-1 LDS-tiled split-fp16 (3 MFMA) variant of mode 0, modes 9 / 10: the weight-stationary split-fp16 kernel,
  * mode 12: its exact-fp32 form (weights as fp32 in the same registers, v_mfma_f32_16x16x4_f32; conv_precision 0),
- * modes 5 / 6: split-fp16 stride-2 forward / data gradient of the refinement stack. */
+ * modes 5 / 6: split-fp16 stride-2 forward / data gradient of the refinement stack, modes 13 / 14: their exact-fp32 forms
+ * (v_mfma_f32_32x32x2_f32, conv_precision 0). */
 int iodine_op_conv3x3(void* stream, int mode, const float* in_nhwc, const float* w_oihw, const float* bias,
                       const float* aux, float* out_nhwc, int n, int ih, int iw, int w_o, int w_i, int cin_pad,
                       int cout, int stride, int epi, int transpose_flip);
@@ -251,7 +252,8 @@ int iodine_op_dec_out_f16x3(void* stream, const float* in_nhwc, const float* w_o
                             int n, int s, int c, int variant);
 /* weight + bias gradient of a 3x3 conv (kernel-level tests): in_nhwc [n][s][s][ci_pad] (ci_real of them meaningful),
  * d_nhwc [n][so][so][co] with so = s (stride 1) or s/2 (stride 2); gw_oihw [co][ci_real][3][3] and gb [co] are
- * ACCUMULATED into.  Split-fp16 kernels (stride 1: decoder stack, stride 2: refinement stack). */
+ * ACCUMULATED into.  Split-fp16 kernels (stride 1: decoder stack, stride 2: refinement stack); stride -2 selects the
+ * exact-fp32 form of the stride-2 kernel (conv_precision 0). */
 int iodine_op_conv3x3_wgrad(void* stream, const float* in_nhwc, const float* d_nhwc, float* gw_oihw, float* gb, int n,
                             int s, int ci_pad, int ci_real, int co, int stride);
 

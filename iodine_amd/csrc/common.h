@@ -327,7 +327,11 @@ hipError_t launch_conv3x3_wino_f16x3(hipStream_t st, const float* in, const void
 
 // kernels_refine.hip: split-fp16 stride-2 convs of the refinement network
 hipError_t launch_conv3x3_s2_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
-                                   float* out, int N, int S, int cin_real, int cout, const float* addmap = nullptr, int kdiv = 0);
+                                   float* out, int N, int S, int cin_real, int cout, const float* addmap = nullptr, int kdiv = 0,
+                                   int f32 = 0);
+// exact-fp32 forms of the three stride-2 kernels (conv_precision 0, round 5: v_mfma_f32_32x32x2_f32; f32 = 1 on the launchers):
+// fp32 weights in the same LDS-tile layout / byte count as launch_pack_conv_weights_f16
+hipError_t launch_pack_conv_weights_s2f32(hipStream_t st, const float* src, int O, int I, int cin, int cout, int tflip, void* dst);
 hipError_t launch_ref_split_weights(hipStream_t st, const float* w, int O, float* w_slot, float* w_sh);
 hipError_t launch_enc_expand_weights(hipStream_t st, const float* w, int O, int n_in, const int* map17, float* w17, int kk = 9);
 hipError_t launch_enc_gather_grad(hipStream_t st, const float* g17, int O, int n_in, const int* map17, float* gw, int kk = 9);
@@ -357,10 +361,10 @@ hipError_t launch_gen_identity(hipStream_t st, float* m, int rows, int L);
 hipError_t launch_ref_unsplit_grad(hipStream_t st, const float* g20, int O, float* gw);
 hipError_t launch_enc_join(hipStream_t st, const float* enck, const float* encs, float* enc, int N, int K, int P);
 hipError_t launch_conv3x3_s2_dgrad_f16x3(hipStream_t st, const float* d, const void* wpk, const float* wmeta, const float* aux,
-                                         float* out, int N, int S, int c);
+                                         float* out, int N, int S, int c, int f32 = 0);
 hipError_t launch_conv3x3_s2_wgrad_f16x3(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
                                          int S, int ci_real, int nco, int* nparts, int* cipad, int* nbias_parts,
-                                         const float* a2 = nullptr, int kdiv = 0);
+                                         const float* a2 = nullptr, int kdiv = 0, int f32 = 0);
 // kernels_refl0.hip: encoding (pixel_pass2's channels) + first refinement layer (conv k3 s2 17 -> 64, ELU) for all slots of an image
 size_t refine_l0_wpk_bytes(int O);
 hipError_t launch_refine_l0_pack(hipStream_t st, const float* w, int O, int cinw, float* meta, void* dst);

@@ -752,7 +752,8 @@ bool refine_f16_ok(const iodine_handle* h)
     return true;
 }
 
-bool refine_split_on(const iodine_handle* h) { return h->refine_split && h->precision == 1 && refine_f16_ok(h); }
+// (round 5: the exact-fp32 path runs the same tuned stride-2 kernels in their fp32-MFMA form, so it takes the split first layer too)
+bool refine_split_on(const iodine_handle* h) { return h->refine_split && refine_f16_ok(h); }
 
 // refine() + posterior.update() for iteration i (iodine.py:95-100 / 144-145)
 int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
@@ -763,7 +764,8 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
     const bool split = refine_split_on(h);     // (training: iodine_train_forward records the form in h->fwd_split - host state must
                                                //  not be written here, a hipGraph replay does not execute this body)
     // ... and with refine_l0_fused the encoding is not written at all (inference): one kernel from the decoder output to layer 0's output
-    const bool l0f = split && h->refine_l0_fused && refine_l0_fused_ok(h->S, h->Cr, h->K);
+    const bool l0f = split && h->precision == 1 && h->refine_l0_fused && refine_l0_fused_ok(h->S, h->Cr, h->K);
+    const int f32 = h->precision == 0;         // exact fp32 products: the fp32-MFMA form of the same stride-2 kernels
     const bool keep_enc = save || h->stop_after >= 0;     // the backward / iodine_debug_copy("enc") read it
     if (l0f)
         PROF(h, st, "refine_l0f", launch_refine_l0_fused(st, b.x4, b.dec_out, b.lnstat, h->lin, h->ref_l0k, h->ref_l0kmeta, h->ref_l0s,
@@ -782,14 +784,14 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
         } else if (l == 0 && l0f) {
         } else if (l == 0 && split) {
             PROF(h, st, "refine_l0", launch_conv3x3_s2_f16x3(st, b.encs[i], h->ref_wsh16, h->ref_wshmeta, nullptr, b.rmap, B, s, 8,
-                                                             h->Cr));
+                                                             h->Cr, nullptr, 0, f32));
             PROF(h, st, "refine_l0", launch_conv3x3_s2_f16x3(st, b.enck[i], h->ref_wk16, h->ref_wkmeta, h->ref_b[0], b.ract[i][0], N,
-                                                             s, 12, h->Cr, b.rmap, h->K));
+                                                             s, 12, h->Cr, b.rmap, h->K, f32));
         } else if (l > 0 && h->refine_ws && h->precision == 1 && refine_f16_ok(h) && conv3x3_s2ws_ok(s, h->Cr)) {
             PROF(h, st, "refine_conv", launch_conv3x3_s2ws_f16x3(st, in, h->ref_wsf[l], h->ref_wsf_meta[l], h->ref_b[l], b.ract[i][l], N, s, h->Cr));
-        } else if (h->precision == 1 && refine_f16_ok(h))
+        } else if (refine_f16_ok(h))
             PROF(h, st, l == 0 ? "refine_l0" : "refine_conv", launch_conv3x3_s2_f16x3(st, in, h->ref_wf16[l], h->ref_wmeta[l], h->ref_b[l],
-                                                               b.ract[i][l], N, s, l == 0 ? 20 : h->Cr, h->Cr));
+                                                               b.ract[i][l], N, s, l == 0 ? 20 : h->Cr, h->Cr, nullptr, 0, f32));
         else
             PROF(h, st, l == 0 ? "refine_l0" : "refine_conv", launch_conv3x3_gather(st, in, h->ref_w[l], h->ref_b[l], b.ract[i][l], N, s, s,
                                                              l == 0 ? 20 : h->Cr, h->Cr, 2));
@@ -1137,7 +1139,7 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     }   // !generic (decoder)
     if (!h->gen_ref) {
     // refinement conv stack
-    const bool ref_fp32 = h->precision == 0 || !refine_f16_ok(h);
+    const bool ref_fp32 = !refine_f16_ok(h);                    // the round-1 gather kernels: only where the tuned stride-2 kernels do not apply
     // first layer: the reference weight has n_in input channels (ARCH.ENCODING subset); the kernels see 17
     const float* w0 = P("refine.mlc.layers.0.weight");
     if (h->n_in < 17) {
@@ -1152,7 +1154,17 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     for (int l = 1; l < h->Dr && ref_fp32; ++l)
         HIPCHK(h, launch_pack_conv_weights(st, P("refine.mlc.layers." + std::to_string(l) + ".weight"), Cr, Cr, Cr, Cr, 2,
                                            h->ref_wb[l]));
-    if (refine_f16_ok(h)) {
+    if (refine_f16_ok(h) && h->precision == 0) {
+        // exact-fp32 path: fp32 weights in the same LDS-tile layouts (same buffers; conv_precision invalidates the parameters)
+        for (int l = 0; l < h->Dr; ++l) {
+            const float* w = l == 0 ? w0 : P("refine.mlc.layers." + std::to_string(l) + ".weight");
+            HIPCHK(h, launch_pack_conv_weights_s2f32(st, w, Cr, l == 0 ? 17 : Cr, l == 0 ? 32 : Cr, Cr, 0, h->ref_wf16[l]));
+            if (l > 0) HIPCHK(h, launch_pack_conv_weights_s2f32(st, w, Cr, Cr, Cr, Cr, 2, h->ref_wb16[l]));
+        }
+        HIPCHK(h, launch_ref_split_weights(st, w0, Cr, h->ref_wk, h->ref_wsh));
+        HIPCHK(h, launch_pack_conv_weights_s2f32(st, h->ref_wk, Cr, 12, 16, Cr, 0, h->ref_wk16));
+        HIPCHK(h, launch_pack_conv_weights_s2f32(st, h->ref_wsh, Cr, 8, 16, Cr, 0, h->ref_wsh16));
+    } else if (refine_f16_ok(h)) {
         for (int l = 0; l < h->Dr; ++l) {
             const float* w = l == 0 ? w0 : P("refine.mlc.layers." + std::to_string(l) + ".weight");
             HIPCHK(h, pack_f16(w, Cr, l == 0 ? 17 : Cr, l == 0 ? 32 : Cr, Cr, 0, h->ref_wmeta[l],
@@ -1305,7 +1317,7 @@ int iodine_reconstruct(iodine_handle* h, void* stream, int batch, const float* x
     h->last_elbo_iter = n_it > 0 ? n_it - 1 : -1;
     h->last_elbo_batch = B;
     // (host state, outside the graphed body) did this call leave the encoding in the workspace?  refine_step: l0f && !keep_enc skips it
-    h->enc_valid = n_it > 0 && (h->stop_after >= 0 || !(refine_split_on(h) && h->refine_l0_fused && refine_l0_fused_ok(h->S, h->Cr, h->K)));
+    h->enc_valid = n_it > 0 && (h->stop_after >= 0 || !(refine_split_on(h) && h->precision == 1 && h->refine_l0_fused && refine_l0_fused_ok(h->S, h->Cr, h->K)));
     return IODINE_OK;
 }
 
@@ -1553,15 +1565,15 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
                 // order, then added to the reference layout
                 int nb = 0;
                 PROF(h, st, "refine_wgrad", launch_conv3x3_s2_wgrad_f16x3(st, b.enck[0], b.rdpre[0], b.wg_part, b.wg_part_b, NT, sz[0],
-                                                                          20, Cr, &nparts, &cipad, &nb, b.encs[0], h->K));
+                                                                          20, Cr, &nparts, &cipad, &nb, b.encs[0], h->K, h->precision == 0));
                 HIPCHK(h, hipMemsetAsync(h->ref_g20, 0, (size_t)Cr * 20 * 9 * sizeof(float), st));
                 HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, 20, 20, 1.f, h->ref_g20, b.wg_fold,
                                               b.wg_part_b, nb, G(base + ".bias")));
                 HIPCHK(h, launch_ref_unsplit_grad(st, h->ref_g20, Cr, gw_dst));
-            } else if (h->precision == 1 && refine_f16_ok(h)) {
+            } else if (refine_f16_ok(h)) {
                 int nb = 0;
                 PROF(h, st, "refine_wgrad", launch_conv3x3_s2_wgrad_f16x3(st, in, b.rdpre[l], b.wg_part, b.wg_part_b, NT, sz[l],
-                                                                          cip, Cr, &nparts, &cipad, &nb));
+                                                                          cip, Cr, &nparts, &cipad, &nb, nullptr, 0, h->precision == 0));
                 HIPCHK(h, launch_wgrad_reduce(st, b.wg_part, nparts, cipad, Cr, Cr, ireal, ireal, 1.f, gw_dst, b.wg_fold,
                                               b.wg_part_b, nb, G(base + ".bias")));
             } else {
@@ -1576,9 +1588,9 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
                 if (h->gen_ref)
                     PROF(h, st, "gen_conv", launch_gen_conv_dgrad(st, b.rdpre[l], h->gen_wref[l], b.ract[0][l - 1], b.rdpre[l - 1], NT, sz[l],
                                                                   Cr, Cr, Cr, h->kr, 2));
-                else if (h->precision == 1 && refine_f16_ok(h))
+                else if (refine_f16_ok(h))
                     PROF(h, st, "refine_dgrad", launch_conv3x3_s2_dgrad_f16x3(st, b.rdpre[l], h->ref_wb16[l], h->ref_wmeta[l] + 2,
-                                                                              b.ract[0][l - 1], b.rdpre[l - 1], NT, sz[l], Cr));
+                                                                              b.ract[0][l - 1], b.rdpre[l - 1], NT, sz[l], Cr, h->precision == 0));
                 else
                     PROF(h, st, "refine_dgrad", launch_conv3x3_gather_dgrad(st, b.rdpre[l], h->ref_wb[l], b.ract[0][l - 1],
                                                                             b.rdpre[l - 1], NT, sz[l], sz[l], Cr, 2));
@@ -1767,16 +1779,19 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, c
 {
     hipStream_t st = (hipStream_t)stream;
     float* wpk = nullptr;
-    if (mode == 5 || mode == 6) {          // split-fp16 stride-2 forward (5) / data gradient (6); ih = fine size
+    if (mode == 5 || mode == 6 || mode == 13 || mode == 14) {   // stride-2 forward (5) / data gradient (6), split-fp16; 13 / 14: their exact-fp32 forms; ih = fine size
         float* meta = nullptr;
-        const int cp = mode == 5 ? (cin_pad == 20 ? 32 : cin_pad) : cin_pad;
+        const bool fwd = mode == 5 || mode == 13;
+        const int f32 = mode >= 13;
+        const int cp = fwd ? (cin_pad == 20 ? 32 : (cin_pad == 12 || cin_pad == 8 ? 16 : cin_pad)) : cin_pad;   // floats per pixel -> packed chunks
         const size_t bytes = (size_t)(cp / 16) * 9 * 2 * 2 * cout * 16;
         if (hipMalloc((void**)&wpk, bytes + 64) != hipSuccess) return IODINE_ERR_HIP;
         meta = (float*)((char*)wpk + bytes);
-        hipError_t e2 = launch_pack_conv_weights_f16(st, w, w_o, w_i, cp, cout, mode == 5 ? 0 : 2, meta, wpk);
+        hipError_t e2 = f32 ? launch_pack_conv_weights_s2f32(st, w, w_o, w_i, cp, cout, fwd ? 0 : 2, wpk)
+                            : launch_pack_conv_weights_f16(st, w, w_o, w_i, cp, cout, fwd ? 0 : 2, meta, wpk);
         if (e2 == hipSuccess)
-            e2 = mode == 5 ? launch_conv3x3_s2_f16x3(st, in, wpk, meta, bias, out, n, ih, cin_pad, cout)
-                           : launch_conv3x3_s2_dgrad_f16x3(st, in, wpk, meta, aux, out, n, ih, cout);
+            e2 = fwd ? launch_conv3x3_s2_f16x3(st, in, wpk, meta, bias, out, n, ih, cin_pad, cout, nullptr, 0, f32)
+                     : launch_conv3x3_s2_dgrad_f16x3(st, in, wpk, meta, aux, out, n, ih, cout, f32);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
         (void)hipFree(wpk);
         if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(s2 f16x3): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
@@ -1905,8 +1920,8 @@ int iodine_op_conv3x3_wgrad(void* stream, const float* in, const float* d, float
         e = launch_conv3x3_wgrad_f16x3_ws(st, in, d, part, part_b, n, s, ci_pad, co, &nparts, &cip, &nb);
         // stride-1 partial tiles are [9][ci][co padded to 32]
         if (e == hipSuccess) e = launch_wgrad_reduce(st, part, nparts, ci_pad, cip, co, ci_real, ci_real, 1.f, gw, fold);
-    } else {
-        e = launch_conv3x3_s2_wgrad_f16x3(st, in, d, part, part_b, n, s, ci_pad, co, &nparts, &cip, &nb);
+    } else {                                           // stride 2; stride -2: the exact-fp32 form of the same kernel
+        e = launch_conv3x3_s2_wgrad_f16x3(st, in, d, part, part_b, n, s, ci_pad, co, &nparts, &cip, &nb, nullptr, 0, stride == -2);
         if (e == hipSuccess) e = launch_wgrad_reduce(st, part, nparts, cip, co, co, ci_real, ci_real, 1.f, gw, fold);
     }
     if (e == hipSuccess) e = launch_colsum(st, part_b, nb, co, co, 1.f, gb);

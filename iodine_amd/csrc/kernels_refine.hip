@@ -35,7 +35,11 @@ __host__ __device__ constexpr int s2_off(int mode, int k) { return mode == 0 ? (
 // forward stage order: the 4-tap class first (its weights are the largest staging burst)
 __host__ __device__ constexpr int s2_fwd_sb(int i) { return 3 - i; }
 
-template <int CIN_REAL, int CIN, int COUT, int MODE, int SBT>
+// F32 (conv_precision 0, round 5): the same stages with IEEE fp32 products on v_mfma_f32_32x32x2_f32 - a staged pixel is its 16 fp32
+// channels (64 of the same 80 bytes), a weight slot (term, kh, co) holds the four fp32 weights of input channels 8 kh + 4 term .. + 3
+// (launch_pack_conv_weights_s2f32: same byte count and staging as the split pack), lane (kh, li) feeds k-step (term, e) with channel
+// 8 kh + 4 term + e of its pixel and of its output channel; no scales, one barrier less per stage.
+template <int CIN_REAL, int CIN, int COUT, int MODE, int SBT, bool F32>
 IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
                              const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
                              int Sc, int tiles, int kdiv, unsigned char* smem_b, int bid)
@@ -127,6 +131,24 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
     auto commit = [&](auto Ic, const float4 (&r)[NIN]) -> float {
         constexpr int I = decltype(Ic)::value;
         constexpr int sb = stage_sb(I);
+        if constexpr (F32) {
+            __syncthreads();                                 // every wave is done reading the previous stage
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) {
+                const int idx = tid + k * 256;
+                const int px = idx < NPX * 4 ? idx >> 2 : NPX;
+                *reinterpret_cast<float4*>(s_in + px * PXS + cq * 16) = r[k];
+            }
+#pragma unroll
+            for (int j = 0; j < s2_ntaps(sb); ++j)
+#pragma unroll
+                for (int k = 0; k < NWT; ++k) {
+                    const int idx = tid + k * 256;
+                    if (idx < TAP_U4) s_w[j * TAP_U4 + idx] = rw[j][k];
+                }
+            __syncthreads();
+            return 1.f;
+        }
         float m = 0.f;
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
@@ -178,7 +200,7 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
             cur_scale = new_scale;
         }
     };
-    const unsigned char* a_base = s_in + ((4 * wv + prow) * HALO + pcol) * PXS + kh * 16;
+    const unsigned char* a_base = s_in + ((4 * wv + prow) * HALO + pcol) * PXS + kh * (F32 ? 32 : 16);
     const uint4* b_base = s_w + kh * COUT + li;
     auto compute = [&](auto Ic) {
         constexpr int I = decltype(Ic)::value;
@@ -186,6 +208,29 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
 #pragma unroll
         for (int j = 0; j < s2_ntaps(sb); ++j) {
             const int aoff = (s2_off(MODE, s2_ky(sb, j)) * HALO + s2_off(MODE, s2_kx(sb, j))) * PXS;
+            if constexpr (F32) {
+                f32x4 av[2][2], bv[NT][2];                   // [.][term]
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    av[mt][0] = *reinterpret_cast<const f32x4*>(a_base + aoff + mt * 2 * HALO * PXS);
+                    av[mt][1] = *reinterpret_cast<const f32x4*>(a_base + aoff + mt * 2 * HALO * PXS + 16);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const uint4 v0 = b_base[j * TAP_U4 + nt * 32], v1 = b_base[j * TAP_U4 + 2 * COUT + nt * 32];
+                    __builtin_memcpy(&bv[nt][0], &v0, 16); __builtin_memcpy(&bv[nt][1], &v1, 16);
+                }
+#pragma unroll
+                for (int term = 0; term < 2; ++term)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[nt][term][e], av[mt][term][e], acc[mt][nt], 0, 0, 0);
+                continue;
+            }
             f16x8 ah[2], al[2], bh[NT], bl[NT];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -234,13 +279,13 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
     static_for<NSTAGE>([&](auto Ic) {
         constexpr int I = decltype(Ic)::value;
         const float sc = commit(Ic, rin[I & 1]);
-        if (I == 0) cur_scale = sc; else rescale(sc);
+        if constexpr (!F32) { if (I == 0) cur_scale = sc; else rescale(sc); }
         if constexpr (I + 1 < NSTAGE) prefetch_w(integral_constant<int, (I + 1 < NSTAGE ? I + 1 : 0)>{});
         if constexpr (I + 2 < NSTAGE) prefetch_in(integral_constant<int, (I + 2 < NSTAGE ? I + 2 : 0)>{}, rin[I & 1]);
         compute(Ic);
     });
 
-    const float inv_ws = wmeta[1] / cur_scale;
+    const float inv_ws = F32 ? 1.f : wmeta[1] / cur_scale;
     // MFMAs are issued as (weights, activations): accumulator rows are channels, lane li = pixel li of a 32-pixel half tile,
     // registers 4g..4g+3 = channels 8g + 4kh .. +3.  Stored directly, every instruction writes 16 bytes per lane at the pixel
     // stride (32 partial cache lines); so each wave transposes its half tile through the (now free) staging buffers and
@@ -289,7 +334,8 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
                 const float4 mv = *reinterpret_cast<const float4*>(aux + (size_t)(((n / kdiv) * Sc + Y) * Sc + X) * COUT + c0);
                 v.x += mv.x; v.y += mv.y; v.z += mv.z; v.w += mv.w;
             }
-            *dst = make_float4(elu1_fast_r(v.x), elu1_fast_r(v.y), elu1_fast_r(v.z), elu1_fast_r(v.w));
+            if constexpr (F32) *dst = make_float4(elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w));      // (expm1f: the VALU is idle beside fp32 MFMA)
+            else *dst = make_float4(elu1_fast_r(v.x), elu1_fast_r(v.y), elu1_fast_r(v.z), elu1_fast_r(v.w));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -302,7 +348,7 @@ IOD_DEVINL void conv_s2_body(const float* __restrict__ in, const uint4* __restri
 #ifndef S2_FWD_WAVES
 #define S2_FWD_WAVES 2
 #endif
-template <int CIN_REAL, int CIN, int COUT, int MODE>
+template <int CIN_REAL, int CIN, int COUT, int MODE, bool F32 = false>
 __global__ __launch_bounds__(256, MODE == 0 ? S2_FWD_WAVES : 2)
 void conv3x3_s2_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
                              const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
@@ -310,7 +356,7 @@ void conv3x3_s2_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s2[];
     if (MODE == 0) {
-        conv_s2_body<CIN_REAL, CIN, COUT, 0, 0>(in, wpk, wmeta, bias, aux, out, Sc, tiles, kdiv, smem_s2, (int)blockIdx.x);
+        conv_s2_body<CIN_REAL, CIN, COUT, 0, 0, F32>(in, wpk, wmeta, bias, aux, out, Sc, tiles, kdiv, smem_s2, (int)blockIdx.x);
     } else {
         // The four parity classes of a coarse tile read the SAME staged input: their blocks are made neighbours in dispatch order ON
         // ONE XCD (block b runs on XCD b % 8, observed; speed only), so that three of the four reads hit that XCD's L2 instead of
@@ -318,25 +364,25 @@ void conv3x3_s2_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
         const int b = (int)blockIdx.x, xcd = b & 7, r = b >> 3, tile = (r >> 2) * 8 + xcd;
         if (tile >= kdiv) return;                            // (kdiv carries the tile count in this mode; block-uniform)
         switch (r & 3) {                                     // heaviest class (4 taps) first
-        case 3: conv_s2_body<CIN_REAL, CIN, COUT, 1, 0>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2, tile); break;
-        case 2: conv_s2_body<CIN_REAL, CIN, COUT, 1, 1>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2, tile); break;
-        case 1: conv_s2_body<CIN_REAL, CIN, COUT, 1, 2>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2, tile); break;
-        default: conv_s2_body<CIN_REAL, CIN, COUT, 1, 3>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2, tile); break;
+        case 3: conv_s2_body<CIN_REAL, CIN, COUT, 1, 0, F32>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2, tile); break;
+        case 2: conv_s2_body<CIN_REAL, CIN, COUT, 1, 1, F32>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2, tile); break;
+        case 1: conv_s2_body<CIN_REAL, CIN, COUT, 1, 2, F32>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2, tile); break;
+        default: conv_s2_body<CIN_REAL, CIN, COUT, 1, 3, F32>(in, wpk, wmeta, bias, aux, out, Sc, tiles, 0, smem_s2, tile); break;
         }
     }
 }
 
-template <int CIN_REAL, int CIN, int COUT, int MODE>
+template <int CIN_REAL, int CIN, int COUT, int MODE, bool F32 = false>
 hipError_t launch_s2_inst(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
                           const float* aux, float* out, int N, int Sc, int kdiv = 0)
 {
     constexpr size_t lds = (size_t)(17 * 17 + 1) * 80 + (size_t)4 * 4 * COUT * 16 + 16;
     static std::atomic<unsigned> attr_devs{0};                             // devices this instance is configured on
-    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_s2_f16x3_kernel<CIN_REAL, CIN, COUT, MODE>, (int)lds, attr_devs); e != hipSuccess) return e;
+    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_s2_f16x3_kernel<CIN_REAL, CIN, COUT, MODE, F32>, (int)lds, attr_devs); e != hipSuccess) return e;
     const int tiles = (Sc + 15) / 16;
     const int ntiles = N * tiles * tiles;
     if (MODE == 1) kdiv = ntiles;                                          // data gradient: 1-D grid, see the kernel
-    hipLaunchKernelGGL((conv3x3_s2_f16x3_kernel<CIN_REAL, CIN, COUT, MODE>), dim3(MODE == 0 ? ntiles : ((ntiles + 7) / 8) * 32),
+    hipLaunchKernelGGL((conv3x3_s2_f16x3_kernel<CIN_REAL, CIN, COUT, MODE, F32>), dim3(MODE == 0 ? ntiles : ((ntiles + 7) / 8) * 32),
                        dim3(256), lds, st, in, reinterpret_cast<const uint4*>(wpk), wmeta, bias, aux, out, Sc, tiles, kdiv);
     return hipGetLastError();
 }
@@ -348,28 +394,64 @@ hipError_t launch_s2_inst(hipStream_t st, const float* in, const void* wpk, cons
 // Split first layer (the encoding's channels that all slots of an image share are convolved once per image):
 //   bias == nullptr          raw result, no bias / ELU (the per-image part; cin_real 8, packed with cin_pad 16)
 //   addmap != nullptr, kdiv  out = ELU(conv + bias + addmap[n / kdiv])   (the per-slot part; cin_real 12, cin_pad 16)
+// f32 = 1: exact fp32 MFMA form (wpk = launch_pack_conv_weights_s2f32 with the same cin_pad / cout / tflip; wmeta unused).
 hipError_t launch_conv3x3_s2_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
-                                   float* out, int N, int S, int cin_real, int cout, const float* addmap, int kdiv)
+                                   float* out, int N, int S, int cin_real, int cout, const float* addmap, int kdiv, int f32)
 {
     IOD_XSKIP(512);
     if (S % 2 != 0 || S < 2 || (addmap != nullptr) != (kdiv > 0)) return hipErrorInvalidValue;
 #define S2F_CASE(CR, CP, CO) \
-    if (cin_real == CR && cout == CO) return launch_s2_inst<CR, CP, CO, 0>(st, in, wpk, wmeta, bias, addmap, out, N, S / 2, kdiv);
+    if (cin_real == CR && cout == CO) return f32 ? launch_s2_inst<CR, CP, CO, 0, true>(st, in, wpk, wmeta, bias, addmap, out, N, S / 2, kdiv) \
+                                                 : launch_s2_inst<CR, CP, CO, 0>(st, in, wpk, wmeta, bias, addmap, out, N, S / 2, kdiv);
     S2F_CASE(20, 32, 64) S2F_CASE(64, 64, 64) S2F_CASE(20, 32, 32) S2F_CASE(32, 32, 32)
     S2F_CASE(12, 16, 64) S2F_CASE(8, 16, 64) S2F_CASE(12, 16, 32) S2F_CASE(8, 16, 32)
 #undef S2F_CASE
     return hipErrorInvalidValue;
 }
 
+namespace {
+// fp32 weights in the LDS-tile layout of conv_s2_body<.., F32 = true>: [chunk of 16 cin][tap][term][k half][cout] x 4 floats,
+// element e of slot (term, kh, co) = input channel 16 chunk + 8 kh + 4 term + e (tflip as in pack_f16_element)
+__global__ void pack_conv_weights_s2f32_kernel(const float* __restrict__ src, int O, int I, int cin, int cout, int tflip, float* __restrict__ dst)
+{
+    const size_t total = (size_t)(cin / 16) * 9 * 2 * 2 * cout * 4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 3;
+        size_t r = idx >> 2;
+        const int co = r % cout; r /= cout;
+        const int kh = r & 1; r >>= 1;
+        const int term = r & 1; r >>= 1;
+        const int tap = r % 9;
+        const int chunk = (int)(r / 9);
+        const int ci = chunk * 16 + kh * 8 + term * 4 + e;
+        float v = 0.f;
+        if (!tflip) { if (ci < I && co < O) v = src[((size_t)co * I + ci) * 9 + tap]; }
+        else if (tflip == 1) { if (ci < O && co < I) v = src[((size_t)ci * I + co) * 9 + (8 - tap)]; }
+        else { if (ci < O && co < I) v = src[((size_t)ci * I + co) * 9 + tap]; }
+        dst[idx] = v;
+    }
+}
+}  // namespace
+
+hipError_t launch_pack_conv_weights_s2f32(hipStream_t st, const float* src, int O, int I, int cin, int cout, int tflip, void* dst)
+{
+    const size_t total = (size_t)(cin / 16) * 9 * 2 * 2 * cout * 4;
+    hipLaunchKernelGGL(pack_conv_weights_s2f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, O, I, cin, cout, tflip,
+                       (float*)dst);
+    return hipGetLastError();
+}
+
 // Data gradient of the stride-2 conv times ELU'(aux): d = coarse [N][S/2][S/2][cout_conv] -> out = fine [N][S][S][cin_conv];
 // wpk = launch_pack_conv_weights_f16(w, O, I, cin_pad = O(conv out), cout = I(conv in), tflip 2).
 hipError_t launch_conv3x3_s2_dgrad_f16x3(hipStream_t st, const float* d, const void* wpk, const float* wmeta, const float* aux,
-                                         float* out, int N, int S, int c)
+                                         float* out, int N, int S, int c, int f32)
 {
     IOD_XSKIP(1024);
     if (S % 2 != 0 || S < 2) return hipErrorInvalidValue;
-    if (c == 64) return launch_s2_inst<64, 64, 64, 1>(st, d, wpk, wmeta, nullptr, aux, out, N, S / 2);
-    if (c == 32) return launch_s2_inst<32, 32, 32, 1>(st, d, wpk, wmeta, nullptr, aux, out, N, S / 2);
+    if (c == 64) return f32 ? launch_s2_inst<64, 64, 64, 1, true>(st, d, wpk, wmeta, nullptr, aux, out, N, S / 2)
+                            : launch_s2_inst<64, 64, 64, 1>(st, d, wpk, wmeta, nullptr, aux, out, N, S / 2);
+    if (c == 32) return f32 ? launch_s2_inst<32, 32, 32, 1, true>(st, d, wpk, wmeta, nullptr, aux, out, N, S / 2)
+                            : launch_s2_inst<32, 32, 32, 1>(st, d, wpk, wmeta, nullptr, aux, out, N, S / 2);
     return hipErrorInvalidValue;
 }
 
@@ -586,6 +668,167 @@ void conv3x3_s2_wgrad_f16x3_kernel(const float* __restrict__ a, const float* __r
     }
 }
 
+// Exact-fp32 form (conv_precision 0, round 5): dW on v_mfma_f32_32x32x2_f32 with K = two neighbouring coarse pixels.  Both operands are
+// staged as fp32 CHANNEL PLANES (one ds_write_b32 per element, plane strides odd: the 16 channel quads x 4 pixels a wave writes per
+// instruction hit 64 distinct banks), the fine input un-de-interleaved: lane (kh, li) reads channel li at fine column 4 s + 2 kh + kx of
+// halo row 2 r + ky - one ds_read_b32 with an immediate offset per MFMA operand, 80 reads for the 72 MFMAs (4608 matrix-pipe cycles) of a
+// tile row, so nothing but the matrix pipe matters.  The next tile's loads are in flight under the current tile's MFMAs; same partial-tile
+// / bias-partial interface as the split kernel above.
+template <int CI_REAL, int CI, int NCO, int TH>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_s2_wgrad_f32_kernel(const float* __restrict__ a, const float* __restrict__ d, float* __restrict__ part,
+                                 float* __restrict__ part_b, int Sc, int ntiles, int tiles_x, int tiles_y,
+                                 const float* __restrict__ a2, int kdiv)
+{
+    constexpr int MT = CI / 32, NTT = NCO / 32, KS = 4 / (MT * NTT);
+    static_assert(TH % KS == 0, "tile rows must split evenly over the K-split waves");
+    constexpr int RW = TH / KS;
+    constexpr int HR = 2 * TH + 1, AWD = 33;
+    constexpr int APL = HR * AWD, DPL = TH * 16 + 1;     // floats per channel plane, both odd
+    static_assert(APL % 2 == 1 && DPL % 2 == 1, "plane strides");
+    constexpr int A4 = CI_REAL / 4, D4 = NCO / 4;
+    constexpr int NA_UNITS = HR * AWD * A4, ND_UNITS = TH * 16 * D4;
+    constexpr int NAU = (NA_UNITS + 255) / 256, NDU = (ND_UNITS + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned smem_w2[];
+    float* s_a = reinterpret_cast<float*>(smem_w2);      // [CI][APL]
+    float* s_d = s_a + CI * APL;                         // [NCO][DPL]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, kh = lane >> 5, li = lane & 31;
+    const int mi = wv % MT, ni = (wv / MT) % NTT, ks = wv / (MT * NTT);
+    const int Sf = 2 * Sc;
+
+    if (CI_REAL < CI) {                                  // planes of the pad channels stay zero for the whole kernel
+        for (int i = CI_REAL * APL + tid; i < CI * APL; i += 256) s_a[i] = 0.f;
+    }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float4 ra[NAU], rd[NDU];
+    auto load_tile = [&](int tile) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int n = t / tiles_y;
+        // split first layer (a2 != nullptr, CI_REAL == 20): channels 0..11 from the per-slot tensor a[n] (12 floats per pixel),
+        // channels 12..19 from the per-image tensor a2[n / kdiv] (8 floats per pixel)
+        const float* a_n = a + (size_t)n * Sf * Sf * (a2 ? 12 : CI_REAL);
+        const float* a2_n = a2 ? a2 + (size_t)(n / kdiv) * Sf * Sf * 8 : nullptr;
+        const float* d_n = d + (size_t)n * Sc * Sc * NCO;
+#pragma unroll
+        for (int k = 0; k < NAU; ++k) {
+            const int u = tid + k * 256;
+            const int c4 = u % A4, tt = u / A4, col = tt % AWD, row = tt / AWD;
+            const int fy = 2 * ty * TH - 1 + row, fx = 32 * tx - 1 + col;
+            ra[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < NA_UNITS && fy >= 0 && fy < Sf && fx >= 0 && fx < Sf) {
+                const bool sh = a2_n && c4 >= 3;
+                const float* src = sh ? a2_n + (c4 - 3) * 4 : a_n + c4 * 4;
+                const int pst = a2_n ? (sh ? 8 : 12) : CI_REAL;
+                ra[k] = *reinterpret_cast<const float4*>(src + ((size_t)fy * Sf + fx) * pst);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NDU; ++k) {
+            const int u = tid + k * 256;
+            const int c4 = u % D4, tt = u / D4, p = tt % 16, row = tt / 16;
+            const int gy = ty * TH + row, gx = tx * 16 + p;
+            rd[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < ND_UNITS && gy < Sc && gx < Sc) rd[k] = *reinterpret_cast<const float4*>(d_n + ((size_t)gy * Sc + gx) * NCO + c4 * 4);
+        }
+    };
+
+    const float* pa = s_a + (mi * 32 + li) * APL + 2 * kh;
+    const float* pd = s_d + (ni * 32 + li) * DPL + kh;
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                   // every wave is done with the previous tile's planes
+#pragma unroll
+        for (int k = 0; k < NAU; ++k) {
+            const int u = tid + k * 256;
+            if (u < NA_UNITS) {
+                const int c4 = u % A4, tt = u / A4;      // tt = row * AWD + col
+                float* dst = s_a + (c4 * 4) * APL + tt;
+                dst[0] = ra[k].x; dst[APL] = ra[k].y; dst[2 * APL] = ra[k].z; dst[3 * APL] = ra[k].w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NDU; ++k) {
+            const int u = tid + k * 256;
+            if (u < ND_UNITS) {
+                const int c4 = u % D4, tt = u / D4;      // tt = row * 16 + p
+                float* dst = s_d + (c4 * 4) * DPL + tt;
+                dst[0] = rd[k].x; dst[DPL] = rd[k].y; dst[2 * DPL] = rd[k].z; dst[3 * DPL] = rd[k].w;
+                bsum.x += rd[k].x; bsum.y += rd[k].y; bsum.z += rd[k].z; bsum.w += rd[k].w;
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + (int)gridDim.x);     // in flight under the MFMAs below
+
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int r = ks * RW + rr;
+            float bq[8];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) bq[s8] = pd[r * 16 + 2 * s8];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* prow = pa + (2 * r + ky) * AWD;
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(prow[4 * s8 + kx], bq[s8], acc[ky * 3 + kx], 0, 0, 0);
+            }
+        }
+    }
+
+    float* pw = part + ((size_t)(blockIdx.x * KS + ks) * 9) * CI * NCO;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            pw[((size_t)tap * CI + cr) * NCO + ni * 32 + li] = acc[tap][r];
+        }
+    __syncthreads();
+    float4* s_red = reinterpret_cast<float4*>(smem_w2);
+    s_red[tid] = bsum;
+    __syncthreads();
+    if (tid < D4) {
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = tid; j < 256; j += D4) { const float4 v = s_red[j]; t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w; }
+        *reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * NCO + tid * 4) = t4;
+    }
+}
+
+template <int CI_REAL, int CI, int NCO, int TH>
+hipError_t launch_s2_wgrad32_inst(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N, int Sc,
+                                  int* nparts, int* cipad, int* nbias_parts, const float* a2, int kdiv)
+{
+    constexpr int MT = CI / 32, NTT = NCO / 32, KS = 4 / (MT * NTT);
+    constexpr size_t lds = (size_t)(CI * (2 * TH + 1) * 33 + NCO * (TH * 16 + 1)) * 4;
+    static_assert(lds >= 256 * 16, "bias reduction reuses the planes");
+    static std::atomic<unsigned> attr_devs{0};
+    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_s2_wgrad_f32_kernel<CI_REAL, CI, NCO, TH>, (int)lds, attr_devs); e != hipSuccess) return e;
+    const int tiles_x = (Sc + 15) / 16, tiles_y = (Sc + TH - 1) / TH, ntiles = N * tiles_x * tiles_y;
+    const int blocks = ntiles < 512 ? ntiles : 512;
+    hipLaunchKernelGGL((conv3x3_s2_wgrad_f32_kernel<CI_REAL, CI, NCO, TH>), dim3(blocks), dim3(256), lds, st, a, d, part,
+                       part_b, Sc, ntiles, tiles_x, tiles_y, a2, kdiv);
+    *nparts = blocks * KS;
+    *cipad = CI;
+    *nbias_parts = blocks;
+    return hipGetLastError();
+}
+
 template <int CI_REAL, int CI, int NCO, int TH>
 hipError_t launch_s2_wgrad_inst(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N, int Sc,
                                 int* nparts, int* cipad, int* nbias_parts, const float* a2, int kdiv)
@@ -612,12 +855,14 @@ hipError_t launch_s2_wgrad_inst(hipStream_t st, const float* a, const float* d, 
 // a2 / kdiv: split first layer - 12 per-slot channels from a, 8 per-image channels from a2[n / kdiv] (ci_real 20 only).
 hipError_t launch_conv3x3_s2_wgrad_f16x3(hipStream_t st, const float* a, const float* d, float* part, float* part_b, int N,
                                          int S, int ci_real, int nco, int* nparts, int* cipad, int* nbias_parts,
-                                         const float* a2, int kdiv)
+                                         const float* a2, int kdiv, int f32)
 {
     IOD_XSKIP(1024);
     if (S % 2 != 0 || S < 2 || (a2 && (ci_real != 20 || kdiv < 1))) return hipErrorInvalidValue;
 #define S2W_CASE(CR, CP, CO, TH) \
-    if (ci_real == CR && nco == CO) return launch_s2_wgrad_inst<CR, CP, CO, TH>(st, a, d, part, part_b, N, S / 2, nparts, cipad, nbias_parts, a2, kdiv);
+    if (ci_real == CR && nco == CO) \
+        return f32 ? launch_s2_wgrad32_inst<CR, CP, CO, TH>(st, a, d, part, part_b, N, S / 2, nparts, cipad, nbias_parts, a2, kdiv) \
+                   : launch_s2_wgrad_inst<CR, CP, CO, TH>(st, a, d, part, part_b, N, S / 2, nparts, cipad, nbias_parts, a2, kdiv);
     S2W_CASE(64, 64, 64, 2) S2W_CASE(20, 32, 64, 4) S2W_CASE(32, 32, 32, 4) S2W_CASE(20, 32, 32, 4)
 #undef S2W_CASE
     return hipErrorInvalidValue;

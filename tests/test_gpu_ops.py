@@ -278,6 +278,34 @@ def test_conv_s2_f16x3_dgrad(C_, S, N):
     assert rel_err(got, nhwc(refd)) < 3e-6, rel_err(got, nhwc(refd))
 
 
+@pytest.mark.parametrize('cin,cpad,cout,S,N', [(17, 20, 64, 32, 3), (64, 64, 64, 16, 5), (17, 20, 32, 16, 2), (32, 32, 32, 8, 7),
+                                                (64, 64, 64, 128, 1), (32, 32, 32, 4, 3), (64, 64, 64, 64, 9),
+                                                (11, 12, 64, 64, 4), (6, 8, 64, 32, 5), (11, 12, 32, 16, 3)])
+def test_conv_s2_exact_fp32_forward(cin, cpad, cout, S, N):
+    """exact-fp32 form of the stride-2 conv + bias + ELU (op mode 13, conv_precision 0: v_mfma_f32_32x32x2_f32 on the same stages;
+    12 / 8 channel inputs = the two halves of the split first layer)"""
+    x = _rand(N, cin, S, S, seed=30)
+    w = _rand(cout, cin, 3, 3, seed=31, scale=3.0 / (cin * 9) ** 0.5)
+    b = _rand(cout, seed=32, scale=0.5)
+    ref = nhwc(F.elu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1))).float()
+    xp = torch.full((N, S, S, cpad), 7.0)
+    xp[..., :cin] = nhwc(x)
+    got = _conv_op(13, xp, w, b, None, N, S, S, cout, cin, cpad, cout, 2, 0, 0, ref.shape)
+    assert rel_err(got, ref) < 2e-6, rel_err(got, ref)
+
+
+@pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 2), (64, 128, 1), (32, 4, 5), (64, 16, 40)])
+def test_conv_s2_exact_fp32_dgrad(C_, S, N):
+    """exact-fp32 form of the stride-2 data gradient times ELU'(saved activation) (op mode 14)"""
+    g = _rand(N, C_, S // 2, S // 2, seed=33, scale=1e-3)
+    w = _rand(C_, C_, 3, 3, seed=34, scale=3.0 / (C_ * 9) ** 0.5)
+    a = F.elu(_rand(N, C_, S, S, seed=35, scale=2.0))
+    refd = (F.conv_transpose2d(g.double(), w.double(), stride=2, padding=1, output_padding=1)
+            * torch.where(a > 0, torch.ones_like(a), a + 1).double()).float()
+    got = _conv_op(14, nhwc(g), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 2, 1, 2, nhwc(refd).shape)
+    assert rel_err(got, nhwc(refd)) < 2e-6, rel_err(got, nhwc(refd))
+
+
 def _wgrad_op(x_nhwc, d_nhwc, n, s, ci_pad, ci_real, co, stride):
     L = _lib.lib()
     gw = torch.zeros(co, ci_real, 3, 3, device=DEV)
@@ -308,6 +336,25 @@ def test_conv_wgrad_f16x3(cin, cpad, cout, S, N, stride):
     gw, gb = _wgrad_op(xp, nhwc(d.float()), N, S, cpad, cin, cout, stride)
     assert rel_err(gw, w.grad.float()) < 3e-6, rel_err(gw, w.grad.float())
     assert rel_err(gb, b.grad.float()) < 3e-6, rel_err(gb, b.grad.float())
+
+
+@pytest.mark.parametrize('cin,cpad,cout,S,N', [(17, 20, 64, 32, 3), (64, 64, 64, 16, 5), (17, 20, 32, 16, 2), (32, 32, 32, 8, 7),
+                                                (64, 64, 64, 128, 1), (32, 32, 32, 4, 3), (17, 20, 64, 128, 2), (64, 64, 64, 64, 9),
+                                                (64, 64, 64, 32, 40)])
+def test_conv_s2_wgrad_exact_fp32(cin, cpad, cout, S, N):
+    """exact-fp32 weight / bias gradient of the stride-2 convs (stride -2 on the op entry: v_mfma_f32_32x32x2_f32 over fp32 channel
+    planes, next tile prefetched) vs autograd in fp64; twice: bit-identical (fixed summation order)"""
+    x = _rand(N, cin, S, S, seed=40).double()
+    d = _rand(N, cout, S // 2, S // 2, seed=41, scale=1e-2).double()
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x, w, b, stride=2, padding=1) * d).sum().backward()
+    xp = torch.full((N, S, S, cpad), 7.0)
+    xp[..., :cin] = nhwc(x.float())
+    res = [_wgrad_op(xp, nhwc(d.float()), N, S, cpad, cin, cout, -2) for _ in range(2)]
+    assert rel_err(res[0][0], w.grad.float()) < 2e-6, rel_err(res[0][0], w.grad.float())
+    assert rel_err(res[0][1], b.grad.float()) < 2e-6, rel_err(res[0][1], b.grad.float())
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
 # ---- the split-fp16 arithmetic where it can actually break (VERDICT r02, weak #3) ------------------------------------------
