@@ -82,6 +82,7 @@ hipError_t launch_cell_max(hipStream_t st, const float* x, float* tmax, int N, i
 #ifdef IODINE_TILE_PROF
 __device__ unsigned g_ws_prof[TP_MAXBLK * 8];
 __device__ unsigned long long g_ws_ts[TP_MAXBLK * 16];
+__device__ unsigned long long g_ws_se[TP_MAXBLK * 2];       // [block]: s_memtime at the block's start / end
 #endif
 
 template <int I, int N, typename F>
@@ -408,6 +409,9 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
 #undef WS_DSR128
 
     if (nstage == 0) return;
+#ifdef IODINE_TILE_PROF
+    if (tid == 0 && blockIdx.x < TP_MAXBLK) g_ws_se[blockIdx.x * 2] = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef WS_ROLEPRIO
     // Two persistent blocks share a CU (one wave of each per SIMD).  Left alone they fall into LOCKSTEP - whoever lags gets the
     // matrix pipe to itself and catches up - so both sit in their epilogues at the same time and the pipe idles.  A static
@@ -422,6 +426,9 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
 #endif
 #ifndef WS_ALTPRIO
 #define WS_ALTPRIO 2
+#endif
+#if !defined(WS_ALTTIME) && !defined(WS_ALTTILES)
+#define WS_ALTTIME 1                             // (WS_ALTTILES: the tile-count form of rounds 2 - 4, kept for A/B builds)
 #endif
 #if WS_ALTPRIO > 0
     unsigned role;
@@ -445,7 +452,15 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
 #if WS_ALTPRIO > 0
         // the older of the two waves of a SIMD wins every arbitration and runs ~1.5x faster than its partner (56 vs 37 tiles in
         // the same time, then a long tail alone): swap the favoured role every WS_ALTPRIO tiles so that both progress alike
+#ifdef WS_ALTTIME
+        // (round 5) ... by the CLOCK, not by the block's own tile count: counted in tiles the two blocks of a CU drift apart until both hold
+        // the same priority at the same time (then the older wave wins every arbitration again): the block in wave slot 1 finished 354 k
+        // ticks = 4.5 tiles of 56 after its partner and ran that tail alone.  s_memtime is one counter per XCD: exactly one of the two is
+        // favoured at any time, for ~2 - 3 tiles
+        if ((((unsigned)(__builtin_amdgcn_s_memtime() >> (F32 ? 18 : 16))) ^ role) & 1u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#else
         if ((((unsigned)(s0 / NCHUNK) / WS_ALTPRIO) ^ role) & 1u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
         const int t = t0 + (s0 / NCHUNK) * bpx;
         int n, ty, tx;
@@ -666,6 +681,7 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         g_ws_prof[blockIdx.x * 8 + 6] = hwid; g_ws_prof[blockIdx.x * 8 + 7] = xcc;
+        g_ws_se[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
     }
 #endif
 #undef WS_BLOAD4
@@ -719,6 +735,30 @@ static hipError_t launch_ws_inst(hipStream_t st, const float* in, const void* wp
                 for (int i = 0; i < 16; ++i) fprintf(stderr, " %lld", (long long)(ts[(size_t)(b2 + 256) * 16 + i] - base));
                 fprintf(stderr, "\n");
             }
+        }
+        if (getenv("IODINE_WS_SE")) {                         // start / end of every block relative to the first start; pairs sharing a CU
+            std::vector<unsigned long long> se((size_t)nb * 2);
+            (void)hipMemcpyFromSymbol(se.data(), HIP_SYMBOL(g_ws_se), se.size() * sizeof(unsigned long long));
+            unsigned long long t0 = ~0ull;
+            for (int b2 = 0; b2 < nb; ++b2) t0 = std::min(t0, se[(size_t)b2 * 2]);
+            std::vector<long long> st_(nb), en_(nb);
+            for (int b2 = 0; b2 < nb; ++b2) { st_[b2] = (long long)(se[(size_t)b2 * 2] - t0); en_[b2] = (long long)(se[(size_t)b2 * 2 + 1] - t0); }
+            std::vector<long long> es(en_), ss(st_);
+            std::sort(es.begin(), es.end()); std::sort(ss.begin(), ss.end());
+            fprintf(stderr, "[ws prof] block start: median %lld max %lld | block end: min %lld p25 %lld median %lld p75 %lld max %lld\n", ss[nb / 2], ss[nb - 1],
+                    es[0], es[nb / 4], es[nb / 2], es[3 * nb / 4], es[nb - 1]);
+            // pairs on the same CU (same xcc / se / sh / cu bits of HW_ID)
+            int shown = 0;
+            for (int a = 0; a < nb && shown < 6; ++a)
+                for (int c2 = a + 1; c2 < nb; ++c2) {
+                    const unsigned ha = hp[(size_t)a * 8 + 6], hc = hp[(size_t)c2 * 8 + 6];
+                    if ((hp[(size_t)a * 8 + 7] & 0xf) == (hp[(size_t)c2 * 8 + 7] & 0xf) && ((ha >> 8) & 0xff) == ((hc >> 8) & 0xff)) {
+                        fprintf(stderr, "  CU pair blocks %d / %d: start %lld / %lld end %lld / %lld (wave slots %u / %u)\n", a, c2, st_[a], st_[c2], en_[a], en_[c2],
+                                ha & 0xf, hc & 0xf);
+                        ++shown;
+                        break;
+                    }
+                }
         }
         if (getenv("IODINE_WS_HWID")) {
             for (int b2 = 0; b2 < nb; ++b2) {
