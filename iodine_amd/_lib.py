@@ -23,7 +23,7 @@ EXPORTS = (
     'iodine_reconstruct', 'iodine_decode', 'iodine_elbo', 'iodine_last_elbo_outputs', 'iodine_last_posterior', 'iodine_randn',
     'iodine_train_forward', 'iodine_train_backward', 'iodine_train_backward_flat', 'iodine_logger_scalars',
     'iodine_adam_step', 'iodine_ari_table', 'iodine_set_option', 'iodine_profile_read', 'iodine_debug_copy', 'iodine_linspace_host', 'iodine_op_conv3x3', 'iodine_op_dec_out',
-    'iodine_op_conv3x3_wgrad', 'iodine_op_conv3x3_wgrad_f32', 'iodine_op_dec_out_f16x3',
+    'iodine_op_conv3x3_wgrad', 'iodine_op_conv3x3_wgrad_f32', 'iodine_op_dec_out_f16x3', 'iodine_op_gen_conv',
 )
 
 
@@ -97,6 +97,8 @@ def lib() -> C.CDLL:
     L.iodine_op_conv3x3_wgrad.argtypes = [vp] + [vp] * 4 + [ci] * 6
     if hasattr(L, 'iodine_op_dec_out_f16x3'):
         L.iodine_op_dec_out_f16x3.argtypes = [vp] + [vp] * 4 + [ci] * 4
+    if hasattr(L, 'iodine_op_gen_conv'):
+        L.iodine_op_gen_conv.argtypes = [vp, ci] + [vp] * 6 + [ci] * 8
     if hasattr(L, 'iodine_op_conv3x3_wgrad_f32'):       # (absent from older builds loaded through IODINE_HIP_LIB for same-box A/B)
         L.iodine_op_conv3x3_wgrad_f32.argtypes = [vp] + [vp] * 4 + [ci] * 3
     if L.iodine_abi_version() != 3:

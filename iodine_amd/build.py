@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, 'libiodine_hip.so')
-SOURCES = ['kernels_conv.hip', 'kernels_convws.hip', 'kernels_out.hip', 'kernels_pixel.hip', 'kernels_misc.hip', 'kernels_train.hip', 'kernels_wgrad32.hip', 'kernels_refine.hip', 'kernels_refbwd.hip', 'kernels_refws.hip', 'kernels_refl0.hip', 'kernels_pack.hip', 'kernels_generic.hip', 'kernels_genl0.hip', 'iodine_api.cpp']
+SOURCES = ['kernels_conv.hip', 'kernels_convws.hip', 'kernels_out.hip', 'kernels_pixel.hip', 'kernels_misc.hip', 'kernels_train.hip', 'kernels_wgrad32.hip', 'kernels_refine.hip', 'kernels_refbwd.hip', 'kernels_refws.hip', 'kernels_refl0.hip', 'kernels_pack.hip', 'kernels_generic.hip', 'kernels_gens2.hip', 'kernels_genl0.hip', 'iodine_api.cpp']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'pixel_terms.h'), os.path.join(CSRC, 'pack_bodies.h'), os.path.join(ROOT, 'include', 'iodine_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
          '-Wno-unused-result'] + os.environ.get('IODINE_EXTRA_HIPCC_FLAGS', '').split()   # e.g. -DIODINE_TILE_PROF (tools only)

@@ -357,6 +357,16 @@ hipError_t launch_gen_l0_fwd(hipStream_t st, const float* z, const float* wt0, c
                              int Co, int k);
 hipError_t launch_gen_l0_bwd(hipStream_t st, const float* dpre, const float* z, const float* wt0, const float* lin, float* scratch, int N, int L,
                              int S, int Co, int k, float alpha, float* gw, float* gb, float* dz, int ld);
+// kernels_gens2.hip: the stride-2 convs of the generic path on v_mfma_f32_16x16x4_f32 (round 5)
+bool gen_s2_fwd_ok(int k, int Ci, int ldc, int Co);
+bool gen_s2_dgrad_ok(int k, int Ci, int ldi, int Co);
+bool gen_s2_wgrad_ok(int k, int Ci, int ldc, int Co);
+hipError_t launch_gen_s2_fwd(hipStream_t st, const float* in, const float* wt, const float* bias, float* out, int N, int Si, int Ci, int ldc,
+                             int Co, int k, int elu);
+hipError_t launch_gen_s2_dgrad(hipStream_t st, const float* dout, const float* wt, const float* aux, float* din, int N, int Si, int Ci, int ldi,
+                               int Co, int k);
+hipError_t launch_gen_s2_wgrad(hipStream_t st, const float* in, const float* dout, float* part, int N, int Si, int Ci, int ldc, int Co, int k,
+                               int nsl_max, int* nsl_out);
 hipError_t launch_gen_identity(hipStream_t st, float* m, int rows, int L);
 hipError_t launch_ref_unsplit_grad(hipStream_t st, const float* g20, int O, float* gw);
 hipError_t launch_enc_join(hipStream_t st, const float* enck, const float* encs, float* enc, int N, int K, int P);

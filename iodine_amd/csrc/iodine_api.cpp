@@ -1931,6 +1931,32 @@ int iodine_op_conv3x3_wgrad(void* stream, const float* in, const float* d, float
     return IODINE_OK;
 }
 
+int iodine_op_gen_conv(void* stream, int mode, const float* in, const float* w, const float* bias, const float* aux, float* out, float* gb,
+                       int n, int si, int ci, int ldc, int co, int k, int s, int elu)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (mode < 0 || mode > 2 || (s != 1 && s != 2) || (k != 3 && k != 5 && k != 7) || ldc < ci) { g_create_error = "iodine_op_gen_conv: argument"; return IODINE_ERR_INVALID; }
+    float* buf = nullptr;
+    // weights [tap][ci][co]: the forward pack has ci rows, the data-gradient pack ldc rows (the packed input-channel count is din's stride)
+    const size_t wfl = (size_t)k * k * ldc * co, scr = mode == 2 ? gen_wgrad_scratch_floats(ci, co, k) : 0;
+    if (hipMalloc((void**)&buf, (wfl + scr) * sizeof(float)) != hipSuccess) return IODINE_ERR_HIP;
+    hipError_t e = hipSuccess;
+    if (mode == 0) {
+        e = launch_gen_pack_weights(st, w, co, ci, k, buf);
+        if (e == hipSuccess) e = launch_gen_conv_fwd(st, in, buf, bias, out, n, si, ci, ldc, co, k, s, elu);
+    } else if (mode == 1) {
+        if (ci != ldc) { (void)hipFree(buf); g_create_error = "iodine_op_gen_conv: mode 1 needs ldc == ci"; return IODINE_ERR_INVALID; }
+        e = launch_gen_pack_weights(st, w, co, ci, k, buf);
+        if (e == hipSuccess) e = launch_gen_conv_dgrad(st, in, buf, aux, out, n, si, ci, ldc, co, k, s);
+    } else {
+        e = launch_gen_conv_wgrad(st, in, aux, buf + wfl, n, si, ci, ldc, ci, co, k, s, 1.f, out, gb);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    if (e != hipSuccess) { g_create_error = std::string("iodine_op_gen_conv: ") + hipGetErrorString(e); return IODINE_ERR_HIP; }
+    return IODINE_OK;
+}
+
 int iodine_op_conv3x3_wgrad_f32(void* stream, const float* in, const float* d, float* gw, float* gb, int n, int s, int c)
 {
     hipStream_t st = (hipStream_t)stream;

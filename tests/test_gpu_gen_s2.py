@@ -1,0 +1,79 @@
+"""Kernel-level parity of the generic path's convolutions (kernels_generic.hip / kernels_gens2.hip) against PyTorch-CPU fp64 convs: the
+stride-2 forms of the refinement stack with REF.KERNEL_SIZE 5 / 7 (reference: configs/test.yaml:40, lib/modeling/iodine.py:459,480) run
+on v_mfma_f32_16x16x4_f32 since round 5 - forward, data gradient (four parity classes) and weight gradient, incl. the 17-of-20-channel
+first layer, ragged image sizes and channel counts that are not multiples of 16."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from iodine_amd import _lib
+from util import nhwc, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _op(mode, x, w, bias, aux, out, gb, n, si, ci, ldc, co, k, s, elu):
+    L = _lib.lib()
+    t = [v.to(DEV).contiguous() if v is not None else None for v in (x, w, bias, aux)]
+    _lib.check(L.iodine_op_gen_conv(None, mode, _lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), _lib.ptr(t[3]), _lib.ptr(out),
+                                    _lib.ptr(gb) if gb is not None else None, n, si, ci, ldc, co, k, s, elu), None, 'iodine_op_gen_conv')
+    torch.cuda.synchronize()
+
+
+CASES = [  # ci, ldc, co, k, S, N
+    (17, 20, 32, 5, 64, 3), (32, 32, 32, 5, 32, 4), (32, 32, 32, 5, 16, 5), (17, 20, 64, 7, 32, 2), (64, 64, 64, 7, 16, 3),
+    (17, 20, 32, 3, 32, 3), (24, 24, 24, 5, 36, 2), (48, 48, 48, 5, 18, 3), (8, 8, 8, 7, 20, 2), (17, 20, 128, 5, 32, 1),
+    (32, 32, 32, 5, 7, 3), (32, 32, 32, 5, 64, 40)]
+
+
+@pytest.mark.parametrize('ci,ldc,co,k,S,N', CASES)
+def test_gen_stride2_forward(ci, ldc, co, k, S, N):
+    x = _rand(N, ci, S, S, seed=50)
+    w = _rand(co, ci, k, k, seed=51, scale=3.0 / (ci * k * k) ** 0.5)
+    b = _rand(co, seed=52, scale=0.5)
+    ref = nhwc(F.elu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=k // 2))).float()
+    xp = torch.full((N, S, S, ldc), float('nan'))              # what lies past the ci real channels must never be read into the sum
+    xp[..., :ci] = nhwc(x)
+    out = torch.full(ref.shape, float('nan'), device=DEV)
+    _op(0, xp, w, b, None, out, None, N, S, ci, ldc, co, k, 2, 1)
+    assert rel_err(out.cpu(), ref) < 2e-6, rel_err(out.cpu(), ref)
+
+
+@pytest.mark.parametrize('ci,ldc,co,k,S,N', [c for c in CASES if c[0] == c[1]])
+def test_gen_stride2_dgrad(ci, ldc, co, k, S, N):
+    So = (S - 1) // 2 + 1
+    g = _rand(N, co, So, So, seed=53, scale=1e-2)
+    w = _rand(co, ci, k, k, seed=54, scale=3.0 / (ci * k * k) ** 0.5)
+    a = F.elu(_rand(N, ci, S, S, seed=55, scale=2.0))
+    x = torch.zeros(N, ci, S, S, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x, w.double(), None, stride=2, padding=k // 2) * g.double()).sum().backward()
+    ref = nhwc((x.grad * torch.where(a > 0, torch.ones_like(a), a + 1).double()).float())
+    out = torch.full(ref.shape, float('nan'), device=DEV)
+    _op(1, nhwc(g), w, None, nhwc(a), out, None, N, S, ci, ldc, co, k, 2, 0)
+    assert rel_err(out.cpu(), ref) < 2e-6, rel_err(out.cpu(), ref)
+
+
+@pytest.mark.parametrize('ci,ldc,co,k,S,N', CASES)
+def test_gen_stride2_wgrad(ci, ldc, co, k, S, N):
+    So = (S - 1) // 2 + 1
+    x = _rand(N, ci, S, S, seed=56).double()
+    d = _rand(N, co, So, So, seed=57, scale=1e-2).double()
+    w = torch.zeros(co, ci, k, k, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x, w, b, stride=2, padding=k // 2) * d).sum().backward()
+    xp = torch.full((N, S, S, ldc), float('nan'))
+    xp[..., :ci] = nhwc(x.float())
+    res = []
+    for _ in range(2):
+        gw, gb = torch.zeros(co, ci, k, k, device=DEV), torch.zeros(co, device=DEV)
+        _op(2, xp, None, None, nhwc(d.float()), gw, gb, N, S, ci, ldc, co, k, 2, 0)
+        res.append((gw.cpu(), gb.cpu()))
+    assert rel_err(res[0][0], w.grad.float()) < 2e-6, rel_err(res[0][0], w.grad.float())
+    assert rel_err(res[0][1], b.grad.float()) < 2e-6, rel_err(res[0][1], b.grad.float())
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])      # fixed summation order
