@@ -655,6 +655,34 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:                      # noqa: BLE001 - a side measurement must not break the bench line
             side['default_dec_kernel5'] = dict(error=f'{type(e).__name__}: {e}')
+        # the reference's configs/test.yaml architecture: KERNEL_SIZE 5 in BOTH stacks (decoder 32 ch x 5 layers, refinement 32 ch x 3 layers
+        # stride 2), 64 x 64, K = 6, T = 5, 4-entry ENCODING - the one shipped configuration whose refinement stack is off the tuned path
+        try:
+            from iodine_amd.model import arch_namespace
+            at = arch_namespace(16, 5, 6, 64, (32, 3, 128), (32, 5), sigma=0.14, kernels=(5, 5),
+                                encoding=['posterior', 'grad_post', 'image', 'leave_one_out_likelihood'])
+            mt = IODINE(at)
+            sht = {k: tuple(v.shape) for k, v in mt.state_dict().items()}
+            mt.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(sht, seed=0).items()})
+            mt = mt.to(device)
+            mt.manual_seed(7)
+            bt = 32
+            xt = torch.from_numpy(synth.make_images(bt, 64, seed=0)).to(device)
+            rec = dict(workload=f'configs/test.yaml architecture (REF / DEC KERNEL_SIZE 5, 32 channels, 64x64, K=6, T=5), batch {bt}, 1 GPU', steps=4,
+                       path='generic path, both stacks on exact-fp32 MFMA: decoder kernels_generic.hip / kernels_genl0.hip, stride-2 refinement convs '
+                            'kernels_gens2.hip (v_mfma_f32_16x16x4_f32; scalar tier until round 5: 118 / 27.7 ms)')
+            for md in ('train', 'infer'):
+                stt, _ = make_step(mt, xt, md)
+                stt()
+                dt_ = timed(stt, 4) / 4
+                rec[f'{md}_ms'] = round(dt_ * 1e3, 3)
+                rec[f'{md}_iters_per_s'] = round(bt * 5 / dt_, 1)
+                del stt
+            side['test_yaml_arch'] = rec
+            del mt, xt
+            torch.cuda.empty_cache()
+        except Exception as e:                      # noqa: BLE001
+            side['test_yaml_arch'] = dict(error=f'{type(e).__name__}: {e}')
         out['configs'] = side
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

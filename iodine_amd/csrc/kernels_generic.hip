@@ -5,9 +5,9 @@
 //
 // Two tiers.  Stride-1 convs (the decoder: ~96 % of the FLOPs) run on exact-fp32 MFMA kernels since round 4 (further down: LDS-resident
 // weight slice per 16 output channels, 16 x 16 pixel tiles, v_mfma_f32_16x16x4_f32; weight gradient on v_mfma_f32_32x32x2_f32) whenever
-// the weight slice fits LDS - 5 x 5 x 64 channels does, 7 x 7 up to 32 channels.  Everything else (stride 2 = the refinement stack,
-// larger slices) runs on the scalar kernels right below: one thread per output element, plain fp32 FMAs in a fixed order, written for
-// correctness.  All of it is deterministic.  The spatial-broadcast layer (decoder layer 0) has its own kernels (kernels_genl0.hip: the broadcast
+// the weight slice fits LDS - 5 x 5 x 64 channels does, 7 x 7 up to 32 channels.  Stride 2 (the refinement stack) runs on the MFMA kernels of
+// kernels_gens2.hip since round 5.  Everything else (larger slices, channel counts that are not multiples of 4) runs on the scalar kernels
+// right below: one thread per output element, plain fp32 FMAs in a fixed order, written for correctness.  All of it is deterministic.  The spatial-broadcast layer (decoder layer 0) has its own kernels (kernels_genl0.hip: the broadcast
 // tensor is never built; until round 5 it was materialised as [N][P][L+2] and convolved like any other layer).  Every shipped / benchmarked configuration stays on the
 // tuned path (iodine_api.cpp: `generic` is false for KERNEL_SIZE 3 with 32 / 64 channels).  Measured (MI355X, CLEVR shapes with
 // DEC.KERNEL_SIZE 5, batch 4): training step 4977 -> 206 ms, reconstruct 2317 -> 96 ms against the scalar tier (round 4); 48.7 / 30.6 ms

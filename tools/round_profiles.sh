@@ -40,5 +40,14 @@ python $REPO/tools/rocpd_summary.py $(ls $OUT/${TAG}_prof_ds/*/*.db | head -1) >
 rm -rf $OUT/${TAG}_prof_k5
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_k5 -- python $REPO/tools/experiments/k5_prof.py > $OUT/${TAG}_prof_k5.log 2>&1
 python $REPO/tools/rocpd_summary.py $(ls $OUT/${TAG}_prof_k5/*/*.db | head -1) > $OUT/${TAG}_dec_kernel5_train_kernel_stats.md
+# the reference's configs/test.yaml architecture (KERNEL_SIZE 5 in both stacks, batch 32: configs.test_yaml_arch) - generic decoder + kernels_gens2.hip
+rm -rf $OUT/${TAG}_prof_ty
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_ty -- python $REPO/tools/experiments/testyaml_prof.py 32 > $OUT/${TAG}_prof_ty.log 2>&1
+python $REPO/tools/rocpd_summary.py $(ls $OUT/${TAG}_prof_ty/*/*.db | head -1) > $OUT/${TAG}_testyaml_train_kernel_stats.md
+# matrix-pipe utilisation / clock of every kernel of the strict path
+rm -rf $OUT/${TAG}_pmc_strict
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_strict -o p -- python $REPO/bench.py --conv-precision 0 --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 --no-extra-configs --no-sustain > $OUT/${TAG}_pmc_strict.log 2>&1
+python $REPO/tools/mfma_util_all.py $OUT/${TAG}_pmc_strict > $OUT/${TAG}_strict_mfma_util.md
+rm -rf $OUT/${TAG}_pmc_strict
 cd $REPO
 ls $OUT | grep $TAG
