@@ -214,6 +214,17 @@ def test_generic_decoder_at_full_image_sizes(what):
     _step_vs_oracle(arch, params, x, eps)
 
 
+def test_reference_test_yaml_arch():
+    """configs/test.yaml:26-52 verbatim - ITERS 5, SLOTS 6, SIGMA 0.14, DIM_LATENT 16, IMG_SIZE 64, REF 32 x 3 with KERNEL_SIZE 5 (stride 2),
+    MLP 128, DEC 32 x 5 with KERNEL_SIZE 5, the four-entry ENCODING: the one shipped configuration whose REFINEMENT stack is off the tuned
+    path (kernels_gens2.hip: stride-2 5 x 5 convs on fp32 MFMA since round 5), against the oracle"""
+    arch = O.Arch(dim_latent=16, iters=5, slots=6, sigma=0.14, img_size=64, ref_chan=32, ref_layers=3, ref_mlp=128, ref_kernel=5,
+                  dec_chan=32, dec_layers=5, dec_kernel=5, encoding=('posterior', 'grad_post', 'image', 'leave_one_out_likelihood'))
+    params, x, eps = _case(arch, 2, seed=23)
+    m = _step_vs_oracle(arch, params, x, eps)
+    assert m.get_input_size() == (4, 64) and tuple(m.refine.mlc.layers[0].weight.shape) == (32, 4, 5, 5)
+
+
 def test_reference_default_arch():
     """lib/config/defaults.py:35-100 verbatim - ITERS 5, SLOTS 7, SIGMA 0.13, DIM_LATENT 128, IMG_SIZE 32, REF 32 x 3 (k 3, stride 2),
     MLP 256, DEC 64 x 5 with KERNEL_SIZE 5, ENCODING without 'coordinate': the configuration a user of the reference gets without a
