@@ -427,6 +427,12 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
 #ifndef WS_ALTPRIO
 #define WS_ALTPRIO 2
 #endif
+#ifndef WS_ALT_SH32
+#define WS_ALT_SH32 18                           // favoured-role period of the clock-based alternation: 2^18 ticks (fp32 form), 2^16 (split-fp16)
+#endif
+#ifndef WS_ALT_SH16
+#define WS_ALT_SH16 16
+#endif
 #if !defined(WS_ALTTIME) && !defined(WS_ALTTILES)
 #define WS_ALTTIME 1                             // (WS_ALTTILES: the tile-count form of rounds 2 - 4, kept for A/B builds)
 #endif
@@ -457,7 +463,7 @@ void conv3x3_ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restri
         // the same priority at the same time (then the older wave wins every arbitration again): the block in wave slot 1 finished 354 k
         // ticks = 4.5 tiles of 56 after its partner and ran that tail alone.  s_memtime is one counter per XCD: exactly one of the two is
         // favoured at any time, for ~2 - 3 tiles
-        if ((((unsigned)(__builtin_amdgcn_s_memtime() >> (F32 ? 18 : 16))) ^ role) & 1u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        if ((((unsigned)(__builtin_amdgcn_s_memtime() >> (F32 ? WS_ALT_SH32 : WS_ALT_SH16))) ^ role) & 1u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
 #else
         if ((((unsigned)(s0 / NCHUNK) / WS_ALTPRIO) ^ role) & 1u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
 #endif
