@@ -77,3 +77,42 @@ def test_gen_stride2_wgrad(ci, ldc, co, k, S, N):
     assert rel_err(res[0][0], w.grad.float()) < 2e-6, rel_err(res[0][0], w.grad.float())
     assert rel_err(res[0][1], b.grad.float()) < 2e-6, rel_err(res[0][1], b.grad.float())
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])      # fixed summation order
+
+
+def _random_cases(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    out = []
+    for _ in range(n):
+        ci = 4 * r(1, 18)
+        out.append((ci, ci, 4 * r(1, 24), (3, 5, 7)[r(0, 2)], r(5, 40), r(1, 4)))
+    return out
+
+
+@pytest.mark.parametrize('ci,ldc,co,k,S,N', _random_cases(24, 7))
+def test_gen_stride2_random_shapes(ci, ldc, co, k, S, N):
+    """seeded sweep over channel counts (multiples of 4 up to 72 / 96), kernel sizes, ragged image sizes: all three directions of one layer.
+    Gate 4e-6: a 7 x 7 conv over 64+ channels is a sum of > 3000 fp32 products accumulated four at a time - 2.4e-6 against fp64 is the
+    accumulation order's rounding (the fp32 ATen conv of the reference sits at the same distance), not a wrong element."""
+    So = (S - 1) // 2 + 1
+    x = _rand(N, ci, S, S, seed=60).double()
+    w = _rand(co, ci, k, k, seed=61, scale=3.0 / (ci * k * k) ** 0.5).double()
+    b = _rand(co, seed=62, scale=0.5).double()
+    d = _rand(N, co, So, So, seed=63, scale=1e-2).double()
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, br, stride=2, padding=k // 2)
+    (y * d).sum().backward()
+    out = torch.full((N, So, So, co), float('nan'), device=DEV)
+    _op(0, nhwc(x.float()), w.float(), b.float(), None, out, None, N, S, ci, ldc, co, k, 2, 1)
+    e_f = rel_err(out.cpu(), nhwc(F.elu(y.detach())).float())
+    assert e_f < 4e-6, e_f
+    a = F.elu(_rand(N, ci, S, S, seed=64, scale=2.0))
+    din = torch.full((N, S, S, ci), float('nan'), device=DEV)
+    _op(1, nhwc(d.float()), w.float(), None, nhwc(a), din, None, N, S, ci, ldc, co, k, 2, 0)
+    refd = nhwc((xr.grad * torch.where(a > 0, torch.ones_like(a), a + 1).double()).float())
+    e_d = rel_err(din.cpu(), refd)
+    assert e_d < 4e-6, e_d
+    gw, gb = torch.zeros(co, ci, k, k, device=DEV), torch.zeros(co, device=DEV)
+    _op(2, nhwc(x.float()), None, None, nhwc(d.float()), gw, gb, N, S, ci, ldc, co, k, 2, 0)
+    e_w, e_b = rel_err(gw.cpu(), wr.grad.float()), rel_err(gb.cpu(), br.grad.float())
+    assert e_w < 4e-6 and e_b < 4e-6, (e_w, e_b)
