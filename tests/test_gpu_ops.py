@@ -294,6 +294,26 @@ def test_conv_s2_exact_fp32_forward(cin, cpad, cout, S, N):
     assert rel_err(got, ref) < 2e-6, rel_err(got, ref)
 
 
+@pytest.mark.parametrize('C_,S,N', [(64, 6, 3), (32, 10, 4), (64, 24, 7), (32, 40, 3), (64, 72, 2), (32, 2, 9)])
+def test_conv_s2_exact_fp32_ragged_sizes(C_, S, N):
+    """all three exact-fp32 stride-2 kernels at fine sizes that are not multiples of the 32-pixel staging tile (partial tiles on both axes)"""
+    x = _rand(N, C_, S, S, seed=70)
+    w = _rand(C_, C_, 3, 3, seed=71, scale=3.0 / (C_ * 9) ** 0.5)
+    b = _rand(C_, seed=72, scale=0.5)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    y = F.conv2d(xr, wr, br, stride=2, padding=1)
+    d = _rand(N, C_, S // 2, S // 2, seed=73, scale=1e-2)
+    (y * d.double()).sum().backward()
+    got = _conv_op(13, nhwc(x), w, b, None, N, S, S, C_, C_, C_, C_, 2, 0, 0, nhwc(y.detach()).shape)
+    assert rel_err(got, nhwc(F.elu(y.detach())).float()) < 2e-6
+    a = F.elu(_rand(N, C_, S, S, seed=74, scale=2.0))
+    refd = nhwc((xr.grad * torch.where(a > 0, torch.ones_like(a), a + 1).double()).float())
+    gotd = _conv_op(14, nhwc(d), w, None, nhwc(a), N, S, S, C_, C_, C_, C_, 2, 1, 2, refd.shape)
+    assert rel_err(gotd, refd) < 2e-6
+    gw, gb = _wgrad_op(nhwc(x), nhwc(d), N, S, C_, C_, C_, -2)
+    assert rel_err(gw, wr.grad.float()) < 2e-6 and rel_err(gb, br.grad.float()) < 2e-6
+
+
 @pytest.mark.parametrize('C_,S,N', [(64, 32, 3), (32, 16, 2), (64, 128, 1), (32, 4, 5), (64, 16, 40)])
 def test_conv_s2_exact_fp32_dgrad(C_, S, N):
     """exact-fp32 form of the stride-2 data gradient times ELU'(saved activation) (op mode 14)"""
