@@ -238,7 +238,8 @@ void iodine_linspace_host(int n, float* out);
  * mode 2: stride-1 LDS-tiled split-fp16 (3 MFMA) variant of mode 0, modes 9 / 10: the weight-stationary split-fp16 kernel,
  * mode 12: its exact-fp32 form (weights as fp32 in the same registers, v_mfma_f32_16x16x4_f32; conv_precision 0),
  * modes 5 / 6: split-fp16 stride-2 forward / data gradient of the refinement stack, modes 13 / 14: their exact-fp32 forms
- * (v_mfma_f32_32x32x2_f32, conv_precision 0). */
+ * (v_mfma_f32_32x32x2_f32, conv_precision 0), modes 15 / 16: the weight-stationary stride-2 conv c -> c of refinement layers 1 ..
+ * (c = 64; split-fp16 / exact fp32). */
 int iodine_op_conv3x3(void* stream, int mode, const float* in_nhwc, const float* w_oihw, const float* bias,
                       const float* aux, float* out_nhwc, int n, int ih, int iw, int w_o, int w_i, int cin_pad,
                       int cout, int stride, int epi, int transpose_flip);

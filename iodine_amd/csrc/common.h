@@ -385,7 +385,7 @@ hipError_t launch_refine_l0_fused(hipStream_t st, const float* x4, const float* 
 // kernels_refws.hip: weight-stationary stride-2 conv C -> C + bias + ELU (refinement layers 1 ..), wpk = launch_pack_conv_weights_ws(w, C, 0)
 bool conv3x3_s2ws_ok(int S, int c);
 hipError_t launch_conv3x3_s2ws_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias, float* out,
-                                     int N, int S, int c);
+                                     int N, int S, int c, int f32 = 0);       // f32 = 1: exact fp32 form, wpk = launch_pack_conv_weights_ws32(w, c, 0)
 // kernels_refbwd.hip: data gradient of refinement layer 1 + weight / bias gradient of layer 0 in one pass (dpre0 never stored)
 bool refine_bwd01_ok(int S, int c);
 hipError_t launch_refine_bwd01(hipStream_t st, const float* rd1, const void* wpk, const float* wmeta, const float* act0, const float* enck,

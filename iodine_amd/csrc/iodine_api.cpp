@@ -787,8 +787,8 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
                                                              h->Cr, nullptr, 0, f32));
             PROF(h, st, "refine_l0", launch_conv3x3_s2_f16x3(st, b.enck[i], h->ref_wk16, h->ref_wkmeta, h->ref_b[0], b.ract[i][0], N,
                                                              s, 12, h->Cr, b.rmap, h->K, f32));
-        } else if (l > 0 && h->refine_ws && h->precision == 1 && refine_f16_ok(h) && conv3x3_s2ws_ok(s, h->Cr)) {
-            PROF(h, st, "refine_conv", launch_conv3x3_s2ws_f16x3(st, in, h->ref_wsf[l], h->ref_wsf_meta[l], h->ref_b[l], b.ract[i][l], N, s, h->Cr));
+        } else if (l > 0 && h->refine_ws && refine_f16_ok(h) && conv3x3_s2ws_ok(s, h->Cr)) {
+            PROF(h, st, "refine_conv", launch_conv3x3_s2ws_f16x3(st, in, h->ref_wsf[l], h->ref_wsf_meta[l], h->ref_b[l], b.ract[i][l], N, s, h->Cr, f32));
         } else if (refine_f16_ok(h))
             PROF(h, st, l == 0 ? "refine_l0" : "refine_conv", launch_conv3x3_s2_f16x3(st, in, h->ref_wf16[l], h->ref_wmeta[l], h->ref_b[l],
                                                                b.ract[i][l], N, s, l == 0 ? 20 : h->Cr, h->Cr, nullptr, 0, f32));
@@ -1164,6 +1164,9 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
         HIPCHK(h, launch_ref_split_weights(st, w0, Cr, h->ref_wk, h->ref_wsh));
         HIPCHK(h, launch_pack_conv_weights_s2f32(st, h->ref_wk, Cr, 12, 16, Cr, 0, h->ref_wk16));
         HIPCHK(h, launch_pack_conv_weights_s2f32(st, h->ref_wsh, Cr, 8, 16, Cr, 0, h->ref_wsh16));
+        if (Cr == 64)                                           // weight-stationary forward of layers 1 .. (fp32 weights in the same registers)
+            for (int l = 1; l < h->Dr; ++l)
+                HIPCHK(h, launch_pack_conv_weights_ws32(st, P("refine.mlc.layers." + std::to_string(l) + ".weight"), Cr, 0, h->ref_wsf[l]));
     } else if (refine_f16_ok(h)) {
         for (int l = 0; l < h->Dr; ++l) {
             const float* w = l == 0 ? w0 : P("refine.mlc.layers." + std::to_string(l) + ".weight");
@@ -1810,6 +1813,19 @@ int iodine_op_conv3x3(void* stream, int mode, const float* in, const float* w, c
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
         (void)hipFree(buf);
         if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(ws): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
+        return IODINE_OK;
+    }
+    if (mode == 15 || mode == 16) { // weight-stationary STRIDE-2 conv c -> c + bias + ELU (kernels_refws.hip): split-fp16 (15) / exact fp32 (16); ih = fine size
+        if (cin_pad != cout || w_o != cout || w_i != cout || ih != iw || !conv3x3_s2ws_ok(ih, cout)) { g_create_error = "iodine_op_conv3x3(s2ws): shape"; return IODINE_ERR_INVALID; }
+        char* buf = nullptr;
+        const size_t wb = conv_ws_wpk_bytes(cout);
+        if (hipMalloc((void**)&buf, wb + 64) != hipSuccess) return IODINE_ERR_HIP;
+        float* meta = (float*)(buf + wb);
+        hipError_t e2 = mode == 16 ? launch_pack_conv_weights_ws32(st, w, cout, 0, buf) : launch_pack_conv_weights_ws(st, w, cout, 0, meta, buf);
+        if (e2 == hipSuccess) e2 = launch_conv3x3_s2ws_f16x3(st, in, buf, meta, bias, out, n, ih, cout, mode == 16);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+        (void)hipFree(buf);
+        if (e2 != hipSuccess) { g_create_error = std::string("iodine_op_conv3x3(s2ws): ") + hipGetErrorString(e2); return IODINE_ERR_HIP; }
         return IODINE_OK;
     }
     if (mode == 12) {               // exact-fp32 form of the weight-stationary kernel (v_mfma_f32_16x16x4_f32)

@@ -49,7 +49,11 @@ IOD_DEVINL float rw_fresh_scale(float mx)
     return __uint_as_float((unsigned)(127 + se) << 23);
 }
 
-template <int C>
+// F32 (conv_precision 0, round 5): the staged pixel is its 32 fp32 channels (128 of the same 160 bytes), the 144 weight registers hold fp32
+// (launch_pack_conv_weights_ws32: element j of a lane's 16 bytes = the A operand of the j-th v_mfma_f32_16x16x4_f32 over the fragment's 16
+// bytes), 8 MFMAs per fragment and (row, ky) pair instead of 3; no scales: the max reduction and the accumulator rescale drop out, the barrier
+// that frees the LDS buffer stays.
+template <int C, bool F32 = false>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_s2ws_f16x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk, const float* __restrict__ wmeta,
                                const float* __restrict__ bias, float* __restrict__ out, int Sc, int tiles_x, int tiles_y, int ntiles)
@@ -66,7 +70,8 @@ void conv3x3_s2ws_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     const int Sf = 2 * Sc;
 
     // ---- this wave's weight slice -> registers (once per block) ----
-    f16x8 wh[NCHUNK][9], wl[NCHUNK][9];
+    using wreg_t = std::conditional_t<F32, f32x4, f16x8>;
+    wreg_t wh[NCHUNK][9], wl[NCHUNK][9];
     {
         const uint4* wp = wpk + (size_t)cg * NCHUNK * 9 * 2 * 64 + lane;
 #pragma unroll
@@ -82,7 +87,8 @@ void conv3x3_s2ws_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 #pragma unroll
             for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(wh[c][t]), "+v"(wl[c][t]));
     }
-    const float inv_w = wmeta[1];
+    float inv_w = 1.f;
+    if constexpr (!F32) inv_w = wmeta[1];
     float* s_bias = s_max + 8;                                               // [C] (kept out of the register file: 254 VGPRs are spoken for)
     if (tid < C) s_bias[tid] = bias[tid];
 
@@ -149,6 +155,11 @@ void conv3x3_s2ws_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             const int px = px0 + 32 * k;
             const int r = (px * 1986) >> 16, hcol = px - r * RW_HC;
             const int pos = r * RW_HC + ((hcol & 1) ? 17 + (hcol >> 1) : (hcol >> 1));
+            if constexpr (F32) {                             // exact fp32: the float4 goes to LDS as it is (channel quad q8 at byte 16 q8)
+                const int lo32 = px < RW_NPX ? pos * RW_PXB + q8 * 16 : RW_NPX * RW_PXB;
+                *reinterpret_cast<f32x4*>(sb + lo32) = rr[k];
+                continue;
+            }
             const int lo_ = px < RW_NPX ? pos * RW_PXB + q8 * 8 : RW_NPX * RW_PXB;
             f32x4 v = rr[k] * scale;
             unsigned l0, l1;
@@ -159,7 +170,7 @@ void conv3x3_s2ws_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
     };
 
 #define RW_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-    struct Frag { f16x8 h, l; };
+    struct Frag { wreg_t h, l; };
     f32x4 acc[2];
     // all taps of chunk c from LDS buffer `buf`: fine halo rows r = 0..4, column taps kx = 0..2
     auto compute = [&](auto cc, int buf) {
@@ -180,9 +191,16 @@ void conv3x3_s2ws_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             for (int y = 0; y < 2; ++y) {
                 const int ky = r - 2 * y;
                 if (ky >= 0 && ky <= 2) {
+                    if constexpr (F32) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[y] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[c][ky * 3 + kx][j], fr.h[j], acc[y], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[y] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[c][ky * 3 + kx][j], fr.l[j], acc[y], 0, 0, 0);
+                    } else {
                     acc[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c][ky * 3 + kx], fr.l, acc[y], 0, 0, 0);
                     acc[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c][ky * 3 + kx], fr.h, acc[y], 0, 0, 0);
                     acc[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c][ky * 3 + kx], fr.h, acc[y], 0, 0, 0);
+                    }
                 }
             }
         };
@@ -209,6 +227,11 @@ void conv3x3_s2ws_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             const int s = s0 + c, par = c & 1;
             // ---- stage s: max of the staged values -> block-wide scale -> split into LDS buffer c ----
             wait_stage(s0 == 0, rin[c]);
+            float scale = 1.f;
+            if constexpr (F32) {
+                (void)par;
+                __syncthreads();                              // every wave is done with the MFMAs of stage s - 2 = this buffer's last readers
+            } else {
             float m = 0.f;
 #pragma unroll
             for (int k = 0; k < RW_NIN; ++k)
@@ -216,7 +239,8 @@ void conv3x3_s2ws_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
             m = wave_max_f32(m);
             if (lane == 0) s_max[par * 4 + wv] = m;
             __syncthreads();                                  // (also: every wave is done with the MFMAs of stage s - 2 = this buffer's last readers)
-            const float scale = rw_fresh_scale(fmaxf(fmaxf(s_max[par * 4], s_max[par * 4 + 1]), fmaxf(s_max[par * 4 + 2], s_max[par * 4 + 3])));
+            scale = rw_fresh_scale(fmaxf(fmaxf(s_max[par * 4], s_max[par * 4 + 1]), fmaxf(s_max[par * 4 + 2], s_max[par * 4 + 3])));
+            }
             convert(c, scale, rin[c]);
             issue(s + NCHUNK, rin[c]);                            // two stages ahead, into the set just converted (masked past the end)
             if (c == 0) {
@@ -261,18 +285,24 @@ void conv3x3_s2ws_f16x3_kernel(const float* __restrict__ in, const uint4* __rest
 bool conv3x3_s2ws_ok(int S, int c) { return c == 64 && S >= 4 && S % 2 == 0; }
 
 // Forward stride-2 conv C -> C + bias + ELU, weight-stationary.  S = fine (input) size; wpk / wmeta = launch_pack_conv_weights_ws(w, C, 0).
+// f32 = 1: exact fp32 MFMA form (wpk = launch_pack_conv_weights_ws32(w, C, 0); wmeta unused)
 hipError_t launch_conv3x3_s2ws_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias, float* out,
-                                     int N, int S, int c)
+                                     int N, int S, int c, int f32)
 {
     IOD_XSKIP(512);
     if (!conv3x3_s2ws_ok(S, c) || !bias) return hipErrorInvalidValue;
     constexpr size_t lds = (size_t)2 * RW_BUFB + 32 + 64 * 4;
-    static std::atomic<unsigned> attr_devs{0};
-    if (hipError_t e = iod_set_max_lds((const void*)conv3x3_s2ws_f16x3_kernel<64>, (int)lds, attr_devs); e != hipSuccess) return e;
+    static std::atomic<unsigned> attr_devs{0}, attr_devs32{0};
+    if (hipError_t e = f32 ? iod_set_max_lds((const void*)conv3x3_s2ws_f16x3_kernel<64, true>, (int)lds, attr_devs32)
+                           : iod_set_max_lds((const void*)conv3x3_s2ws_f16x3_kernel<64>, (int)lds, attr_devs); e != hipSuccess) return e;
     int n_cu = 0;
     if (hipError_t e = iod_cu_count(&n_cu); e != hipSuccess) return e;
     const int Sc = S / 2, tiles_x = (Sc + 15) / 16, tiles_y = (Sc + 1) / 2, ntiles = N * tiles_x * tiles_y;
     const int blocks = std::min(ntiles, 2 * n_cu);
+    if (f32)
+        hipLaunchKernelGGL((conv3x3_s2ws_f16x3_kernel<64, true>), dim3(blocks), dim3(256), lds, st, in, reinterpret_cast<const uint4*>(wpk), wmeta, bias,
+                           out, Sc, tiles_x, tiles_y, ntiles);
+    else
     hipLaunchKernelGGL((conv3x3_s2ws_f16x3_kernel<64>), dim3(blocks), dim3(256), lds, st, in, reinterpret_cast<const uint4*>(wpk), wmeta, bias,
                        out, Sc, tiles_x, tiles_y, ntiles);
     return hipGetLastError();

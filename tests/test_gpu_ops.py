@@ -294,6 +294,19 @@ def test_conv_s2_exact_fp32_forward(cin, cpad, cout, S, N):
     assert rel_err(got, ref) < 2e-6, rel_err(got, ref)
 
 
+@pytest.mark.parametrize('mode,tol', [(15, 3e-6), (16, 2e-6)], ids=['split_fp16', 'exact_fp32'])
+@pytest.mark.parametrize('S,N', [(64, 5), (32, 9), (16, 40), (8, 3), (128, 2), (24, 7), (6, 4)])
+def test_conv_s2_weight_stationary(S, N, mode, tol):
+    """weight-stationary stride-2 conv 64 -> 64 + bias + ELU of refinement layers 1 .. (kernels_refws.hip: 2 x 16 output tiles, weights in 144
+    registers, persistent blocks) - op modes 15 (split-fp16) / 16 (exact fp32: v_mfma_f32_16x16x4_f32, conv_precision 0)"""
+    x = _rand(N, 64, S, S, seed=80)
+    w = _rand(64, 64, 3, 3, seed=81, scale=3.0 / (64 * 9) ** 0.5)
+    b = _rand(64, seed=82, scale=0.5)
+    ref = nhwc(F.elu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1))).float()
+    got = _conv_op(mode, nhwc(x), w, b, None, N, S, S, 64, 64, 64, 64, 2, 0, 0, ref.shape)
+    assert rel_err(got, ref) < tol, rel_err(got, ref)
+
+
 @pytest.mark.parametrize('C_,S,N', [(64, 6, 3), (32, 10, 4), (64, 24, 7), (32, 40, 3), (64, 72, 2), (32, 2, 9)])
 def test_conv_s2_exact_fp32_ragged_sizes(C_, S, N):
     """all three exact-fp32 stride-2 kernels at fine sizes that are not multiples of the 32-pixel staging tile (partial tiles on both axes)"""
