@@ -900,13 +900,6 @@ hipError_t gen_mfma_launch(hipStream_t st, const float* in, const float* wt, con
 
 }  // namespace
 
-// (tests: IODINE_GEN_SCALAR=1 keeps the stride-2 convs on the scalar tier - the reference form the MFMA kernels are checked against)
-static bool gen_force_scalar()
-{
-    static const bool v = [] { const char* e = getenv("IODINE_GEN_SCALAR"); return e && e[0] == '1'; }();
-    return v;
-}
-
 hipError_t launch_gen_pack_weights(hipStream_t st, const float* w, int Co, int Ci, int k, float* wt)
 {
     hipLaunchKernelGGL(gen_pack_weights_kernel, dim3(gen_blocks((size_t)Co * Ci * k * k)), dim3(256), 0, st, w, Co, Ci, k * k, wt);
@@ -922,7 +915,7 @@ hipError_t launch_gen_conv_fwd(hipStream_t st, const float* in, const float* wt,
         if (k == 5) return gen_mfma_launch<5>(st, in, wt, bias, nullptr, out, N, Si, Ci, ldc, Co, Co, 0, Ci * Co, Co, 1, elu, lds);
         return gen_mfma_launch<7>(st, in, wt, bias, nullptr, out, N, Si, Ci, ldc, Co, Co, 0, Ci * Co, Co, 1, elu, lds);
     }
-    if (s == 2 && !gen_force_scalar() && gen_s2_fwd_ok(k, Ci, ldc, Co))         // stride 2 on the matrix pipe (kernels_gens2.hip, round 5)
+    if (s == 2 && gen_s2_fwd_ok(k, Ci, ldc, Co))         // stride 2 on the matrix pipe (kernels_gens2.hip, round 5)
         return launch_gen_s2_fwd(st, in, wt, bias, out, N, Si, Ci, ldc, Co, k, elu);
     const int So = (Si - 1) / s + 1;
     const size_t total = (size_t)N * So * So * Co;
@@ -939,7 +932,7 @@ hipError_t launch_gen_conv_dgrad(hipStream_t st, const float* dout, const float*
         if (k == 5) return gen_mfma_launch<5>(st, dout, wt, nullptr, aux, din, N, Si, Co, Co, Ci, ldi, 1, ldi * Co, 1, Co, 0, lds);
         return gen_mfma_launch<7>(st, dout, wt, nullptr, aux, din, N, Si, Co, Co, Ci, ldi, 1, ldi * Co, 1, Co, 0, lds);
     }
-    if (s == 2 && !gen_force_scalar() && gen_s2_dgrad_ok(k, Ci, ldi, Co))
+    if (s == 2 && gen_s2_dgrad_ok(k, Ci, ldi, Co))
         return launch_gen_s2_dgrad(st, dout, wt, aux, din, N, Si, Ci, ldi, Co, k);
     const int So = (Si - 1) / s + 1;
     const size_t total = (size_t)N * Si * Si * Ci;
@@ -1015,7 +1008,7 @@ hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* d
                            k * k, alpha, gw, gb);
         return hipGetLastError();
     }
-    if (s == 2 && !gen_force_scalar() && gen_s2_wgrad_ok(k, Ci, ldc, Co)) {
+    if (s == 2 && gen_s2_wgrad_ok(k, Ci, ldc, Co)) {
         int nsl = 0;
         if (hipError_t e = launch_gen_s2_wgrad(st, in, dout, scratch, N, Si, Ci, ldc, Co, k, GEN_WGRAD_SLICES_MAX, &nsl); e != hipSuccess) return e;
         hipLaunchKernelGGL(gen_conv_wgrad_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, scratch, nsl, Ci, Ci_dst, Co,
