@@ -162,20 +162,21 @@ def cpu_baseline(args, arch, params, mode):
     return cb, (x, eps, ref_elbos, ref_grads)
 
 
-def pmc_file():
-    """The newest tracked PMC record (profiles/rNN_pmc.json)."""
+def pmc_file(strict=False):
+    """The newest tracked PMC record (profiles/rNN_pmc.json; strict: rNN_pmc_strict.json = the same passes over --conv-precision 0)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_strict.json' if strict else 'r[0-9][0-9]_pmc.json')))
     return files[-1] if files else None
 
 
-def pmc_record(args, B, K):
+def pmc_record(args, B, K, strict=None):
     """HBM bytes per launch (every profiled category) and matrix-pipe utilisation / shader clock of the dominant kernels from the
     tracked PMC file (tools/pmc_to_json.py writes it from rocprofv3 --pmc passes: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).
     Quoted only while the file describes THIS tree (source digest) and THIS shape; otherwise (None, None, reason)."""
-    path = pmc_file()
+    strict = (args.conv_precision == 0) if strict is None else strict
+    path = pmc_file(strict)
     if not path:
-        return None, None, 'no profiles/rNN_pmc.json'
+        return None, None, 'no profiles/rNN_pmc_strict.json' if strict else 'no profiles/rNN_pmc.json'
     name = os.path.relpath(path, ROOT)
     try:
         from iodine_amd.build import source_digest
@@ -183,7 +184,7 @@ def pmc_record(args, B, K):
         if rec.get('csrc_sha256') != source_digest():
             return None, None, f'{name} was measured on other kernel sources (digest mismatch)'
         shape = rec.get('shape', {})
-        if (shape.get('config'), shape.get('batch'), shape.get('slots')) != (args.config, B, K) or args.conv_precision != 1:
+        if (shape.get('config'), shape.get('batch'), shape.get('slots')) != (args.config, B, K) or bool(rec.get('conv_precision', 1) == 0) != bool(strict):
             return None, None, f'{name} was measured on another shape'
         per = {k: v['hbm_bytes_per_launch'] for k, v in rec['kernels'].items() if 'hbm_bytes_per_launch' in v}
         pipe = {k: {f: v[f] for f in ('mfma_util', 'clock_ghz', 'mfma_rate_of_2p4ghz_peak') if f in v}
@@ -573,6 +574,14 @@ def main():
         xn = sum(px[c]['launches'] for c in DOMINANT if c in px)
         xall = sum(px[c].get('launches_seen', px[c]['launches']) for c in DOMINANT if c in px)
         xa = flops_per_launch / (xm / xn * 1e-3) / 1e12 if xn else 0.0
+        # HBM bytes per launch of the strict kernels: their own PMC record (profiles/rNN_pmc_strict.json: the passes of tools/pmc_traffic.sh over
+        # --conv-precision 0), quoted while its source digest matches the tree
+        xper, xpipe, xsrc = pmc_record(args, B, K, strict=True)
+        xtraffic = None
+        if xper:
+            xw = {c: px[c].get('launches_seen', px[c]['launches']) for c in DOMINANT if c in px}
+            if xw and all(c in xper for c in xw):
+                xtraffic = sum(xper[c] * n for c, n in xw.items()) / sum(xw.values())
         out['exact_fp32'] = dict(
             metric='refinement_iters_per_s', value=round(world * B * T / dtx, 2), unit='image-refinement-iters/s',
             ms_per_step=round(dtx * 1e3, 3), steps=nx, dtype='f32 (v_mfma_f32_16x16x4_f32 / 32x32x2_f32: IEEE fp32 products, fp32 accumulate)',
@@ -580,7 +589,9 @@ def main():
             roofline=dict(bound='mfma',
                           kernel=FP32_KNAME.format(C=C_),
                           achieved=round(xa, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=round(xa / PEAK_F32_MFMA_TFLOPS, 4),
-                          traffic=None, flops_per_launch=flops_per_launch, avg_launch_ms=round(xm / max(xn, 1), 4), launches=xall,
+                          traffic=xtraffic, traffic_source=xsrc, matrix_pipe_pmc=xpipe,
+                          algorithmic_hbm_bytes_per_launch=2.0 * B * K * S * S * C_ * 4,
+                          flops_per_launch=flops_per_launch, avg_launch_ms=round(xm / max(xn, 1), 4), launches=xall,
                           launches_timed=xn, events_in_timed_region=True,
                           kernel_time_share=round(xm / max(xn, 1) * xall / max(nx, 1) / (dtx * 1e3), 4),
                           per_form={c: dict(ms_avg=px[c]['ms_avg'],

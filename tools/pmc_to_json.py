@@ -25,7 +25,10 @@ sys.path.insert(0, ROOT)
 HELPERS = (('dec_out_stream_f16x3_kernel', 'dec_out'), ('dec_out_rows_f16x3_kernel', 'dec_out'), ('dec_out_bwd_fused_f16x3_kernel', 'dec_out_bwd'), ('dec_l0_cells_kernel', 'dec_l0'),
            ('dec_out_dgrad_f16x3_kernel', 'dec_out_dgrad'), ('pixel_pass1_kernel', 'pixel_pass1'), ('pixel_pass2_kernel', 'pixel_pass2'),
            ('l0_rows_reduce_kernel', 'l0_reduce'), ('refine_head', 'refine_head'), ('conv3x3_s2_wgrad_f16x3_kernel', 'refine_wgrad'),
-           ('refine_bwd01_kernel', 'refine_bwd01'), ('conv3x3_s2ws_f16x3_kernel', 'refine_conv'), ('refine_l0_fused_kernel', 'refine_l0f'))
+           ('refine_bwd01_kernel', 'refine_bwd01'), ('conv3x3_s2ws_f16x3_kernel', 'refine_conv'), ('refine_l0_fused_kernel', 'refine_l0f'),
+           # kernels only the exact-fp32 path launches (rNN_pmc_strict.json)
+           ('conv3x3_s2_wgrad_f32_kernel', 'refine_wgrad'), ('dec_out_wgrad_f32_kernel', 'dec_out_wgrad'), ('conv3x3_tile_kernel<4,', 'dec_out_dgrad'),
+           ('dec_l0_kernel', 'dec_l0'))
 
 
 def category(name):
@@ -37,7 +40,7 @@ def category(name):
         if targs[3] != '0':
             return 'refine_dgrad'
         return 'refine_l0' if targs[0] in ('8', '12', '20') else 'refine_conv'
-    if 'conv3x3_wgrad_f16x3_ws_kernel' in name or 'conv3x3_wgrad_f16x3_kernel' in name:
+    if 'conv3x3_wgrad_f16x3_ws_kernel' in name or 'conv3x3_wgrad_f16x3_kernel' in name or 'conv3x3_wgrad_f32_ws_kernel' in name:
         return 'conv_tile_wgrad'
     if 'conv3x3_ws_f16x3_kernel' in name:                    # <C, EPI>: 0 = forward, 1 / 4 = data gradient (stored / row sums)
         targs = name.split('<', 1)[1].split('>')[0].replace(' ', '').split(',')
@@ -84,6 +87,7 @@ def main():
     outdir = sys.argv[1]
     tag = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith('-') else 'r05'
     cfg = 'dsprites' if 'dsprites' in sys.argv[2:] else 'clevr6'
+    strict = '0' in [sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == '--conv-precision']      # passes over the exact-fp32 path
     from iodine_amd.build import source_digest
     # the GPU box has no .git: the commit is handed over in the environment (tools/round_profiles.sh, IODINE_COMMIT=$(git rev-parse HEAD))
     commit = os.environ.get('IODINE_COMMIT', '').strip()
@@ -118,15 +122,15 @@ def main():
                 # fraction of the 2.4 GHz matrix peak the launch sustains: utilisation x clock / 2.4
                 k['mfma_rate_of_2p4ghz_peak'] = round(k['mfma_util'] * k['clock_ghz'] / 2.4, 4)
         kernels[c] = k
-    rec = dict(commit=commit, csrc_sha256=source_digest(),
+    rec = dict(commit=commit, csrc_sha256=source_digest(), conv_precision=0 if strict else 1,
                shape=dict(config=cfg, batch=32, slots=7 if cfg == 'clevr6' else 6),
                method='rocprofv3 --pmc <one set per run> --kernel-trace over bench.py --steps 2 --warmup 1; '
                       'hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (tools/pmc_traffic.sh)',
                kernels=kernels)
-    path = os.path.join(ROOT, 'gpurun_out', f'{tag}_pmc.json')
+    path = os.path.join(ROOT, 'gpurun_out', f'{tag}_pmc_strict.json' if strict else f'{tag}_pmc.json')
     json.dump(rec, open(path, 'w'), indent=1)
     print(json.dumps(rec, indent=1))
-    print('wrote', path, f'(copy to profiles/{tag}_pmc.json)')
+    print('wrote', path, '(copy to profiles/)')
 
 
 if __name__ == '__main__':

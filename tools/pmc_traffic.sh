@@ -9,7 +9,11 @@ set -u
 TAG=${1:-r05}
 shift || true
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/pmc_$TAG
+# passes over the exact-fp32 path (bash tools/pmc_traffic.sh <tag> --conv-precision 0) are kept beside the default ones:
+# gpurun_out/pmc_<tag>_strict/, <tag>_pmc_strict.json, <tag>_kernel_traffic_strict.md
+SFX=""
+case " $* " in *" --conv-precision 0 "*) SFX="_strict";; esac
+OUT=$REPO/gpurun_out/pmc_$TAG$SFX
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
@@ -21,4 +25,4 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE";
 done
 cd $REPO
 python tools/pmc_to_json.py $OUT $TAG "$@"
-python tools/pmc_all_kernels.py $OUT > $REPO/gpurun_out/${TAG}_kernel_traffic.md
+python tools/pmc_all_kernels.py $OUT > $REPO/gpurun_out/${TAG}_kernel_traffic$SFX.md

@@ -13,6 +13,9 @@ cd $REPO
 # matches the tree, so the record of THIS tree has to be in place before the bench lines are taken
 bash tools/pmc_traffic.sh $TAG > $OUT/${TAG}_pmc.log 2>&1
 cp $OUT/${TAG}_pmc.json $REPO/profiles/${TAG}_pmc.json
+# ... and of the exact-fp32 path (the exact_fp32 sub-line / --conv-precision 0 quote their traffic from it)
+bash tools/pmc_traffic.sh $TAG --conv-precision 0 > $OUT/${TAG}_pmc_strict.log 2>&1
+cp $OUT/${TAG}_pmc_strict.json $REPO/profiles/${TAG}_pmc_strict.json
 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
 python bench.py --mode infer --no-exact-fp32 --no-sustain > $OUT/${TAG}_bench_infer.json 2> /dev/null
 for g in 0 1; do
