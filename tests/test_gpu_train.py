@@ -170,15 +170,16 @@ def test_rccl_allreduce_on_flat_gradient_buffer():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('prec', [1, 0], ids=['split_f16x3', 'exact_fp32'])
 @pytest.mark.parametrize('name,ltol', [('traj_tiny', 2e-5), ('traj_cfg1', 5e-5)])
-def test_training_trajectory_matches_reference(name, ltol):
+def test_training_trajectory_matches_reference(name, ltol, prec):
     """four steps of the reference's training-step body (lib/engine/train.py:58-65) with its optimizer (Adam, lr 3e-4,
     lib/solver/build.py:5-16): HIP forward/backward + the fused Adam kernel against the losses and final parameters the
     unmodified reference produced (tests/golden/gen_trajectory.py)"""
     from iodine_amd.optim import make_optimizer
     from util import check_trajectory_params, trajectory_setup
     tr, arch, params, x, eps = trajectory_setup(name)
-    m = make_hip_model(arch, params)
+    m = make_hip_model(arch, params, options={'conv_precision': prec})       # (the strict path: fp32-MFMA forms of every conv, round 5)
     opt = make_optimizer(m, base_lr=float(tr['meta_lr']), weight_decay=0.0)
     xd, losses = x.to(DEV), []
     for e in eps:
