@@ -41,8 +41,8 @@ struct Gs2Geom {
 
 // MODE 0: out[n][oy][ox][:] = act(bias + sum_{tap, k} in[n][2 oy + ky - pad][2 ox + kx - pad][k] W(tap, k, :))
 // MODE 1: out[n][2 Y + py][2 X + px][:] = ELU'(aux) * sum_{taps of the class, k} in[n][Y + oy][X + ox][k] W(tap, k, :)
-template <int MODE, int C4N>                                  // C4N: 4-channel steps per staged chunk (1, 2 or 4)
-__global__ __launch_bounds__(256, 2)
+template <int MODE, int C4N, int NR>                          // C4N: 4-channel steps per staged chunk (1, 2 or 4); NR: position rows per wave (1 or
+__global__ __launch_bounds__(256, 2)                          // 2: a block of 8 x 16 positions stages the chunk's weights half as often per output)
 void gen_s2_conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
                         const float* __restrict__ aux, float* __restrict__ out, Gs2Geom g)
 {
@@ -52,7 +52,8 @@ void gen_s2_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
     const int ks = g.ks, pad = ks >> 1;
     constexpr int cch = 4 * C4N;
     const int H = (pad + 1) >> 1;                              // data gradient: halo radius of the coarse gather
-    const int HR = MODE == 0 ? 2 * (GS2_TR - 1) + ks : GS2_TR + 2 * H;
+    constexpr int TRB = GS2_TR * NR;                           // position rows of the block: wave w owns rows w, w + 4
+    const int HR = MODE == 0 ? 2 * (TRB - 1) + ks : TRB + 2 * H;
     const int HC = MODE == 0 ? 2 * (GS2_TC - 1) + ks : GS2_TC + 2 * H;
     const int PS = cch + (MODE == 0 ? 2 : 4);                  // floats per staged pixel
     const int n0 = blockIdx.z * 64;                            // first output channel of this block
@@ -69,15 +70,19 @@ void gen_s2_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
     const int tx = t % g.tiles_x; t /= g.tiles_x;
     const int ty = t % g.tiles_y;
     const int n = t / g.tiles_y;
-    const int r0 = ty * GS2_TR, c0 = tx * GS2_TC;             // first position of the tile
+    const int r0 = ty * TRB, c0 = tx * GS2_TC;                // first position of the tile
     const int hy0 = MODE == 0 ? 2 * r0 - pad : r0 - H, hx0 = MODE == 0 ? 2 * c0 - pad : c0 - H;
     const float* in_n = in + (size_t)n * g.Sin * g.Sin * g.ldk;
 
-    f32x4 acc[4];
+    f32x4 acc[NR][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int lane_pix = MODE == 0 ? (2 * wv * HC + 2 * lp) : (wv * HC + lp);
+    int lane_pix[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) lane_pix[i] = MODE == 0 ? (2 * (wv + 4 * i) * HC + 2 * lp) : ((wv + 4 * i) * HC + lp);
     constexpr int c4n = C4N;
     for (int k0 = 0; k0 < g.K; k0 += cch) {
         __syncthreads();                                       // the previous chunk has been read
@@ -125,31 +130,33 @@ void gen_s2_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
         __syncthreads();
         // ---- MFMAs: per tap and 4-channel step one B read (pixels) and NG A reads (weights) ----
         // (the operands of tap j + 1 are read while the MFMAs of tap j issue)
-        float bv[2][C4N], av[2][C4N][4];
+        float bv[2][NR][C4N], av[2][C4N][4];
         int jy = 0, jx = 0;
-        auto load_tap = [&](int j, float (&b)[C4N], float (&a)[C4N][4]) {
+        auto load_tap = [&](int j, float (&b)[NR][C4N], float (&a)[C4N][4]) {
             int toff;
             if (MODE == 0) toff = jy * HC + jx;
             else {
                 const int ky = ky0 + 2 * jy, kx = kx0 + 2 * jx;
                 toff = (H + ((py + pad - ky) >> 1)) * HC + H + ((px + pad - kx) >> 1);      // (arithmetic shift: the numerator is even)
             }
-            const float* pb = s_in + (lane_pix + toff) * PS + lq;
             const float* pa = s_w + (j * cch + lq) * NP + lp;
 #pragma unroll
             for (int k4 = 0; k4 < C4N; ++k4) {
-                b[k4] = pb[4 * k4];
+#pragma unroll
+                for (int i = 0; i < NR; ++i) b[i][k4] = s_in[(lane_pix[i] + toff) * PS + lq + 4 * k4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a[k4][q] = q < NG ? pa[4 * k4 * NP + 16 * q] : 0.f;
             }
             if (++jx == nkx) { jx = 0; ++jy; }
         };
-        auto mma_tap = [&](const float (&b)[C4N], const float (&a)[C4N][4]) {
+        auto mma_tap = [&](const float (&b)[NR][C4N], const float (&a)[C4N][4]) {
 #pragma unroll
             for (int k4 = 0; k4 < C4N; ++k4)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (q < NG) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k4][q], b[k4], acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < NR; ++i)
+                        if (q < NG) acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k4][q], b[i][k4], acc[i][q], 0, 0, 0);
         };
         load_tap(0, bv[0], av[0]);
         for (int j = 0; j < ntap; j += 2) {
@@ -161,21 +168,23 @@ void gen_s2_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
             }
         }
     }
-    // ---- epilogue: lane = 4 consecutive channels (16 q + 4 lq ..) of position (r0 + wv, c0 + lp) ----
-    const int oy = r0 + wv, ox = c0 + lp;
-    if (oy >= g.Sout || ox >= g.Sout) return;
+    // ---- epilogue: lane = 4 consecutive channels (16 q + 4 lq ..) of positions (r0 + wv + 4 i, c0 + lp) ----
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+    const int oy = r0 + wv + 4 * i, ox = c0 + lp;
+    if (oy >= g.Sout || ox >= g.Sout) continue;
     size_t opix;
     if (MODE == 0) opix = ((size_t)n * g.Sout + oy) * g.Sout + ox;
     else {
         const int fy = 2 * oy + py, fx = 2 * ox + px;
-        if (fy >= g.Sf || fx >= g.Sf) return;
+        if (fy >= g.Sf || fx >= g.Sf) continue;
         opix = ((size_t)n * g.Sf + fy) * g.Sf + fx;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int c = n0 + 16 * q + 4 * lq;
         if (q >= NG || c >= g.Nn) continue;                    // (Nn is a multiple of 4: a float4 is all in or all out)
-        f32x4 v = acc[q];
+        f32x4 v = acc[i][q];
         float* o = out + opix * g.ldn + c;
         if (MODE == 0) {
             if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + c); v += f32x4{b4.x, b4.y, b4.z, b4.w}; }
@@ -187,12 +196,13 @@ void gen_s2_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
         }
         *reinterpret_cast<float4*>(o) = make_float4(v.x, v.y, v.z, v.w);
     }
+    }
 }
 
-inline int gs2_cch(int mode, int ks, int K, int nn, size_t* lds_out)
+inline int gs2_cch(int mode, int ks, int K, int nn, size_t* lds_out, int nr = 1)
 {
-    const int pad = ks / 2, H = (pad + 1) / 2;
-    const int HR = mode == 0 ? 2 * (GS2_TR - 1) + ks : GS2_TR + 2 * H, HC = mode == 0 ? 2 * (GS2_TC - 1) + ks : GS2_TC + 2 * H;
+    const int pad = ks / 2, H = (pad + 1) / 2, TRB = GS2_TR * nr;
+    const int HR = mode == 0 ? 2 * (TRB - 1) + ks : TRB + 2 * H, HC = mode == 0 ? 2 * (GS2_TC - 1) + ks : GS2_TC + 2 * H;
     const int ntap = mode == 0 ? ks * ks : ((ks + 1) / 2) * ((ks + 1) / 2);
     const int NP = ((std::min(nn, 64) + 15) / 16) * 16 + 16;
     for (int cch = K <= 4 ? 4 : (K <= 8 ? 8 : 16); cch >= 4; cch >>= 1) {
@@ -202,22 +212,34 @@ inline int gs2_cch(int mode, int ks, int K, int nn, size_t* lds_out)
     return 0;
 }
 
-template <int MODE, int C4N>
+template <int MODE, int C4N, int NR>
 hipError_t gs2_launch_c(hipStream_t st, dim3 grid, size_t lds, const float* in, const float* wt, const float* bias, const float* aux, float* out,
                         const Gs2Geom& g)
 {
     static std::atomic<unsigned> attr_devs{0};
-    if (hipError_t e = iod_set_max_lds((const void*)gen_s2_conv_kernel<MODE, C4N>, 72 * 1024, attr_devs); e != hipSuccess) return e;
-    hipLaunchKernelGGL((gen_s2_conv_kernel<MODE, C4N>), grid, dim3(256), lds, st, in, wt, bias, aux, out, g);
+    if (hipError_t e = iod_set_max_lds((const void*)gen_s2_conv_kernel<MODE, C4N, NR>, 72 * 1024, attr_devs); e != hipSuccess) return e;
+    hipLaunchKernelGGL((gen_s2_conv_kernel<MODE, C4N, NR>), grid, dim3(256), lds, st, in, wt, bias, aux, out, g);
     return hipGetLastError();
 }
+// geometry + launch: 8 x 16 positions per block (NR = 2) when the position grid has more than 4 rows and the taller halo fits beside the same
+// weight chunk, else 4 x 16
 template <int MODE>
-hipError_t gs2_launch(hipStream_t st, dim3 grid, size_t lds, const float* in, const float* wt, const float* bias, const float* aux, float* out,
-                      const Gs2Geom& g)
+hipError_t gs2_launch(hipStream_t st, int N, int nz, int ygrid, const float* in, const float* wt, const float* bias, const float* aux, float* out,
+                      Gs2Geom g)
 {
-    if (g.cch == 16) return gs2_launch_c<MODE, 4>(st, grid, lds, in, wt, bias, aux, out, g);
-    if (g.cch == 8) return gs2_launch_c<MODE, 2>(st, grid, lds, in, wt, bias, aux, out, g);
-    return gs2_launch_c<MODE, 1>(st, grid, lds, in, wt, bias, aux, out, g);
+    size_t lds1 = 0, lds2 = 0;
+    const int c1 = gs2_cch(MODE, g.ks, g.K, g.Nn, &lds1, 1), c2 = g.Sout > GS2_TR ? gs2_cch(MODE, g.ks, g.K, g.Nn, &lds2, 2) : 0;
+    if (!c1) return hipErrorInvalidValue;
+    const int nr = c2 == c1 ? 2 : 1;
+    g.cch = c1;
+    g.tiles_x = (g.Sout + GS2_TC - 1) / GS2_TC;
+    g.tiles_y = (g.Sout + GS2_TR * nr - 1) / (GS2_TR * nr);
+    const dim3 grid((unsigned)(N * g.tiles_x * g.tiles_y), (unsigned)ygrid, (unsigned)nz);
+    const size_t lds = nr == 2 ? lds2 : lds1;
+#define GS2_CASE(C4, R) if (g.cch == 4 * C4 && nr == R) return gs2_launch_c<MODE, C4, R>(st, grid, lds, in, wt, bias, aux, out, g);
+    GS2_CASE(4, 2) GS2_CASE(2, 2) GS2_CASE(1, 2) GS2_CASE(4, 1) GS2_CASE(2, 1) GS2_CASE(1, 1)
+#undef GS2_CASE
+    return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------------
@@ -339,12 +361,9 @@ hipError_t launch_gen_s2_fwd(hipStream_t st, const float* in, const float* wt, c
                              int Co, int k, int elu)
 {
     if (!gen_s2_mfma_ok(k, Ci, ldc, Co, Co)) return hipErrorInvalidValue;
-    size_t lds = 0;
-    const int cch = gs2_cch(0, k, Ci, Co, &lds);
-    if (!cch) return hipErrorInvalidValue;
     const int So = (Si - 1) / 2 + 1;
-    Gs2Geom g{Si, So, Si, Ci, ldc, Co, Co, k, Ci * Co, Co, 1, cch, elu, (So + GS2_TC - 1) / GS2_TC, (So + GS2_TR - 1) / GS2_TR};
-    return gs2_launch<0>(st, dim3((unsigned)(N * g.tiles_x * g.tiles_y), 1, (unsigned)((Co + 63) / 64)), lds, in, wt, bias, nullptr, out, g);
+    Gs2Geom g{Si, So, Si, Ci, ldc, Co, Co, k, Ci * Co, Co, 1, 0, elu, 0, 0};
+    return gs2_launch<0>(st, N, (Co + 63) / 64, 1, in, wt, bias, nullptr, out, g);
 }
 
 // data gradient: dout [N][So][So][Co], wt [tap][ldi][Co] -> din [N][Si][Si][ldi] (Ci <= ldi channels computed) times ELU'(aux)
@@ -352,13 +371,10 @@ hipError_t launch_gen_s2_dgrad(hipStream_t st, const float* dout, const float* w
                                int Co, int k)
 {
     if (!gen_s2_mfma_ok(k, Co, Co, Ci, ldi)) return hipErrorInvalidValue;
-    size_t lds = 0;
-    const int cch = gs2_cch(1, k, Co, Ci, &lds);
-    if (!cch) return hipErrorInvalidValue;
     const int So = (Si - 1) / 2 + 1;
     // W(tap, k = co, n = ci) = wt[tap][ci][co]
-    Gs2Geom g{So, So, Si, Co, Co, Ci, ldi, k, ldi * Co, 1, Co, cch, 0, (So + GS2_TC - 1) / GS2_TC, (So + GS2_TR - 1) / GS2_TR};
-    return gs2_launch<1>(st, dim3((unsigned)(N * g.tiles_x * g.tiles_y), 4, (unsigned)((Ci + 63) / 64)), lds, dout, wt, nullptr, aux, din, g);
+    Gs2Geom g{So, So, Si, Co, Co, Ci, ldi, k, ldi * Co, 1, Co, 0, 0, 0, 0};
+    return gs2_launch<1>(st, N, (Ci + 63) / 64, 4, dout, wt, nullptr, aux, din, g);
 }
 
 // weight gradient partials: part [nsl][k * k * Ci * Co + Co]; *nsl_out slices were written (sum them with gen_conv_wgrad_reduce_kernel)
