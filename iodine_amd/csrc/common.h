@@ -341,13 +341,15 @@ constexpr int GEN_WGRAD_SLICES = 64;
 constexpr int GEN_WGRAD_OUT_SLICES_MAX = 512;   // row slices of the 4-output-channel GEMM form (one per resident block)
 constexpr int GEN_WGRAD_SLICES_MAX = 128;  // the row-staged form sizes its slices to the chip (two blocks per CU): scratch is sized for this many
 hipError_t launch_gen_pack_weights(hipStream_t st, const float* w, int Co, int Ci, int k, float* wt);
+// chmask (stride-2 MFMA forms only): bit c = input channel c can be non-zero - groups of channels whose weights AND inputs are zero (an
+// ARCH.ENCODING subset: absent encoding channels) are skipped; all ones = every channel
 hipError_t launch_gen_conv_fwd(hipStream_t st, const float* in, const float* wt, const float* bias, float* out, int N, int Si, int Ci,
-                               int ldc, int Co, int k, int s, int elu);
+                               int ldc, int Co, int k, int s, int elu, unsigned chmask = 0xffffffffu);
 hipError_t launch_gen_conv_dgrad(hipStream_t st, const float* dout, const float* wt, const float* aux, float* din, int N, int Si, int Ci,
                                  int ldi, int Co, int k, int s);
 size_t gen_wgrad_scratch_floats(int Ci, int Co, int k);
 hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* dout, float* scratch, int N, int Si, int Ci, int ldc,
-                                 int Ci_dst, int Co, int k, int s, float alpha, float* gw, float* gb);
+                                 int Ci_dst, int Co, int k, int s, float alpha, float* gw, float* gb, unsigned chmask = 0xffffffffu);
 // kernels_genl0.hip: the spatial-broadcast layer of the generic decoder without the broadcast tensor (prefix table of per-tap latent products
 // forward, tap-window sums of the gradient backward); any odd k <= GEN_L0_KMAX
 constexpr int GEN_L0_KMAX = 7;
@@ -362,11 +364,11 @@ bool gen_s2_fwd_ok(int k, int Ci, int ldc, int Co);
 bool gen_s2_dgrad_ok(int k, int Ci, int ldi, int Co);
 bool gen_s2_wgrad_ok(int k, int Ci, int ldc, int Co);
 hipError_t launch_gen_s2_fwd(hipStream_t st, const float* in, const float* wt, const float* bias, float* out, int N, int Si, int Ci, int ldc,
-                             int Co, int k, int elu);
+                             int Co, int k, int elu, unsigned chmask = 0xffffffffu);
 hipError_t launch_gen_s2_dgrad(hipStream_t st, const float* dout, const float* wt, const float* aux, float* din, int N, int Si, int Ci, int ldi,
                                int Co, int k);
 hipError_t launch_gen_s2_wgrad(hipStream_t st, const float* in, const float* dout, float* part, int N, int Si, int Ci, int ldc, int Co, int k,
-                               int nsl_max, int* nsl_out);
+                               int nsl_max, int* nsl_out, unsigned chmask = 0xffffffffu);
 hipError_t launch_gen_identity(hipStream_t st, float* m, int rows, int L);
 hipError_t launch_ref_unsplit_grad(hipStream_t st, const float* g20, int O, float* gw);
 hipError_t launch_enc_join(hipStream_t st, const float* enck, const float* encs, float* enc, int N, int K, int P);

@@ -780,7 +780,7 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
     for (int l = 0; l < h->Dr; ++l) {
         if (h->gen_ref) {
             PROF(h, st, "gen_conv", launch_gen_conv_fwd(st, in, h->gen_wref[l], h->ref_b[l], b.ract[i][l], N, s, l == 0 ? 17 : h->Cr,
-                                                        l == 0 ? 20 : h->Cr, h->Cr, h->kr, 2, 1));
+                                                        l == 0 ? 20 : h->Cr, h->Cr, h->kr, 2, 1, l == 0 ? h->enc_chmask : 0xffffffffu));
         } else if (l == 0 && l0f) {
         } else if (l == 0 && split) {
             PROF(h, st, "refine_l0", launch_conv3x3_s2_f16x3(st, b.encs[i], h->ref_wsh16, h->ref_wshmeta, nullptr, b.rmap, B, s, 8,
@@ -1554,7 +1554,7 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
             if (gather0) HIPCHK(h, hipMemsetAsync(h->ref_g17, 0, (size_t)Cr * 17 * h->kr * h->kr * sizeof(float), st));
             if (h->gen_ref) {
                 PROF(h, st, "gen_conv", launch_gen_conv_wgrad(st, in, b.rdpre[l], b.gen_scr, NT, sz[l], ireal, cip, ireal, Cr, h->kr, 2, 1.f,
-                                                              gw_dst, G(base + ".bias")));
+                                                              gw_dst, G(base + ".bias"), l == 0 ? h->enc_chmask : 0xffffffffu));
             } else if (l == 0 && fuse01) {
                 int nb = 0;
                 PROF(h, st, "refine_bwd01", launch_refine_bwd01(st, b.rdpre[1], h->ref_w1ws, h->ref_w1ws_meta, b.ract[0][0], b.enck[0], b.encs[0],

@@ -907,7 +907,7 @@ hipError_t launch_gen_pack_weights(hipStream_t st, const float* w, int Co, int C
 }
 
 hipError_t launch_gen_conv_fwd(hipStream_t st, const float* in, const float* wt, const float* bias, float* out, int N, int Si, int Ci,
-                               int ldc, int Co, int k, int s, int elu)
+                               int ldc, int Co, int k, int s, int elu, unsigned chmask)
 {
     if (const size_t lds = gen_mfma_lds(k, Ci, ldc, s)) {
         // [tap][ci][co] pack: W(tap, k = ci, n = co)
@@ -916,7 +916,7 @@ hipError_t launch_gen_conv_fwd(hipStream_t st, const float* in, const float* wt,
         return gen_mfma_launch<7>(st, in, wt, bias, nullptr, out, N, Si, Ci, ldc, Co, Co, 0, Ci * Co, Co, 1, elu, lds);
     }
     if (s == 2 && gen_s2_fwd_ok(k, Ci, ldc, Co))         // stride 2 on the matrix pipe (kernels_gens2.hip, round 5)
-        return launch_gen_s2_fwd(st, in, wt, bias, out, N, Si, Ci, ldc, Co, k, elu);
+        return launch_gen_s2_fwd(st, in, wt, bias, out, N, Si, Ci, ldc, Co, k, elu, chmask);
     const int So = (Si - 1) / s + 1;
     const size_t total = (size_t)N * So * So * Co;
     hipLaunchKernelGGL(gen_conv_fwd_kernel, dim3(gen_blocks(total)), dim3(256), 0, st, in, wt, bias, out, Si, So, Ci, ldc, Co, k, s, elu, total);
@@ -947,7 +947,7 @@ size_t gen_wgrad_scratch_floats(int Ci, int Co, int k)
 }
 
 hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* dout, float* scratch, int N, int Si, int Ci, int ldc,
-                                 int Ci_dst, int Co, int k, int s, float alpha, float* gw, float* gb)
+                                 int Ci_dst, int Co, int k, int s, float alpha, float* gw, float* gb, unsigned chmask)
 {
     const int So = (Si - 1) / s + 1;
     const size_t per = (size_t)k * k * Ci * Co + Co;
@@ -1010,7 +1010,7 @@ hipError_t launch_gen_conv_wgrad(hipStream_t st, const float* in, const float* d
     }
     if (s == 2 && gen_s2_wgrad_ok(k, Ci, ldc, Co)) {
         int nsl = 0;
-        if (hipError_t e = launch_gen_s2_wgrad(st, in, dout, scratch, N, Si, Ci, ldc, Co, k, GEN_WGRAD_SLICES_MAX, &nsl); e != hipSuccess) return e;
+        if (hipError_t e = launch_gen_s2_wgrad(st, in, dout, scratch, N, Si, Ci, ldc, Co, k, GEN_WGRAD_SLICES_MAX, &nsl, chmask); e != hipSuccess) return e;
         hipLaunchKernelGGL(gen_conv_wgrad_reduce_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, scratch, nsl, Ci, Ci_dst, Co,
                            k * k, alpha, gw, gb);
         return hipGetLastError();

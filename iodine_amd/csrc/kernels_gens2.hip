@@ -35,6 +35,7 @@ struct Gs2Geom {
     int ks;             // kernel size
     int w_tap, w_k, w_n;  // strides of W(tap, k, n) in the packed [tap][ci][co] weight
     int cch;            // reduction channels per staged chunk (4, 8 or 16)
+    unsigned kmask;     // bit i: reduction channels 4 i .. 4 i + 3 can be non-zero (K <= 128; all ones otherwise) - zero groups are skipped
     int elu;
     int tiles_x, tiles_y;
 };
@@ -85,6 +86,8 @@ void gen_s2_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
     for (int i = 0; i < NR; ++i) lane_pix[i] = MODE == 0 ? (2 * (wv + 4 * i) * HC + 2 * lp) : ((wv + 4 * i) * HC + lp);
     constexpr int c4n = C4N;
     for (int k0 = 0; k0 < g.K; k0 += cch) {
+        const unsigned cm = k0 < 128 ? (g.kmask >> (k0 >> 2)) & ((1u << C4N) - 1u) : ~0u;      // live 4-channel steps of this chunk (block-uniform)
+        if (!cm) continue;                                     // nothing but zero weights x zero inputs in this chunk (absent encoding channels)
         __syncthreads();                                       // the previous chunk has been read
         // ---- halo chunk: float4 (pixel, channel quad) ----
         for (int i = tid; i < HR * HC * c4n; i += 256) {
@@ -142,6 +145,7 @@ void gen_s2_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
             const float* pa = s_w + (j * cch + lq) * NP + lp;
 #pragma unroll
             for (int k4 = 0; k4 < C4N; ++k4) {
+                if (!((cm >> k4) & 1u)) continue;
 #pragma unroll
                 for (int i = 0; i < NR; ++i) b[i][k4] = s_in[(lane_pix[i] + toff) * PS + lq + 4 * k4];
 #pragma unroll
@@ -151,12 +155,14 @@ void gen_s2_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
         };
         auto mma_tap = [&](const float (&b)[NR][C4N], const float (&a)[C4N][4]) {
 #pragma unroll
-            for (int k4 = 0; k4 < C4N; ++k4)
+            for (int k4 = 0; k4 < C4N; ++k4) {
+                if (!((cm >> k4) & 1u)) continue;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int i = 0; i < NR; ++i)
                         if (q < NG) acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k4][q], b[i][k4], acc[i][q], 0, 0, 0);
+            }
         };
         load_tap(0, bv[0], av[0]);
         for (int j = 0; j < ntap; j += 2) {
@@ -248,7 +254,7 @@ hipError_t gs2_launch(hipStream_t st, int N, int nz, int ygrid, const float* in,
 template <int KS>
 __global__ __launch_bounds__(256, 2)
 void gen_s2_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dout, float* __restrict__ part, int N, int Si, int So,
-                         int Ci, int ldc, int Co, int nsl, int npg)
+                         int Ci, int ldc, int Co, int nsl, int npg, unsigned cimask)
 {
     constexpr int ks = KS;
     extern __shared__ __attribute__((aligned(16))) float smem_gs2[];
@@ -274,6 +280,7 @@ void gen_s2_wgrad_kernel(const float* __restrict__ in, const float* __restrict__
 #pragma unroll
     for (int q = 0; q < KS; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};                    // bias partial: row 0 of a ones x gradient product
+    const bool work = live && ((cimask >> min(cig, 31)) & 1u);       // a 16-channel group of all-zero inputs (absent encoding channels): zeros, no MFMAs
     const bool do_bias = live && ky == 0 && cig == 0;
     const int ci4 = (Ci + 3) >> 2, co4 = Co >> 2;
 
@@ -312,7 +319,7 @@ void gen_s2_wgrad_kernel(const float* __restrict__ in, const float* __restrict__
                 s_a[pix * Cip + c] = 0.f;
             }
         __syncthreads();
-        if (live) {
+        if (work || do_bias) {
             // K = positions: 4 per MFMA (lq), 16 per slab row -> 4 steps per row
 #pragma unroll 1
             for (int r = 0; r < GS2_TR; ++r) {
@@ -324,8 +331,10 @@ void gen_s2_wgrad_kernel(const float* __restrict__ in, const float* __restrict__
                     float av[KS];
 #pragma unroll
                     for (int kx = 0; kx < KS; ++kx) av[kx] = pa[(8 * s4 + kx) * Cip];
+                    if (work) {
 #pragma unroll
-                    for (int kx = 0; kx < KS; ++kx) acc[kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kx], dv, acc[kx], 0, 0, 0);
+                        for (int kx = 0; kx < KS; ++kx) acc[kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kx], dv, acc[kx], 0, 0, 0);
+                    }
                     if (do_bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv, accb, 0, 0, 0);
                 }
             }
@@ -357,12 +366,21 @@ bool gen_s2_mfma_ok(int k, int K, int ldk, int Nn, int ldn)
 }
 
 // forward: in [N][Si][Si][ldc] (Ci of ldc channels), wt [tap][Ci][Co] -> out [N][So][So][Co], So = (Si - 1) / 2 + 1
+// 4-channel groups of a per-channel mask (bit c = channel c can be non-zero), for K <= 128 channels
+static unsigned gs2_kmask4(unsigned chmask, int K)
+{
+    if (chmask == 0xffffffffu || K > 32) return 0xffffffffu;       // (the per-channel mask has 32 bits: larger layers are never subsets)
+    unsigned m = 0;
+    for (int c = 0; c < K; ++c) if ((chmask >> c) & 1u) m |= 1u << (c >> 2);
+    return m;
+}
+
 hipError_t launch_gen_s2_fwd(hipStream_t st, const float* in, const float* wt, const float* bias, float* out, int N, int Si, int Ci, int ldc,
-                             int Co, int k, int elu)
+                             int Co, int k, int elu, unsigned chmask)
 {
     if (!gen_s2_mfma_ok(k, Ci, ldc, Co, Co)) return hipErrorInvalidValue;
     const int So = (Si - 1) / 2 + 1;
-    Gs2Geom g{Si, So, Si, Ci, ldc, Co, Co, k, Ci * Co, Co, 1, 0, elu, 0, 0};
+    Gs2Geom g{Si, So, Si, Ci, ldc, Co, Co, k, Ci * Co, Co, 1, 0, gs2_kmask4(chmask, Ci), elu, 0, 0};
     return gs2_launch<0>(st, N, (Co + 63) / 64, 1, in, wt, bias, nullptr, out, g);
 }
 
@@ -373,14 +391,19 @@ hipError_t launch_gen_s2_dgrad(hipStream_t st, const float* dout, const float* w
     if (!gen_s2_mfma_ok(k, Co, Co, Ci, ldi)) return hipErrorInvalidValue;
     const int So = (Si - 1) / 2 + 1;
     // W(tap, k = co, n = ci) = wt[tap][ci][co]
-    Gs2Geom g{So, So, Si, Co, Co, Ci, ldi, k, ldi * Co, 1, Co, 0, 0, 0, 0};
+    Gs2Geom g{So, So, Si, Co, Co, Ci, ldi, k, ldi * Co, 1, Co, 0, 0xffffffffu, 0, 0, 0};
     return gs2_launch<1>(st, N, (Ci + 63) / 64, 4, dout, wt, nullptr, aux, din, g);
 }
 
 // weight gradient partials: part [nsl][k * k * Ci * Co + Co]; *nsl_out slices were written (sum them with gen_conv_wgrad_reduce_kernel)
 hipError_t launch_gen_s2_wgrad(hipStream_t st, const float* in, const float* dout, float* part, int N, int Si, int Ci, int ldc, int Co, int k,
-                               int nsl_max, int* nsl_out)
+                               int nsl_max, int* nsl_out, unsigned chmask)
 {
+    unsigned cimask = 0xffffffffu;                                  // 16-channel groups with a channel that can be non-zero
+    if (chmask != 0xffffffffu && Ci <= 32) {
+        cimask = 0;
+        for (int c = 0; c < Ci; ++c) if ((chmask >> c) & 1u) cimask |= 1u << (c >> 4);
+    }
     if (!gen_s2_mfma_ok(k, Ci, ldc, Co, Co)) return hipErrorInvalidValue;
     const int So = (Si - 1) / 2 + 1;
     const int ncig = (Ci + 15) / 16, ncog = (Co + 15) / 16, npg = (ncig * ncog + 3) / 4;
@@ -396,9 +419,9 @@ hipError_t launch_gen_s2_wgrad(hipStream_t st, const float* in, const float* dou
     const int nslab = N * ((So + GS2_TC - 1) / GS2_TC) * ((So + GS2_TR - 1) / GS2_TR);
     const int nsl = std::max(1, std::min(std::min(nsl_max, nslab), std::max(1, 2 * n_cu / (k * npg))));
     const dim3 grid((unsigned)(k * npg * nsl));
-    if (k == 3) hipLaunchKernelGGL((gen_s2_wgrad_kernel<3>), grid, dim3(256), lds, st, in, dout, part, N, Si, So, Ci, ldc, Co, nsl, npg);
-    else if (k == 5) hipLaunchKernelGGL((gen_s2_wgrad_kernel<5>), grid, dim3(256), lds, st, in, dout, part, N, Si, So, Ci, ldc, Co, nsl, npg);
-    else hipLaunchKernelGGL((gen_s2_wgrad_kernel<7>), grid, dim3(256), lds, st, in, dout, part, N, Si, So, Ci, ldc, Co, nsl, npg);
+    if (k == 3) hipLaunchKernelGGL((gen_s2_wgrad_kernel<3>), grid, dim3(256), lds, st, in, dout, part, N, Si, So, Ci, ldc, Co, nsl, npg, cimask);
+    else if (k == 5) hipLaunchKernelGGL((gen_s2_wgrad_kernel<5>), grid, dim3(256), lds, st, in, dout, part, N, Si, So, Ci, ldc, Co, nsl, npg, cimask);
+    else hipLaunchKernelGGL((gen_s2_wgrad_kernel<7>), grid, dim3(256), lds, st, in, dout, part, N, Si, So, Ci, ldc, Co, nsl, npg, cimask);
     *nsl_out = nsl;
     return hipGetLastError();
 }
