@@ -175,7 +175,9 @@ int iodine_ari_table(void* stream, const float* mask, const unsigned char* gt, i
  * "profile" (bracket kernel launches with HIP events on the launch stream: 1 = the dominant "conv_tile_*" launches only --
  * 54 of ~330 per training step, what bench.py keeps on inside its timed region; 2 = every category; 0 = off),
  * "conv_precision" (3x3 convs of the decoder and refinement stacks: 0 = exact fp32 MFMA -- IEEE fp32 products, fp32 accumulate,
- * the reference's arithmetic (nn.Conv2d fp32, iodine.py:583); 1 = fp32 operands split into fp16 hi+lo with one power-of-two
+ * the reference's arithmetic (nn.Conv2d fp32, iodine.py:583), and with it the per-pixel mixture terms (sigmoid, slot softmax,
+ * responsibilities: iodine.py:185-216) on libm expf + IEEE division like ATen, where the default path uses v_exp_f32 / v_rcp_f32
+ * on their bounded arguments (pixel_terms.h); 1 = fp32 operands split into fp16 hi+lo with one power-of-two
  * scale per 8 x 16 cell, 3 fp16 MFMAs, fp32 accumulate: products carry >= 22 bits relative to the CELL maximum (tile-relative,
  * not element-relative) -- default; only the selected path's weight packs are maintained, so a change must be followed by
  * iodine_set_params before the next compute call),

@@ -178,15 +178,17 @@ hipError_t launch_dec_out(hipStream_t st, const float* in, const float* wk, cons
 
 // kernels_pixel.hip
 int pixel_blocks_per_image(int P);
+// strict = 1 (conv_precision 0): libm expf + IEEE division in the per-pixel mixture terms (pixel_terms.h), 0: v_exp_f32 / v_rcp_f32 where bounded
 hipError_t launch_pixel_pass1(hipStream_t st, const float* x4, const float* dec, float* g, double* part, int B,
-                              int K, int P, float sigma);
+                              int K, int P, float sigma, int strict = 0);
 hipError_t launch_pixel_finalize(hipStream_t st, const double* part, int B, int K, int P, int use_ln,
                                  float* lnstat, float* ll_img);
 // finalize + KL + batch means in one launch; counter: one zero-initialised device word per handle
 hipError_t launch_pixel_finalize_elbo(hipStream_t st, const double* part, int B, int K, int P, int use_ln, float* lnstat, float* ll_img,
                                       const float* pm, const float* plv, int L, float* img_terms, float* scal, unsigned* counter);
 hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec, const float* lnstat,
-                              const float* lin, float* enc, int B, int K, int S, float sigma, float* enc_sh = nullptr, unsigned chmask = 0x1ffffu);
+                              const float* lin, float* enc, int B, int K, int S, float sigma, float* enc_sh = nullptr, unsigned chmask = 0x1ffffu,
+                              int strict = 0);
 hipError_t launch_final_out(hipStream_t st, const float* dec, float* pred, float* mask, float* mean, float* logits,
                             int B, int K, int P);
 // kernels_misc.hip

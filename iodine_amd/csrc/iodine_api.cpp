@@ -587,11 +587,11 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
     bool fused_l0 = false;
     // training: one pass over the last hidden activation gives the data gradient AND the weight / bias gradient
     const bool out_fused = train_alpha != 0.f && h->precision == 1 && h->out_bwd_fused;
+    // round 5: a block's partial tile accumulates alpha_i x (pass i) in a per-layer buffer; reduced once, after the last pass (it == T)
+    const bool acc_w = train_alpha != 0.f && h->wgrad_accum && !b.wg_acc.empty() && b.wg_acc[0];
 #ifdef IODINE_XSKIP_HOOK
     if (!(g_iod_xskip & 256))
 #endif
-    // round 5: a block's partial tile accumulates alpha_i x (pass i) in a per-layer buffer; reduced once, after the last pass (it == T)
-    const bool acc_w = train_alpha != 0.f && h->wgrad_accum && !b.wg_acc.empty() && b.wg_acc[0];
     if (out_fused) {
         const int wi = param_index(h, "decoder.conv.weight"), bi = param_index(h, "decoder.conv.bias");
         if (acc_w) {
@@ -725,7 +725,7 @@ int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps
     HIPCHK(h, launch_dec_v(st, b.pm, b.plv, eps_i, nullptr, h->wcls, b.z[i], b.V, N, h->L, h->Cd));
     int rc = decoder_forward(h, st, N, b.z[i]);
     if (rc) return rc;
-    PROF(h, st, "pixel_pass1", launch_pixel_pass1(st, b.x4, b.dec_out, b.g, b.part, B, h->K, h->P, (float)h->cfg.sigma));
+    PROF(h, st, "pixel_pass1", launch_pixel_pass1(st, b.x4, b.dec_out, b.g, b.part, B, h->K, h->P, (float)h->cfg.sigma, h->precision == 0));
     // the ticket of pixel_finalize_elbo_kernel is reset by the last block of every launch; the first launch of an entry point also
     // starts from a fresh 0 (a memset node under graph capture), whatever a failed call or a misuse of the handle from a second
     // stream left in it - once per call, not per launch (a memset is a launch of its own)
@@ -774,7 +774,7 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
                                                          h->enc_chmask));
     else
         PROF(h, st, "pixel_pass2", launch_pixel_pass2(st, b.x4, b.dec_out, b.lnstat, h->lin, split ? b.enck[i] : b.enc[i], B, h->K, h->S,
-                                                      (float)h->cfg.sigma, split ? b.encs[i] : nullptr, h->enc_chmask));
+                                                      (float)h->cfg.sigma, split ? b.encs[i] : nullptr, h->enc_chmask, h->precision == 0));
     int s = h->S;
     const float* in = b.enc[i];
     for (int l = 0; l < h->Dr; ++l) {

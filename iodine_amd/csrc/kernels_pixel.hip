@@ -44,7 +44,7 @@ IOD_DEVINL double wave_sum_d(double v)
 
 // ---- pass 1: ELBO log-likelihood partials, gradient wrt decoder output, layer-norm partial sums ----
 // part layout per (b, block): [0] ll, [1] like.s1, [2] like.s2, then per k: g1.s1, g1.s2, g2.s1, g2.s2, loo.s1, loo.s2
-template <int K>
+template <int K, bool STRICT>
 __global__ __launch_bounds__(PIX_BLOCK)
 void pixel_pass1_kernel(const float4* __restrict__ x4, const float4* __restrict__ dec, float4* __restrict__ g,
                         double* __restrict__ part, int P, int ppb, float inv2s2, float invs2, float lconst)
@@ -62,7 +62,7 @@ void pixel_pass1_kernel(const float4* __restrict__ x4, const float4* __restrict_
     const int pend = min(P, (blk + 1) * ppb);
     for (int p = blk * ppb + tid; p < pend; p += PIX_BLOCK) {
         PixelTerms<K> t;
-        pixel_terms<K>(x4[(size_t)b * P + p], dec_b, (size_t)P, (size_t)p, inv2s2, invs2, lconst, t);
+        pixel_terms<K, STRICT>(x4[(size_t)b * P + p], dec_b, (size_t)P, (size_t)p, inv2s2, invs2, lconst, t);
         float tg = 0.f;
 #pragma unroll
         for (int k = 0; k < K; ++k) tg += t.m[k] * t.g2[k];
@@ -238,7 +238,7 @@ void pixel_finalize_elbo_kernel(const double* __restrict__ part, int nblk, int K
 // and the 6 channels every slot of an image shares, once per image, to
 //   enc_sh[b][p][8]  = image rgb, LN(pixel likelihood), coordinate x, coordinate y, 0, 0
 // (294 -> 176 + 17 MB per iteration at cfg3; the shared part is convolved once per image instead of once per slot).
-template <int K, bool SPLIT>
+template <int K, bool SPLIT, bool STRICT>
 __global__ __launch_bounds__(PIX_BLOCK)
 void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict__ dec,
                         const float* __restrict__ lnstat, const float* __restrict__ lin, float* __restrict__ enc,
@@ -266,7 +266,7 @@ void pixel_pass2_kernel(const float4* __restrict__ x4, const float4* __restrict_
         const int p = p0 + min(lane, nvalid - 1);                          // idle lanes recompute the last pixel
         PixelTerms<K> t;
         const float4 xv = x4[(size_t)b * P + p];
-        pixel_terms<K>(xv, dec_b, (size_t)P, (size_t)p, inv2s2, invs2, lconst, t);
+        pixel_terms<K, STRICT>(xv, dec_b, (size_t)P, (size_t)p, inv2s2, invs2, lconst, t);
         float psum = 0.f;
 #pragma unroll
         for (int k = 0; k < K; ++k) psum += t.pk[k];
@@ -379,15 +379,19 @@ void final_out_kernel(const float4* __restrict__ dec, float* __restrict__ pred, 
 int pixel_blocks_per_image(int P) { return (P + 2 * PIX_BLOCK - 1) / (2 * PIX_BLOCK); }   // 2 pixels / thread
 
 hipError_t launch_pixel_pass1(hipStream_t st, const float* x4, const float* dec, float* g, double* part, int B,
-                              int K, int P, float sigma)
+                              int K, int P, float sigma, int strict)
 {
     IOD_XSKIP(8);
     const int nblk = pixel_blocks_per_image(P), ppb = (P + nblk - 1) / nblk;
     const float inv2s2 = 1.f / (2.f * sigma * sigma), invs2 = 1.f / (sigma * sigma);
     const float lconst = (float)(-log((double)sigma) - 0.5 * log(2.0 * M_PI));
     switch (K) {
-#define CASE(KK) case KK: hipLaunchKernelGGL((pixel_pass1_kernel<KK>), dim3(nblk, B), dim3(PIX_BLOCK), 0, st, \
-        (const float4*)x4, (const float4*)dec, (float4*)g, part, P, ppb, inv2s2, invs2, lconst); break;
+#define CASE(KK) case KK: \
+        if (strict) hipLaunchKernelGGL((pixel_pass1_kernel<KK, true>), dim3(nblk, B), dim3(PIX_BLOCK), 0, st, \
+            (const float4*)x4, (const float4*)dec, (float4*)g, part, P, ppb, inv2s2, invs2, lconst); \
+        else hipLaunchKernelGGL((pixel_pass1_kernel<KK, false>), dim3(nblk, B), dim3(PIX_BLOCK), 0, st, \
+            (const float4*)x4, (const float4*)dec, (float4*)g, part, P, ppb, inv2s2, invs2, lconst); \
+        break;
         FOR_EACH_K(CASE)
 #undef CASE
         default: return hipErrorInvalidValue;
@@ -415,7 +419,7 @@ hipError_t launch_pixel_finalize_elbo(hipStream_t st, const double* part, int B,
 }
 
 hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec, const float* lnstat,
-                              const float* lin, float* enc, int B, int K, int S, float sigma, float* enc_sh, unsigned chmask)
+                              const float* lin, float* enc, int B, int K, int S, float sigma, float* enc_sh, unsigned chmask, int strict)
 {
     IOD_XSKIP(8);
     const int P = S * S;
@@ -423,14 +427,15 @@ hipError_t launch_pixel_pass2(hipStream_t st, const float* x4, const float* dec,
     const float inv2s2 = 1.f / (2.f * sigma * sigma), invs2 = 1.f / (sigma * sigma);
     const float lconst = (float)(-log((double)sigma) - 0.5 * log(2.0 * M_PI));
     switch (K) {
+#define P2(KQ, SP, ST) hipLaunchKernelGGL((pixel_pass2_kernel<KQ, SP, ST>), dim3(nblk, B), dim3(PIX_BLOCK), 0, st, \
+            (const float4*)x4, (const float4*)dec, lnstat, lin, enc, enc_sh, P, S, ppb, inv2s2, invs2, lconst, chmask)
 #define CASE(KK) case KK: \
-        if (enc_sh) hipLaunchKernelGGL((pixel_pass2_kernel<KK, true>), dim3(nblk, B), dim3(PIX_BLOCK), 0, st, \
-            (const float4*)x4, (const float4*)dec, lnstat, lin, enc, enc_sh, P, S, ppb, inv2s2, invs2, lconst, chmask); \
-        else hipLaunchKernelGGL((pixel_pass2_kernel<KK, false>), dim3(nblk, B), dim3(PIX_BLOCK), 0, st, \
-            (const float4*)x4, (const float4*)dec, lnstat, lin, enc, enc_sh, P, S, ppb, inv2s2, invs2, lconst, chmask); \
+        if (enc_sh) { if (strict) P2(KK, true, true); else P2(KK, true, false); } \
+        else { if (strict) P2(KK, false, true); else P2(KK, false, false); } \
         break;
         FOR_EACH_K(CASE)
 #undef CASE
+#undef P2
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -26,12 +26,14 @@ struct PixelTerms {
 // 1 / inf = 0 and NaN propagate like the IEEE sequence).  The UN-stabilised terms of the reference keep libm's expf and the IEEE
 // division: p_k = exp(sum_c l_kc) and exp(ll_sum) (arguments down to -140: denormal results matter for WHERE the 0 / 0 of
 // mask_posterior appears, iodine.py:286-293) and the leave-one-out channel (the reference's exact sequence of rounded operations, below).
-IOD_DEVINL float pt_exp_bounded(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
-IOD_DEVINL float pt_rcp(float d) { return __builtin_amdgcn_rcpf(d); }
-IOD_DEVINL float pt_sigmoid(float v) { return pt_rcp(1.f + pt_exp_bounded(-v)); }
+// Round 6: STRICT = the strict path (option conv_precision 0, "the reference's arithmetic"): libm expf and IEEE division
+// everywhere, like ATen - the hardware approximations above are a property of the DEFAULT path only.
+template <bool STRICT> IOD_DEVINL float pt_exp_bounded(float x) { if constexpr (STRICT) return expf(x); else return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+template <bool STRICT> IOD_DEVINL float pt_rcp(float d) { if constexpr (STRICT) return 1.f / d; else return __builtin_amdgcn_rcpf(d); }
+template <bool STRICT> IOD_DEVINL float pt_sigmoid(float v) { return pt_rcp<STRICT>(1.f + pt_exp_bounded<STRICT>(-v)); }
 
 // dv[k] = decoder output (rgb logits, mask logit) of slot k at this pixel
-template <int K>
+template <int K, bool STRICT = false>
 IOD_DEVINL void pixel_terms_core(const float4 xv, const float4 (&dv)[K], float inv2s2, float invs2, float lconst, PixelTerms<K>& t)
 {
     // No fp contraction in here: pass 1 (layer-norm statistics) and pass 2 (the values that get normalised) inline this function
@@ -45,21 +47,21 @@ IOD_DEVINL void pixel_terms_core(const float4 xv, const float4 (&dv)[K], float i
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const float4 d = dv[k];
-        t.mu[k][0] = pt_sigmoid(d.x); t.mu[k][1] = pt_sigmoid(d.y); t.mu[k][2] = pt_sigmoid(d.z);
+        t.mu[k][0] = pt_sigmoid<STRICT>(d.x); t.mu[k][1] = pt_sigmoid<STRICT>(d.y); t.mu[k][2] = pt_sigmoid<STRICT>(d.z);
         t.logit[k] = d.w;
         mx = fmaxf(mx, d.w);
     }
     float den = 0.f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) { t.m[k] = pt_exp_bounded(t.logit[k] - mx); den += t.m[k]; }
-    const float rden = pt_rcp(den);
+    for (int k = 0; k < K; ++k) { t.m[k] = pt_exp_bounded<STRICT>(t.logit[k] - mx); den += t.m[k]; }
+    const float rden = pt_rcp<STRICT>(den);
     float lm[K], rme[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         t.m[k] *= rden;
         const float me = t.m[k] + 1e-12f;
         lm[k] = logf(me);
-        rme[k] = pt_rcp(me);                                   // 1 / (m_k + 1e-12): d log(m + 1e-12) / dm, once per slot
+        rme[k] = pt_rcp<STRICT>(me);                                   // 1 / (m_k + 1e-12): d log(m + 1e-12) / dm, once per slot
         t.g2[k] = 0.f;
     }
     float lsum[K];
@@ -80,9 +82,9 @@ IOD_DEVINL void pixel_terms_core(const float4 xv, const float4 (&dv)[K], float i
         }
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < K; ++k) { a[k] = pt_exp_bounded(a[k] - amax); s += a[k]; }
+        for (int k = 0; k < K; ++k) { a[k] = pt_exp_bounded<STRICT>(a[k] - amax); s += a[k]; }
         t.ll_sum += amax + logf(s);
-        const float rs = pt_rcp(s);
+        const float rs = pt_rcp<STRICT>(s);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float r = a[k] * rs;                         // responsibility of slot k for channel c
@@ -114,12 +116,12 @@ IOD_DEVINL void pixel_terms_core(const float4 xv, const float4 (&dv)[K], float i
     for (int k = 0; k < K; ++k) t.loo[k] = (t.mix - prod[k]) / ((1.f - t.m[k]) + 1e-5f);
 }
 
-template <int K>
+template <int K, bool STRICT = false>
 IOD_DEVINL void pixel_terms(const float4 xv, const float4* __restrict__ dec, size_t slot_stride, size_t p,
                             float inv2s2, float invs2, float lconst, PixelTerms<K>& t)
 {
     float4 dv[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) dv[k] = dec[(size_t)k * slot_stride + p];
-    pixel_terms_core<K>(xv, dv, inv2s2, invs2, lconst, t);
+    pixel_terms_core<K, STRICT>(xv, dv, inv2s2, invs2, lconst, t);
 }

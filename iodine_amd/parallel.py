@@ -106,23 +106,34 @@ def replicas_identical(params: Iterable[torch.nn.Parameter], group=None) -> bool
         return True
     with torch.no_grad():
         ps = list(params)
+        # every rank enters the SAME sequence of collectives, whatever it holds: first the tensor count (a rank without parameters
+        # still takes part), then the per-tensor byte sizes, and only when both agree everywhere the bit patterns themselves
+        if ps:
+            dev = ps[0].device
+        else:                                              # (a rank without tensors: the backend decides where collectives live)
+            dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+        cnt = torch.tensor([len(ps)], dtype=torch.int64, device=dev)
+        c_lo, c_hi = cnt.clone(), cnt.clone()
+        dist.all_reduce(c_lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(c_hi, op=dist.ReduceOp.MAX, group=group)
+        if int(c_lo.item()) != int(c_hi.item()):
+            return False                                   # different numbers of tensors
         if not ps:
-            return True                                    # nothing to compare
-        dev = ps[0].device
-        # element counts in units of the view below (bytes for dtypes that are not 4 bytes wide)
-        n = torch.tensor([sum(p.numel() * p.element_size() for p in ps), len(ps)], dtype=torch.int64, device=dev)
-        n_lo, n_hi = n.clone(), n.clone()
-        dist.all_reduce(n_lo, op=dist.ReduceOp.MIN, group=group)
-        dist.all_reduce(n_hi, op=dist.ReduceOp.MAX, group=group)
-        if not torch.equal(n_lo, n_hi):
-            return False                                   # different shapes: the bit buffers below would not even line up
+            return True                                    # nothing to compare, on any rank
+        sizes = torch.tensor([p.numel() * p.element_size() for p in ps] + [p.element_size() for p in ps], dtype=torch.int64, device=dev)
+        s_lo, s_hi = sizes.clone(), sizes.clone()
+        dist.all_reduce(s_lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(s_hi, op=dist.ReduceOp.MAX, group=group)
+        if not torch.equal(s_lo, s_hi):
+            return False                                   # same count, different per-tensor sizes: the collectives below would not line up
         # per tensor, in chunks of at most 16 Mi elements: one reused pair of buffers instead of three copies of all parameters;
-        # every rank runs the same sequence of collectives (the shapes were just found equal); the verdict is formed at the end
+        # every rank runs the same sequence of collectives (the per-tensor sizes were just found equal); the verdict is formed at the end.
+        # 4-byte dtypes are compared as int32 bit patterns; anything else byte by byte, widened to int32 (RCCL has no int16 / uint8 MIN)
         same = True
         CH = 1 << 24
         for p in ps:
             flat = p.detach().contiguous().reshape(-1)
-            bits = flat.view(torch.int32) if flat.element_size() == 4 else flat.view(torch.uint8).to(torch.int16)
+            bits = flat.view(torch.int32) if flat.element_size() == 4 else flat.view(torch.uint8).to(torch.int32)
             for o in range(0, bits.numel(), CH):
                 lo, hi = bits[o:o + CH].clone(), bits[o:o + CH].clone()
                 dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)

@@ -134,3 +134,17 @@ def test_reference_checkpoint_loads_on_cpu_side(tmp_path):
     assert extra == {'epoch': 3}
     for k, v in m.state_dict().items():
         assert torch.equal(v, params[k]), k
+
+
+def test_ablation_hook_build_of_the_host_file_compiles():
+    """tools/helper_cost.py and the DESIGN.md helper-cost figures come from a -DIODINE_XSKIP_HOOK build; the guard sits in front of
+    an if / else in decoder_backward_data and once swallowed a declaration: keep that build compiling."""
+    import shutil
+    import subprocess
+    hipcc = '/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else shutil.which('hipcc')
+    if not hipcc:
+        pytest.skip('hipcc not installed')
+    src = os.path.join(ROOT, 'iodine_amd', 'csrc', 'iodine_api.cpp')
+    r = subprocess.run([hipcc, '-fsyntax-only', '--cuda-host-only', '--offload-arch=gfx950', '-std=c++17', '-x', 'hip', '-Wno-dangling-else',
+                        '-Wno-unused-command-line-argument', '-DIODINE_XSKIP_HOOK', src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

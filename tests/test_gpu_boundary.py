@@ -244,6 +244,29 @@ def test_every_kernel_option_end_to_end(opt, val, case):
 
 
 @pytest.mark.parametrize('case', ['cfg1_dsprites_k4_t3_b4', 'cfg3_clevr_k7_t5_b1'])
+def test_wgrad_accum_on_the_exact_fp32_path(case):
+    """Option wgrad_accum has its own read-modify-write tail in conv3x3_wgrad_f32_ws_kernel, and with conv_precision 0 the output conv
+    keeps its per-pass reduction while layers 1.. accumulate over the passes: the mix against the reference goldens, at
+    one 32-channel and one 64-channel shape."""
+    g = load_golden(case)
+    arch, params, x, eps, _ = golden_setup(g)
+    m = make_hip_model(arch, params, options={'conv_precision': 0, 'wgrad_accum': 1})
+    ref = make_hip_model(arch, params, options={'conv_precision': 0})
+    xd, ed = x.to(DEV), eps.to(DEV)
+    for mm in (m, ref):
+        mm.zero_grad(set_to_none=True)
+        mm(xd, ed).backward()
+    bad = []
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        a = p.grad.double().cpu().flatten()
+        ss, ref_ss = float((a * a).sum()), float(g[f'f64.train.grad.{n}.sumsq'])
+        if abs(ss - ref_ss) > 2e-3 * ref_ss + 1e-12:
+            bad.append((n, ss, ref_ss))
+        assert rel_l2(p.grad.cpu(), q.grad.cpu()) < 2e-5, n          # same products, other summation order over the passes
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('case', ['cfg1_dsprites_k4_t3_b4', 'cfg3_clevr_k7_t5_b1'])
 def test_fused_output_conv_backward_equals_the_two_kernel_form(case):
     """Training: dec_out_bwd_fused_f16x3_kernel (one pass over the saved activation) against dec_out_dgrad_f16x3_kernel +
     dec_out_wgrad_gemm_f16x3_kernel (same packs, same three split passes; only tile shapes / summation order differ)."""

@@ -55,6 +55,18 @@ def _worker(rank, world, port, ret, flat_layout=False):
     holder = torch.nn.ParameterList(list(ps.values()))
     parallel.broadcast_parameters(holder, 0)
     assert parallel.replicas_identical(ps.values())
+    # same total bytes and tensor count, different per-tensor sizes: a verdict (False), not mismatched collectives
+    odd = [torch.zeros(3 if rank == 0 else 5), torch.zeros(5 if rank == 0 else 3)]
+    assert not parallel.replicas_identical(odd)
+    # a rank that holds nothing still takes part in the count exchange
+    assert not parallel.replicas_identical([] if rank == 0 else [torch.zeros(2)])
+    assert parallel.replicas_identical([])
+    # 2-byte dtypes: compared byte by byte (widened to int32: RCCL / gloo have no int16 MIN everywhere)
+    half = [torch.full((7,), 1.5, dtype=torch.float16), torch.arange(4, dtype=torch.bfloat16)]
+    assert parallel.replicas_identical(half)
+    if rank == 1:
+        half[0][3] = 1.501
+    assert not parallel.replicas_identical(half)
     if rank == 0:
         ret['loss'] = float(loss.item())
         ret['grads'] = {k: p.grad.numpy().copy() for k, p in ps.items()}
