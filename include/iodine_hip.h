@@ -269,7 +269,10 @@ int iodine_op_conv3x3_wgrad_f32(void* stream, const float* in_nhwc, const float*
 /* the generic path's convolution (any odd kernel size k, any stride s in {1, 2}; kernels_generic.hip / kernels_gens2.hip), one
  * direction per call - mode 0: out_nhwc [n][so][so][co] = act(bias + conv(in_nhwc [n][si][si][ldc], w_oihw [co][ci][k][k])), elu = 1
  * applies ELU; mode 1: out_nhwc [n][si][si][ci] = ELU'(aux) * data gradient of the gradient in_nhwc [n][so][so][co]; mode 2: weight +
- * bias gradient of (in_nhwc, aux = gradient [n][so][so][co]) ADDED to out_nhwc = gw [co][ci][k][k] and gb [co].  so = (si - 1) / s + 1. */
+ * bias gradient of (in_nhwc, aux = gradient [n][so][so][co]) ADDED to out_nhwc = gw [co][ci][k][k] and gb [co].  so = (si - 1) / s + 1.
+ * Modes 0 / 2, tests only: elu | 0x100 | (mask << 9) hands the kernels the per-channel mask of input channels that can be non-zero (bit c =
+ * channel c; ci <= 22), as the library does for the first refinement layer of an ARCH.ENCODING subset - channel groups that are zero in
+ * the input AND the weights are skipped; the result must equal the unmasked call. */
 int iodine_op_gen_conv(void* stream, int mode, const float* in_nhwc, const float* w_oihw, const float* bias, const float* aux,
                        float* out_nhwc, float* gb, int n, int si, int ci, int ldc, int co, int k, int s, int elu);
 

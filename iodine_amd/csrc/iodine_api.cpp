@@ -1952,6 +1952,10 @@ int iodine_op_gen_conv(void* stream, int mode, const float* in, const float* w, 
 {
     hipStream_t st = (hipStream_t)stream;
     if (mode < 0 || mode > 2 || (s != 1 && s != 2) || (k != 3 && k != 5 && k != 7) || ldc < ci) { g_create_error = "iodine_op_gen_conv: argument"; return IODINE_ERR_INVALID; }
+    // tests only: elu bit 8 set = bits 9.. carry a per-channel mask of the input channels that can be non-zero (what the library hands
+    // the stride-2 kernels for an ARCH.ENCODING subset: all-zero 4- / 16-channel groups are skipped) - the masked form must equal the plain one
+    const unsigned chmask = (elu & 0x100) ? ((unsigned)elu >> 9) : 0xffffffffu;
+    elu &= 1;
     float* buf = nullptr;
     // weights [tap][ci][co]: the forward pack has ci rows, the data-gradient pack ldc rows (the packed input-channel count is din's stride)
     const size_t wfl = (size_t)k * k * ldc * co, scr = mode == 2 ? gen_wgrad_scratch_floats(ci, co, k) : 0;
@@ -1959,13 +1963,13 @@ int iodine_op_gen_conv(void* stream, int mode, const float* in, const float* w, 
     hipError_t e = hipSuccess;
     if (mode == 0) {
         e = launch_gen_pack_weights(st, w, co, ci, k, buf);
-        if (e == hipSuccess) e = launch_gen_conv_fwd(st, in, buf, bias, out, n, si, ci, ldc, co, k, s, elu);
+        if (e == hipSuccess) e = launch_gen_conv_fwd(st, in, buf, bias, out, n, si, ci, ldc, co, k, s, elu, chmask);
     } else if (mode == 1) {
         if (ci != ldc) { (void)hipFree(buf); g_create_error = "iodine_op_gen_conv: mode 1 needs ldc == ci"; return IODINE_ERR_INVALID; }
         e = launch_gen_pack_weights(st, w, co, ci, k, buf);
         if (e == hipSuccess) e = launch_gen_conv_dgrad(st, in, buf, aux, out, n, si, ci, ldc, co, k, s);
     } else {
-        e = launch_gen_conv_wgrad(st, in, aux, buf + wfl, n, si, ci, ldc, ci, co, k, s, 1.f, out, gb);
+        e = launch_gen_conv_wgrad(st, in, aux, buf + wfl, n, si, ci, ldc, ci, co, k, s, 1.f, out, gb, chmask);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(buf);

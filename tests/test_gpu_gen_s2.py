@@ -116,3 +116,44 @@ def test_gen_stride2_random_shapes(ci, ldc, co, k, S, N):
     _op(2, nhwc(x.float()), None, None, nhwc(d.float()), gw, gb, N, S, ci, ldc, co, k, 2, 0)
     e_w, e_b = rel_err(gw.cpu(), wr.grad.float()), rel_err(gb.cpu(), br.grad.float())
     assert e_w < 4e-6 and e_b < 4e-6, (e_w, e_b)
+
+
+# ARCH.ENCODING subsets as internal-channel masks (code order of iodine.py:277-340: image 0-2, means 3-5, mask 6, mask_logits 7,
+# mask_posterior 8, grad_means 9-11, grad_mask 12, likelihood 13, leave-one-out 14, coordinate 15-16): configs/test.yaml keeps
+# {image, leave_one_out_likelihood}; the reference's default list drops the coordinates
+_MASKS = {'test_yaml': 0b0000100000000000111, 'no_coordinate': 0x7fff, 'only_grads': 0b0001111000000000, 'full': 0x1ffff}
+
+
+@pytest.mark.parametrize('name', sorted(_MASKS))
+@pytest.mark.parametrize('k', [3, 5])
+def test_gen_stride2_channel_mask_equals_the_plain_form(name, k):
+    """The first refinement layer of an ENCODING subset: the library skips 4- / 16-channel groups whose channels are all absent (zero
+    inputs x zero weights).  ADVICE r05: nothing compared the masked kernels with the unmasked ones - a wrong mask would silently drop real
+    channels.  Inputs and weights of absent channels are zero, as pixel_pass2 / the weight expansion leave them; forward and weight
+    gradient with the mask must be BITWISE what they are without it (skipped groups add exact zeros), and equal the fp64 conv."""
+    mask = _MASKS[name]
+    ci, ldc, co, S, N = 17, 20, 32, 32, 3
+    on = torch.tensor([(mask >> c) & 1 for c in range(ci)], dtype=torch.float32)
+    x = _rand(N, ci, S, S, seed=70) * on.view(1, ci, 1, 1)
+    w = _rand(co, ci, k, k, seed=71, scale=3.0 / (ci * k * k) ** 0.5) * on.view(1, ci, 1, 1)
+    b = _rand(co, seed=72, scale=0.5)
+    So = (S - 1) // 2 + 1
+    d = _rand(N, co, So, So, seed=73, scale=1e-2)
+    ref = nhwc(F.elu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=k // 2))).float()
+    xp = torch.zeros(N, S, S, ldc)
+    xp[..., :ci] = nhwc(x)
+    outs, grads = [], []
+    for flag in (1, 1 | 0x100 | (mask << 9)):
+        out = torch.full(ref.shape, float('nan'), device=DEV)
+        _op(0, xp, w, b, None, out, None, N, S, ci, ldc, co, k, 2, flag)
+        outs.append(out.cpu())
+        gw, gb = torch.zeros(co, ci, k, k, device=DEV), torch.zeros(co, device=DEV)
+        _op(2, xp, None, None, nhwc(d), gw, gb, N, S, ci, ldc, co, k, 2, flag & ~1)
+        grads.append((gw.cpu(), gb.cpu()))
+    assert rel_err(outs[0], ref) < 2e-6
+    assert torch.equal(outs[0], outs[1])
+    wd = torch.zeros(co, ci, k, k, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x.double(), wd, None, stride=2, padding=k // 2) * d.double()).sum().backward()
+    # the skipped groups' weight gradients are exactly zero in both forms (their inputs are zero); live channels agree bitwise
+    assert rel_err(grads[0][0], wd.grad.float()) < 2e-6
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
