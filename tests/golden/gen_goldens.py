@@ -38,6 +38,9 @@ ARCHS = {
     'tiny': dict(L=8, T=2, K=3, S=16, ref=(32, 2, 32), dec=(32, 2)),
     'dsprites': dict(L=16, S=64, ref=(32, 3, 128), dec=(32, 5)),   # configs/dsprites_noclip.yaml:26-45
     'clevr': dict(L=64, S=128, ref=(64, 4, 256), dec=(64, 4)),     # configs/clevr6_prop.yaml:26-45
+    # round 6: the two architectures of the reference whose conv stacks leave KERNEL_SIZE 3 - their own SIGMA too
+    'testyaml': dict(L=16, S=64, ref=(32, 3, 128), dec=(32, 5), sigma=0.14),    # configs/test.yaml:26-52 (KERNEL_SIZE 5 in both stacks)
+    'defaults': dict(L=128, S=32, ref=(32, 3, 256), dec=(64, 5), sigma=0.13),   # lib/config/defaults.py:35-100 (DEC.KERNEL_SIZE 5)
 }
 CASES = {
     # fixture name: (arch family, K, T, B, images)
@@ -52,14 +55,20 @@ CASES = {
     # KERNEL_SIZE 5 (the reference's default DEC.KERNEL_SIZE, lib/config/defaults.py:100; configs/test.yaml:40,44 use 5 for both
     # stacks) together with its default ENCODING: the generic fallback path of the library (round 3)
     'tiny_k5': ('tiny', 3, 2, 2, 'uniform'),
+    # round 6: configs/test.yaml verbatim (ITERS 5, SLOTS 6, four-entry ENCODING) and lib/config/defaults.py verbatim (ITERS 5, SLOTS 7,
+    # ENCODING without 'coordinate'), batch 1: summaries of both precisions + every gradient tensor of the fp64 run in full
+    'testyaml_k6_t5_b1': ('testyaml', 6, 5, 1, 'blobs'),
+    'defaults_k7_t5_b1': ('defaults', 7, 5, 1, 'blobs'),
 }
+FULL_GRADS = ('testyaml_k6_t5_b1', 'defaults_k7_t5_b1')       # cases that also keep 'f64.train.gradfull.<name>' (float32 storage)
 # Round 4 (VERDICT r03, next #3c): FULL gradient tensors of the headline-architecture cases, so that reference <-> oracle <-> HIP are
 # compared element by element there too (the base fixtures keep sum / sumsq / 16 samples per tensor).  Own files: the base fixtures
 # stay byte-identical.  Values: the reference's fp64 run, stored as float32 (rounding 6e-8, the gate is 1e-3).
 GRAD_CASES = {'cfg3_clevr_k7_t5_b1_grads': 'cfg3_clevr_k7_t5_b1', 'cfg5_clevr_k11_t7_b1_grads': 'cfg5_clevr_k11_t7_b1'}
-CASE_KERNEL = {'tiny_k5': (5, 5)}          # (REF.KERNEL_SIZE, DEC.KERNEL_SIZE)
+CASE_KERNEL = {'tiny_k5': (5, 5), 'testyaml_k6_t5_b1': (5, 5), 'defaults_k7_t5_b1': (3, 5)}          # (REF.KERNEL_SIZE, DEC.KERNEL_SIZE)
 # encoding list per case (default: the full 12-entry list of the shipped IODINE configs)
-CASE_ENCODING = {c: [e for e in ENCODING if e != 'coordinate'] for c in ('tiny_default_enc', 'cfg1_default_enc', 'tiny_k5')}
+CASE_ENCODING = {c: [e for e in ENCODING if e != 'coordinate'] for c in ('tiny_default_enc', 'cfg1_default_enc', 'tiny_k5', 'defaults_k7_t5_b1')}
+CASE_ENCODING['testyaml_k6_t5_b1'] = ['posterior', 'grad_post', 'image', 'leave_one_out_likelihood']      # configs/test.yaml:30-35
 DEC_GAIN = 3.0
 POST_SCALE = 0.1
 SEED_W, SEED_X, SEED_E = 0, 0, 1
@@ -69,7 +78,7 @@ def make_arch_ns(fam, K, T, encoding=None, kernels=(3, 3)):
     f = ARCHS[fam]
     return SimpleNamespace(
         DIM_LATENT=f['L'], ITERS=T, SLOTS=K, ENCODING=list(encoding or ENCODING), IMG_CHANNELS=3,
-        IMG_SIZE=f['S'], SIGMA=0.10, LAYERNORM=True, STOP_GRADIENT=False,
+        IMG_SIZE=f['S'], SIGMA=f.get('sigma', 0.10), LAYERNORM=True, STOP_GRADIENT=False,
         REF=SimpleNamespace(CONV_CHAN=f['ref'][0], CONV_LAYERS=f['ref'][1], MLP_UNITS=f['ref'][2],
                             KERNEL_SIZE=kernels[0], STRIDE=2),
         DEC=SimpleNamespace(CONV_CHAN=f['dec'][0], CONV_LAYERS=f['dec'][1], KERNEL_SIZE=kernels[1]))
@@ -127,6 +136,8 @@ def run_case(case):
         out['meta_encoding'] = ','.join(CASE_ENCODING[case])
     if case in CASE_KERNEL:
         out['meta_kernels'] = np.array(CASE_KERNEL[case])
+    if 'sigma' in ARCHS[fam]:
+        out['meta_sigma'] = np.float64(ARCHS[fam]['sigma'])
     for tag, dtype in (('f32', torch.float32), ('f64', torch.float64)):
         model, shapes = build_reference(fam, K, T, dtype, CASE_ENCODING.get(case), CASE_KERNEL.get(case, (3, 3)))
         x = torch.from_numpy(imgs).to(dtype)
@@ -161,6 +172,8 @@ def run_case(case):
                 out[f'{tag}.train.grad.{n}'] = g.detach().double().numpy().copy()
             else:
                 summarize(f'{tag}.train.grad.{n}', g, out)
+                if case in FULL_GRADS and tag == 'f64':
+                    out[f'f64.train.gradfull.{n}'] = g.detach().double().numpy().astype(np.float32)
         print(f'  [{case}/{tag}] train loss {loss.item():.6f}  ({dt:.1f}s)')
 
         # ---- inference step: IODINE.reconstruct (iodine.py:107-112) ----

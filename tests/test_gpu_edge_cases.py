@@ -225,6 +225,36 @@ def test_reference_test_yaml_arch():
     assert m.get_input_size() == (4, 64) and tuple(m.refine.mlc.layers[0].weight.shape) == (32, 4, 5, 5)
 
 
+@pytest.mark.parametrize('prec', [1, 0], ids=['default_precision', 'exact_fp32'])
+@pytest.mark.parametrize('case', ['testyaml_k6_t5_b1', 'defaults_k7_t5_b1'])
+def test_reference_generic_architectures_against_reference_goldens(case, prec):
+    """Round 6: the generic kernels (kernels_generic.hip / kernels_genl0.hip / kernels_gens2.hip) at the REAL shapes of
+    the two reference architectures that need them, against fixtures written by the UNMODIFIED reference (gen_goldens.py: configs/test.yaml:26-52
+    and lib/config/defaults.py:35-100 verbatim, batch 1) - loss, ELBO trajectory, every gradient tensor element-wise against the fp64 run,
+    reconstruct summaries and the arg-max masks; both precisions (the defaults architecture keeps the tuned split-fp16 refinement kernels
+    beside its 5 x 5 decoder at conv_precision 1; the generic kernels themselves are exact fp32 either way)."""
+    g = load_golden(case)
+    arch, params, x, eps, _ = golden_setup(g)
+    m = make_hip_model(arch, params, options={'conv_precision': prec})
+    xd, ed = x.to(DEV), eps.to(DEV)
+    m.zero_grad(set_to_none=True)
+    loss = m(xd, ed)
+    loss.backward()
+    assert abs(loss.item() - float(g['f64.train.loss'])) <= 1e-4 * abs(float(g['f64.train.loss']))
+    assert rel_err(m.elbo_terms[:, 0].cpu(), g['f64.train.elbos']) < 1e-4
+    worst = max((rel_l2(*grad_views(n, p.grad.cpu().numpy(), g['f64.train.gradfull.' + n])), n) for n, p in m.named_parameters())
+    print(f'[{case}, conv_precision {prec}] HIP vs reference fp64, element-wise: worst tensor {worst[1]} {worst[0]:.2e}')
+    assert worst[0] <= 1e-3, worst
+    pred, mask, mean = m.reconstruct(xd, ed)
+    assert rel_err(m.elbo_terms[:, 0].cpu(), g['f32.recon.elbos']) < 1e-4
+    for nm, t in (('pred', pred), ('mask', mask), ('mean', mean)):
+        a = t.double().cpu().flatten()
+        ss = float((a * a).sum())
+        assert abs(ss - float(g[f'f32.recon.{nm}.sumsq'])) <= 2e-4 * float(g[f'f32.recon.{nm}.sumsq']), nm
+    amax = mask[:, :, 0].argmax(dim=1).cpu().numpy()
+    assert (amax == g['f32.recon.argmax']).mean() >= 0.999
+
+
 def test_reference_default_arch():
     """lib/config/defaults.py:35-100 verbatim - ITERS 5, SLOTS 7, SIGMA 0.13, DIM_LATENT 128, IMG_SIZE 32, REF 32 x 3 (k 3, stride 2),
     MLP 256, DEC 64 x 5 with KERNEL_SIZE 5, ENCODING without 'coordinate': the configuration a user of the reference gets without a

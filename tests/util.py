@@ -13,6 +13,9 @@ FAMILIES = {
     'tiny': lambda K, T: O.tiny_arch(slots=K, iters=T),
     'dsprites': lambda K, T: O.dsprites_arch(slots=K, iters=T),
     'clevr': lambda K, T: O.clevr_arch(slots=K, iters=T),
+    # configs/test.yaml:26-52 and lib/config/defaults.py:35-100 (kernel sizes / ENCODING / SIGMA come from the fixture's meta entries)
+    'testyaml': lambda K, T: O.Arch(dim_latent=16, iters=T, slots=K, img_size=64, ref_chan=32, ref_layers=3, ref_mlp=128, dec_chan=32, dec_layers=5),
+    'defaults': lambda K, T: O.Arch(dim_latent=128, iters=T, slots=K, img_size=32, ref_chan=32, ref_layers=3, ref_mlp=256, dec_chan=64, dec_layers=5),
 }
 
 
@@ -30,6 +33,8 @@ def golden_setup(g, dtype=torch.float32):
         arch.encoding = tuple(str(g['meta_encoding']).split(','))
     if 'meta_kernels' in g.files:                       # (REF.KERNEL_SIZE, DEC.KERNEL_SIZE) other than 3
         arch.ref_kernel, arch.dec_kernel = (int(v) for v in g['meta_kernels'])
+    if 'meta_sigma' in g.files:
+        arch.sigma = float(g['meta_sigma'])
     assert arch.img_size == S and arch.dim_latent == L
     shapes = O.param_shapes(arch)
     pn = synth.make_params(shapes, seed=sw, dec_gain=float(g['meta_dec_gain']),
