@@ -53,7 +53,7 @@ extern "C" {
 
 /* Mirror of the ARCH.* node read by IODINE.__init__ (iodine.py:8-32; defaults lib/config/defaults.py:35-100). */
 typedef struct iodine_config {
-    int dim_latent;        /* ARCH.DIM_LATENT  */
+    int dim_latent;        /* ARCH.DIM_LATENT  (2..256; widths that are not multiples of 4 run zero-padded inside, same shapes at this boundary) */
     int iters;             /* ARCH.ITERS       */
     int slots;             /* ARCH.SLOTS       */
     int img_size;          /* ARCH.IMG_SIZE    (multiples of 16: tuned kernels; other sizes >= 8: generic fallback path) */
@@ -64,7 +64,7 @@ typedef struct iodine_config {
     unsigned encoding;     /* ARCH.ENCODING as IODINE_ENC_* bits (see above for what is accepted) */
     int ref_conv_chan;     /* ARCH.REF.CONV_CHAN   (32 or 64: tuned kernels; other divisors of 256: generic fallback path) */
     int ref_conv_layers;   /* ARCH.REF.CONV_LAYERS */
-    int ref_mlp_units;     /* ARCH.REF.MLP_UNITS   */
+    int ref_mlp_units;     /* ARCH.REF.MLP_UNITS   (1..1024; not a multiple of 4: zero-padded inside, iodine_debug_copy then shows the padded widths) */
     int ref_kernel_size;   /* ARCH.REF.KERNEL_SIZE (3: tuned kernels; 5, 7: generic fallback path, kernels_generic.hip) */
     int ref_stride;        /* ARCH.REF.STRIDE      (2) */
     int dec_conv_chan;     /* ARCH.DEC.CONV_CHAN   (32 or 64: tuned kernels; other multiples of 4 in 8..256: generic path) */

@@ -217,7 +217,7 @@ hipError_t launch_l0_coord_grads_rows(hipStream_t st, const float* Rsum, const f
 hipError_t launch_l0_reduce(hipStream_t st, const float* dpre, float* rows, float* Rc, int N, int S, int C, float* Dpart,
                             float* Dacc, float alpha, int first);
 hipError_t launch_dz_latent(hipStream_t st, const float* Rc, const float* wclsT, const float* pm, const float* plv,
-                            const float* eps, int N, int L, int C, int use_ln, float* g_pm, float* g_plv, float* latent);
+                            const float* eps, int N, int L, int C, int use_ln, float* g_pm, float* g_plv, float* latent, int Lreal = 0);
 hipError_t launch_elbo(hipStream_t st, const float* pm, const float* plv, const float* ll_img, int B, int K, int L,
                        float* img_terms, float* scal);
 hipError_t launch_refine_head(hipStream_t st, const float* feat, int N, int PL, int C, int H, int L,
@@ -302,6 +302,10 @@ hipError_t launch_pack_conv_weights_ws(hipStream_t st, const float* src, int C, 
 constexpr int PACK_BATCH_MAX = 48;
 struct PackJob { const float* src; void* dst; float* meta; int kind; int p[5]; };
 hipError_t launch_pack_batch(hipStream_t st, const PackJob* jobs, int n);
+// round 6: tensors between the reference's shapes and the padded shapes of the inner handle (DIM_LATENT / MLP_UNITS not multiples of 4)
+hipError_t launch_pad_gather(hipStream_t st, const float* src, const int* map, float* dst, int n);
+hipError_t launch_pad_scatter(hipStream_t st, const float* src, const int* map, float* dst, int n, int accumulate);
+hipError_t launch_resize_rows(hipStream_t st, const float* src, float* dst, long long rows, int w_src, int w_dst);
 hipError_t launch_cell_max(hipStream_t st, const float* x, float* tmax, int N, int S, int C);
 hipError_t launch_conv3x3_ws_f16x3(hipStream_t st, const float* in, const void* wpk, const float* wmeta, const float* bias,
                                    const float* aux, float* out, const float* tmax_in, float* tmax_out, int N, int S, int c,

@@ -160,6 +160,11 @@ struct iodine_handle {
     unsigned long long graph_clock = 0;
     long long graph_replays = 0, graph_captures = 0;
     std::vector<void*> owned;
+    // round 6: DIM_LATENT / REF.MLP_UNITS that are not multiples of 4.  Lreal: the reference's DIM_LATENT when this handle runs at a padded
+    // latent width (the 3-D layer-norm and the logger means are taken over the real entries); shim: this handle is only the boundary of a
+    // padded INNER handle (see PadShim below)
+    int Lreal = 0;
+    struct PadShim* shim = nullptr;
 
     // workspace
     void* ws_user = nullptr; size_t ws_user_bytes = 0;
@@ -308,9 +313,10 @@ std::string validate(const iodine_config& c)
     if (c.ref_conv_layers < 1 || (c.img_size >> c.ref_conv_layers) < 1) return "REF.CONV_LAYERS out of range for IMG_SIZE";
     if (c.slots < 1 || c.slots > 12) return "ARCH.SLOTS must be in 1..12";
     if (c.iters < 1) return "ARCH.ITERS must be >= 1";
-    // (the refinement head reads its weight rows as 16-byte vectors: refine_head_kernel / head_bptt_kernel)
-    if (c.dim_latent < 4 || c.dim_latent > 256 || c.dim_latent % 4 != 0) return "ARCH.DIM_LATENT must be a multiple of 4 in 4..256";
-    if (c.ref_mlp_units < 4 || c.ref_mlp_units > 1024 || c.ref_mlp_units % 4 != 0) return "REF.MLP_UNITS must be a multiple of 4 in 4..1024";
+    // (the refinement head reads its weight rows as 16-byte vectors: widths that are not multiples of 4 run on a zero-padded inner handle,
+    // PadShim - round 6)
+    if (c.dim_latent < 2 || c.dim_latent > 256) return "ARCH.DIM_LATENT must be in 2..256";
+    if (c.ref_mlp_units < 1 || c.ref_mlp_units > 1024) return "REF.MLP_UNITS must be in 1..1024";
     if (!(c.sigma > 0)) { snprintf(m, sizeof m, "ARCH.SIGMA must be > 0 (got %g)", c.sigma); return m; }
     return "";
 }
@@ -738,7 +744,7 @@ int elbo_and_gradients(iodine_handle* h, hipStream_t st, int B, const float* eps
     rc = decoder_backward_data(h, st, N, &dpre0, train_alpha, i);
     if (rc) return rc;
     HIPCHK(h, launch_dz_latent(st, b.Rc, h->generic ? h->gen_ident : h->wclsT, b.pm, b.plv, eps_i, N, h->L, h->Cd, h->cfg.layernorm,
-                               b.g_pm[i], b.g_plv[i], b.latent[i]));
+                               b.g_pm[i], b.g_plv[i], b.latent[i], h->Lreal));
     return IODINE_OK;
 }
 
@@ -874,6 +880,124 @@ std::vector<uintptr_t> graph_key(const iodine_handle* h, int entry, int batch, s
     return k;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 6 - DIM_LATENT / REF.MLP_UNITS that are not multiples of 4 (the reference takes any: iodine.py:8-32, 446-464).
+// The refinement-head kernels move weight rows as 16-byte vectors, so such a model runs on an INNER handle created at Lp = ceil4(L),
+// Hp = ceil4(H) with every parameter zero-padded into the wider shapes.  Padding is exact, not approximate:
+//   * padded latent entries have init_mean = init_logvar = 0, their decoder-input weights and the rows of mean_update / logvar_update
+//     that produce them are 0, eps is padded with 0: z = mu = 0, logvar = 0 for the whole loop, KL contribution 1/2 (0 + 1 - 0 - 1) = 0,
+//     d ELBO / d lambda = 0, and the LSTM reads them through zero columns of weight_ih;
+//   * padded hidden units: zero MLP row and bias -> u = ELU(ELU(0)) = 0; zero gate rows and biases -> i = f = o = 1/2, g = 0 -> c1 = h1 = 0
+//     from c0 = h0 = 0; the read-out and weight_hh see them through zero columns;
+//   * the one place where the WIDTH itself enters the arithmetic - the layer-norm of the lambda gradients over the latent axis
+//     (iodine.py:263-272, 376-384: mean and unbiased std over L) - runs over the real L (inner->Lreal, dz_latent_kernel), and so does the
+//     logger's mean of init_mean / init_logvar.
+// The outer handle owns the reference-shaped boundary: parameter table, padded copies of the parameters, the element maps, scratch for the
+// tensors with a latent axis (eps, z, posterior), and the gradient in padded shape; every entry point forwards to the inner handle.
+}  // namespace
+struct PadShim {
+    iodine_handle* inner = nullptr;
+    int L = 0, H = 0, Lp = 0, Hp = 0;
+    std::vector<float*> pparam;            // padded parameter copies [param]
+    std::vector<int*> pmap;                // [param][padded element] -> element of the reference-shaped tensor, or -1 (zero)
+    std::vector<int> pnumel;               // padded element counts
+    float* pgrad = nullptr;                // flat gradient in padded shapes (the inner handle's named_parameters() order)
+    std::vector<size_t> poff;
+    size_t pgrad_total = 0;
+    // scratch for one call's tensors with a latent axis: grown on demand (outside the refinement loop)
+    size_t cap = 0;                        // floats per buffer
+    float *eps = nullptr, *z = nullptr, *pm = nullptr, *plv = nullptr, *pm_in = nullptr, *plv_in = nullptr;
+    std::vector<void*> owned;
+};
+namespace {
+
+int shim_fail(iodine_handle* h, int rc)
+{
+    if (rc && h->shim && h->shim->inner) h->err = h->shim->inner->err.empty() ? std::string(iodine_last_error(nullptr)) : h->shim->inner->err;
+    return rc;
+}
+
+// per-dimension index map of a concatenation of segments (real length -> padded length): padded index -> real index or -1
+std::vector<int> seg_map(std::initializer_list<std::pair<int, int>> segs)
+{
+    std::vector<int> m;
+    int real0 = 0;
+    for (const auto& sg : segs) {
+        for (int i = 0; i < sg.second; ++i) m.push_back(i < sg.first ? real0 + i : -1);
+        real0 += sg.first;
+    }
+    return m;
+}
+
+int shim_build(iodine_handle* h)
+{
+    PadShim* sh = h->shim;
+    const int L = sh->L, H = sh->H, Lp = sh->Lp, Hp = sh->Hp;
+    iodine_handle* in = sh->inner;
+    const size_t np = h->params.size();
+    if (in->params.size() != np) return h->fail(IODINE_ERR_INVALID, "padded inner handle: parameter tables differ");
+    sh->pparam.assign(np, nullptr); sh->pmap.assign(np, nullptr); sh->pnumel.assign(np, 0); sh->poff.assign(np, 0);
+    auto ident = [](int n) { std::vector<int> m(n); for (int i = 0; i < n; ++i) m[i] = i; return m; };
+    const std::vector<int> mH = seg_map({{H, Hp}}), mL = seg_map({{L, Lp}}), m4H = seg_map({{H, Hp}, {H, Hp}, {H, Hp}, {H, Hp}}),
+                           mIN = seg_map({{H, Hp}, {L, Lp}, {L, Lp}, {L, Lp}, {L, Lp}}), mL2 = seg_map({{L, Lp}, {2, 2}});
+    size_t off = 0;
+    for (size_t i = 0; i < np; ++i) {
+        const ParamInfo &pr = h->params[i], &pp = in->params[i];
+        if (pr.name != pp.name || pr.ndim != pp.ndim) return h->fail(IODINE_ERR_INVALID, "padded inner handle: parameter " + pr.name + " differs");
+        std::vector<int> dm[4];
+        for (int d = 0; d < 4; ++d) dm[d] = ident((int)pp.dims[d]);
+        const std::string& n = pr.name;
+        if (n == "refine.mlp.layers.0.weight" || n == "refine.mlp.layers.0.bias") dm[0] = mH;
+        else if (n == "refine.lstm.weight_ih") { dm[0] = m4H; dm[1] = mIN; }
+        else if (n == "refine.lstm.weight_hh") { dm[0] = m4H; dm[1] = mH; }
+        else if (n == "refine.lstm.bias_ih" || n == "refine.lstm.bias_hh") dm[0] = m4H;
+        else if (n == "refine.mean_update.weight" || n == "refine.logvar_update.weight") { dm[0] = mL; dm[1] = mH; }
+        else if (n == "refine.mean_update.bias" || n == "refine.logvar_update.bias" || n == "posterior.init_mean" || n == "posterior.init_logvar") dm[0] = mL;
+        else if (n == "decoder.mlc.layers.0.weight") dm[1] = mL2;          // [Cd][L latent channels | x, y][k][k]
+        for (int d = 0; d < 4; ++d)
+            if ((long long)dm[d].size() != pp.dims[d]) return h->fail(IODINE_ERR_INVALID, "padded inner handle: shape of " + n);
+        const size_t numel = pp.numel();
+        std::vector<int> map(numel);
+        size_t e = 0;
+        for (int a = 0; a < (int)pp.dims[0]; ++a)
+            for (int b2 = 0; b2 < (int)pp.dims[1]; ++b2)
+                for (int c = 0; c < (int)pp.dims[2]; ++c)
+                    for (int d = 0; d < (int)pp.dims[3]; ++d, ++e) {
+                        const int ia = dm[0][a], ib = dm[1][b2], ic = dm[2][c], id = dm[3][d];
+                        map[e] = (ia < 0 || ib < 0 || ic < 0 || id < 0) ? -1
+                                 : (int)((((size_t)ia * pr.dims[1] + ib) * pr.dims[2] + ic) * pr.dims[3] + id);
+                    }
+        void *dmap = nullptr, *dpar = nullptr;
+        HIPCHK(h, hipMalloc(&dmap, numel * sizeof(int))); sh->owned.push_back(dmap);
+        HIPCHK(h, hipMemcpy(dmap, map.data(), numel * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMalloc(&dpar, numel * sizeof(float))); sh->owned.push_back(dpar);
+        sh->pmap[i] = (int*)dmap; sh->pparam[i] = (float*)dpar; sh->pnumel[i] = (int)numel; sh->poff[i] = off;
+        off += numel;
+    }
+    sh->pgrad_total = off;
+    void* g = nullptr;
+    HIPCHK(h, hipMalloc(&g, off * sizeof(float))); sh->owned.push_back(g);
+    sh->pgrad = (float*)g;
+    return IODINE_OK;
+}
+
+// scratch for (rows x Lp) tensors of a call; rows_eps = (T + 1) * N for the noise, N for the others
+int shim_scratch(iodine_handle* h, size_t floats)
+{
+    PadShim* sh = h->shim;
+    if (floats <= sh->cap) return IODINE_OK;
+    float** bufs[6] = {&sh->eps, &sh->z, &sh->pm, &sh->plv, &sh->pm_in, &sh->plv_in};
+    for (float** b : bufs) {
+        if (*b) { HIPCHK(h, hipDeviceSynchronize()); HIPCHK(h, hipFree(*b)); *b = nullptr; }
+        void* q = nullptr;
+        HIPCHK(h, hipMalloc(&q, floats * sizeof(float)));
+        *b = (float*)q;
+    }
+    sh->cap = floats;
+    return IODINE_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -890,6 +1014,30 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     if (!why.empty()) { g_create_error = why; return IODINE_ERR_INVALID; }
     iodine_handle* h = new iodine_handle();
     h->cfg = *cfg;
+    if (cfg->dim_latent % 4 != 0 || cfg->ref_mlp_units % 4 != 0) {
+        // boundary handle of a zero-padded inner handle (PadShim above): owns the reference-shaped parameter table and the maps only
+        h->L = cfg->dim_latent; h->T = cfg->iters; h->K = cfg->slots; h->S = cfg->img_size; h->P = h->S * h->S; h->H = cfg->ref_mlp_units;
+        h->Cd = cfg->dec_conv_chan; h->Dd = cfg->dec_conv_layers; h->Cr = cfg->ref_conv_chan; h->Dr = cfg->ref_conv_layers;
+        h->kd = cfg->dec_kernel_size; h->kr = cfg->ref_kernel_size;
+        h->n_in = 0;
+        for (unsigned bit = 0; bit < 12; ++bit) {
+            static const int cnt[12] = {0, 0, 3, 3, 1, 1, 1, 3, 1, 1, 1, 2};      // channels per ENCODING entry, order of the IODINE_ENC_* bits
+            if (cfg->encoding & (1u << bit)) h->n_in += cnt[bit];
+        }
+        build_param_table(h);
+        h->shim = new PadShim();
+        h->shim->L = cfg->dim_latent; h->shim->H = cfg->ref_mlp_units;
+        h->shim->Lp = (cfg->dim_latent + 3) / 4 * 4; h->shim->Hp = (cfg->ref_mlp_units + 3) / 4 * 4;
+        iodine_config pc = *cfg;
+        pc.dim_latent = h->shim->Lp; pc.ref_mlp_units = h->shim->Hp;
+        const int rc = iodine_create(&pc, &h->shim->inner);
+        if (rc) { iodine_destroy(h); return rc; }                           // (g_create_error holds the inner message)
+        h->shim->inner->Lreal = cfg->dim_latent;
+        const int rb = shim_build(h);
+        if (rb) { g_create_error = h->err; iodine_destroy(h); return rb; }
+        *out = h;
+        return IODINE_OK;
+    }
     h->L = cfg->dim_latent; h->T = cfg->iters; h->K = cfg->slots; h->S = cfg->img_size; h->P = h->S * h->S;
     h->Cd = cfg->dec_conv_chan; h->Dd = cfg->dec_conv_layers; h->Cr = cfg->ref_conv_chan; h->Dr = cfg->ref_conv_layers;
     h->H = cfg->ref_mlp_units;
@@ -1017,6 +1165,13 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
 void iodine_destroy(iodine_handle* h)
 {
     if (!h) return;
+    if (h->shim) {
+        if (h->shim->inner) iodine_destroy(h->shim->inner);
+        for (void* p : h->shim->owned) (void)hipFree(p);
+        for (float* p : {h->shim->eps, h->shim->z, h->shim->pm, h->shim->plv, h->shim->pm_in, h->shim->plv_in}) if (p) (void)hipFree(p);
+        delete h->shim;
+        h->shim = nullptr;
+    }
     for (void* p : h->owned) (void)hipFree(p);
     for (auto& c : h->prof) for (auto& e : c.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->ws_own) (void)hipFree(h->ws_own);
@@ -1043,6 +1198,11 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
     for (int i = 0; i < n; ++i)
         if (!dev[i]) return h->fail(IODINE_ERR_INVALID, "iodine_set_params: null pointer for " + h->params[i].name);
     hipStream_t st = (hipStream_t)stream;
+    if (h->shim) {                                             // reference shapes -> zero-padded copies -> the inner handle
+        PadShim* sh = h->shim;
+        for (int i = 0; i < n; ++i) HIPCHK(h, launch_pad_gather(st, dev[i], sh->pmap[i], sh->pparam[i], sh->pnumel[i]));
+        return shim_fail(h, iodine_set_params(sh->inner, stream, sh->pparam.data(), n));
+    }
     auto P = [&](const std::string& name) { return dev[param_index(h, name)]; };
     // plain copies (biases, raw weights of the head backward) are collected and issued as one launch
     MultiCopy mc;
@@ -1220,6 +1380,7 @@ int iodine_set_params(iodine_handle* h, void* stream, const float* const* dev, i
 size_t iodine_workspace_bytes(const iodine_handle* h, int batch, int mode)
 {
     if (!h || batch < 1) return 0;
+    if (h->shim) return iodine_workspace_bytes(h->shim->inner, batch, mode);
     Arena q(nullptr); Buffers tmp; plan(h, batch, mode, q, tmp);
     return tmp.bytes;
 }
@@ -1228,6 +1389,7 @@ int iodine_set_workspace(iodine_handle* h, void* dev_ptr, size_t bytes)
 {
     if (!h) return IODINE_ERR_INVALID;
     if (((uintptr_t)dev_ptr & 255) != 0) return h->fail(IODINE_ERR_INVALID, "workspace must be 256-byte aligned");
+    if (h->shim) return shim_fail(h, iodine_set_workspace(h->shim->inner, dev_ptr, bytes));
     h->ws_user = dev_ptr; h->ws_user_bytes = dev_ptr ? bytes : 0;
     h->buf = Buffers();
     h->fwd_done = false;
@@ -1238,6 +1400,7 @@ int iodine_set_workspace(iodine_handle* h, void* dev_ptr, size_t bytes)
 int iodine_set_option(iodine_handle* h, const char* key, double value)
 {
     if (!h || !key) return IODINE_ERR_INVALID;
+    if (h->shim) return shim_fail(h, iodine_set_option(h->shim->inner, key, value));
     if (!strcmp(key, "stop_after_iters")) { h->stop_after = (int)value; return IODINE_OK; }
     if (!strcmp(key, "profile")) { h->profile = (int)value; return IODINE_OK; }
     if (!strcmp(key, "graph")) { h->graph = value != 0; if (!h->graph) drop_graphs(h); return IODINE_OK; }
@@ -1279,6 +1442,21 @@ int iodine_set_option(iodine_handle* h, const char* key, double value)
 int iodine_reconstruct(iodine_handle* h, void* stream, int batch, const float* x, const float* eps, float* pred,
                        float* mask, float* mean, float* z, float* post_mean, float* post_logvar, float* elbo_iter)
 {
+    if (h && h->shim) {
+        PadShim* sh = h->shim;
+        if (batch < 1 || !x || !eps) return h->fail(IODINE_ERR_INVALID, "iodine_reconstruct: batch >= 1, x and eps are required");
+        hipStream_t st = (hipStream_t)stream;
+        const long long N = (long long)batch * h->K, R = (long long)(h->T + 1) * N;
+        if (int r = shim_scratch(h, (size_t)R * sh->Lp)) return r;
+        HIPCHK(h, launch_resize_rows(st, eps, sh->eps, R, sh->L, sh->Lp));
+        const int rc = iodine_reconstruct(sh->inner, stream, batch, x, sh->eps, pred, mask, mean, z ? sh->z : nullptr, post_mean ? sh->pm : nullptr,
+                                          post_logvar ? sh->plv : nullptr, elbo_iter);
+        if (rc) return shim_fail(h, rc);
+        if (z) HIPCHK(h, launch_resize_rows(st, sh->z, z, N, sh->Lp, sh->L));
+        if (post_mean) HIPCHK(h, launch_resize_rows(st, sh->pm, post_mean, N, sh->Lp, sh->L));
+        if (post_logvar) HIPCHK(h, launch_resize_rows(st, sh->plv, post_logvar, N, sh->Lp, sh->L));
+        return IODINE_OK;
+    }
     int rc = check_ready(h, batch);
     if (rc) return rc;
     if (!x || !eps) return h->fail(IODINE_ERR_INVALID, "iodine_reconstruct: x and eps are required");
@@ -1326,6 +1504,14 @@ int iodine_reconstruct(iodine_handle* h, void* stream, int batch, const float* x
 
 int iodine_decode(iodine_handle* h, void* stream, int batch, const float* z, float* pred, float* mask, float* mean)
 {
+    if (h && h->shim) {
+        PadShim* sh = h->shim;
+        if (batch < 1 || !z) return h->fail(IODINE_ERR_INVALID, "iodine_decode: batch >= 1 and z are required");
+        const long long N = (long long)batch * h->K;
+        if (int r = shim_scratch(h, (size_t)N * sh->Lp)) return r;
+        HIPCHK(h, launch_resize_rows((hipStream_t)stream, z, sh->z, N, sh->L, sh->Lp));
+        return shim_fail(h, iodine_decode(sh->inner, stream, batch, sh->z, pred, mask, mean));
+    }
     int rc = check_ready(h, batch);
     if (rc) return rc;
     if (!z) return h->fail(IODINE_ERR_INVALID, "iodine_decode: z is required");
@@ -1348,6 +1534,21 @@ int iodine_decode(iodine_handle* h, void* stream, int batch, const float* z, flo
 int iodine_elbo(iodine_handle* h, void* stream, int batch, const float* x, const float* post_mean, const float* post_logvar,
                 const float* eps, float* terms)
 {
+    if (h && h->shim) {
+        PadShim* sh = h->shim;
+        if (batch < 1 || !x || !eps) return h->fail(IODINE_ERR_INVALID, "iodine_elbo: batch >= 1, x and eps are required");
+        if ((post_mean == nullptr) != (post_logvar == nullptr))
+            return h->fail(IODINE_ERR_INVALID, "iodine_elbo: pass both post_mean and post_logvar, or neither");
+        hipStream_t st = (hipStream_t)stream;
+        const long long N = (long long)batch * h->K;
+        if (int r = shim_scratch(h, (size_t)N * sh->Lp)) return r;
+        HIPCHK(h, launch_resize_rows(st, eps, sh->eps, N, sh->L, sh->Lp));
+        if (post_mean) {
+            HIPCHK(h, launch_resize_rows(st, post_mean, sh->pm_in, N, sh->L, sh->Lp));
+            HIPCHK(h, launch_resize_rows(st, post_logvar, sh->plv_in, N, sh->L, sh->Lp));
+        }
+        return shim_fail(h, iodine_elbo(sh->inner, stream, batch, x, post_mean ? sh->pm_in : nullptr, post_mean ? sh->plv_in : nullptr, sh->eps, terms));
+    }
     int rc = check_ready(h, batch);
     if (rc) return rc;
     if (!x || !eps) return h->fail(IODINE_ERR_INVALID, "iodine_elbo: x and eps are required");
@@ -1383,6 +1584,15 @@ int iodine_last_elbo_outputs(iodine_handle* h, void* stream, int count, float* z
                              float* mask_logits, float* pred)
 {
     if (!h) return IODINE_ERR_INVALID;
+    if (h->shim) {
+        PadShim* sh = h->shim;
+        const long long N = (long long)std::max(count, 0) * h->K;
+        if (z) if (int r = shim_scratch(h, (size_t)N * sh->Lp)) return r;
+        const int rc = iodine_last_elbo_outputs(sh->inner, stream, count, z ? sh->z : nullptr, mean, mask, mask_logits, pred);
+        if (rc) return shim_fail(h, rc);
+        if (z) HIPCHK(h, launch_resize_rows((hipStream_t)stream, sh->z, z, N, sh->Lp, sh->L));
+        return IODINE_OK;
+    }
     if (h->last_elbo_iter < 0 || h->buf.bytes == 0)
         return h->fail(IODINE_ERR_STATE, "iodine_last_elbo_outputs: no elbo() has run on the current workspace");
     if (count < 1 || count > h->last_elbo_batch)
@@ -1400,6 +1610,16 @@ int iodine_last_elbo_outputs(iodine_handle* h, void* stream, int count, float* z
 int iodine_last_posterior(iodine_handle* h, void* stream, int count, float* post_mean, float* post_logvar)
 {
     if (!h) return IODINE_ERR_INVALID;
+    if (h->shim) {
+        PadShim* sh = h->shim;
+        const long long N = (long long)std::max(count, 0) * h->K;
+        if (int r = shim_scratch(h, (size_t)N * sh->Lp)) return r;
+        const int rc = iodine_last_posterior(sh->inner, stream, count, post_mean ? sh->pm : nullptr, post_logvar ? sh->plv : nullptr);
+        if (rc) return shim_fail(h, rc);
+        if (post_mean) HIPCHK(h, launch_resize_rows((hipStream_t)stream, sh->pm, post_mean, N, sh->Lp, sh->L));
+        if (post_logvar) HIPCHK(h, launch_resize_rows((hipStream_t)stream, sh->plv, post_logvar, N, sh->Lp, sh->L));
+        return IODINE_OK;
+    }
     if (h->last_elbo_iter < 0 || h->buf.bytes == 0)
         return h->fail(IODINE_ERR_STATE, "iodine_last_posterior: no refinement has run on the current workspace");
     if (count < 1 || count > h->last_elbo_batch)
@@ -1414,6 +1634,14 @@ int iodine_last_posterior(iodine_handle* h, void* stream, int count, float* post
 int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float* x, const float* eps, float* loss,
                          float* elbo_iter)
 {
+    if (h && h->shim) {
+        PadShim* sh = h->shim;
+        if (batch < 1 || !x || !eps || !loss) return h->fail(IODINE_ERR_INVALID, "iodine_train_forward: batch >= 1, x, eps and loss are required");
+        const long long R = (long long)(h->T + 1) * batch * h->K;
+        if (int r = shim_scratch(h, (size_t)R * sh->Lp)) return r;
+        HIPCHK(h, launch_resize_rows((hipStream_t)stream, eps, sh->eps, R, sh->L, sh->Lp));
+        return shim_fail(h, iodine_train_forward(sh->inner, stream, batch, x, sh->eps, loss, elbo_iter));
+    }
     int rc = check_ready(h, batch);
     if (rc) return rc;
     if (!x || !eps || !loss) return h->fail(IODINE_ERR_INVALID, "iodine_train_forward: x, eps and loss are required");
@@ -1466,6 +1694,18 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
                                float* const* param_grads, int n, int accumulate)
 {
     if (!h) return IODINE_ERR_INVALID;
+    if (h->shim) {
+        // the inner handle writes its (scaled) gradient in padded shapes; the real entries are scattered (or added) into the caller's tensors
+        PadShim* sh = h->shim;
+        if (n != (int)h->params.size() || !param_grads) return h->fail(IODINE_ERR_INVALID, "iodine_train_backward: wrong parameter count");
+        std::vector<float*> ptrs(h->params.size());
+        for (size_t p = 0; p < ptrs.size(); ++p) ptrs[p] = sh->pgrad + sh->poff[p];
+        const int rc = train_backward_impl(sh->inner, stream, grad_scale, grad_scale_dev, ptrs.data(), n, 0);
+        if (rc) return shim_fail(h, rc);
+        for (size_t p = 0; p < ptrs.size(); ++p)
+            if (param_grads[p]) HIPCHK(h, launch_pad_scatter((hipStream_t)stream, ptrs[p], sh->pmap[p], param_grads[p], sh->pnumel[p], accumulate));
+        return IODINE_OK;
+    }
     if (!h->fwd_done) return h->fail(IODINE_ERR_STATE, "iodine_train_backward: no iodine_train_forward to differentiate");
     if (n != (int)h->params.size() || !param_grads) return h->fail(IODINE_ERR_INVALID, "iodine_train_backward: wrong parameter count");
     if (h->buf.mode != 1 || h->buf.B != h->fwd_batch)
@@ -1630,15 +1870,17 @@ int iodine_train_backward_flat(iodine_handle* h, void* stream, const float* grad
     if (!h) return IODINE_ERR_INVALID;
     if (!flat_grads) return h->fail(IODINE_ERR_INVALID, "iodine_train_backward_flat: flat_grads is required");
     std::vector<float*> ptrs(h->params.size());
-    for (size_t p = 0; p < h->params.size(); ++p) ptrs[p] = flat_grads + (h->gacc[p] - h->gacc_arena);
+    size_t off = 0;                                            // parameters back to back in named_parameters() order (= the gacc layout)
+    for (size_t p = 0; p < h->params.size(); ++p) { ptrs[p] = flat_grads + off; off += h->params[p].numel(); }
     return train_backward_impl(h, stream, 1.f, grad_loss_dev, ptrs.data(), (int)ptrs.size(), accumulate ? 1 : 0);
 }
 
 int iodine_logger_scalars(iodine_handle* h, void* stream, float* out2)
 {
     if (!h || !out2) return IODINE_ERR_INVALID;
+    if (h->shim) return shim_fail(h, iodine_logger_scalars(h->shim->inner, stream, out2));
     if (!h->params_set) return h->fail(IODINE_ERR_STATE, "iodine_set_params has not been called");
-    HIPCHK(h, launch_mean2((hipStream_t)stream, h->init_mean, h->init_logvar, h->L, out2));
+    HIPCHK(h, launch_mean2((hipStream_t)stream, h->init_mean, h->init_logvar, h->Lreal > 0 ? h->Lreal : h->L, out2));
     return IODINE_OK;
 }
 
@@ -1646,6 +1888,7 @@ int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter
                       size_t* n_floats)
 {
     if (!h || !name) return IODINE_ERR_INVALID;
+    if (h->shim) return shim_fail(h, iodine_debug_copy(h->shim->inner, stream, name, iter, dst, max_floats, n_floats));   // (padded widths)
     if (h->buf.bytes == 0) return h->fail(IODINE_ERR_STATE, "iodine_debug_copy: no workspace yet");
     Buffers& b = h->buf;
     const size_t N = (size_t)b.B * h->K, P = h->P, L = h->L;
@@ -1702,6 +1945,7 @@ int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter
 int iodine_profile_read(iodine_handle* h, const char* category, double* total_ms, long long* launches, int reset)
 {
     if (!h || !category) return IODINE_ERR_INVALID;
+    if (h->shim) return shim_fail(h, iodine_profile_read(h->shim->inner, category, total_ms, launches, reset));
     double tot = 0.0; long long cnt = 0;
     if (!strcmp(category, "graph_captures") || !strcmp(category, "graph_replays")) {    // hipGraph bookkeeping (option "graph")
         if (total_ms) *total_ms = 0.0;

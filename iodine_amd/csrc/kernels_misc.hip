@@ -556,8 +556,11 @@ IOD_DEVINL float block_sum_f(float v, float* s_buf, int tid, int nthreads)
 __global__ void dz_latent_kernel(const float* __restrict__ Rc, const float* __restrict__ wclsT /*[9][C][L]*/,
                                  const float* __restrict__ pm, const float* __restrict__ plv,
                                  const float* __restrict__ eps, int L, int C, int use_ln,
-                                 float* __restrict__ g_pm, float* __restrict__ g_plv, float* __restrict__ latent)
+                                 float* __restrict__ g_pm, float* __restrict__ g_plv, float* __restrict__ latent, int Lreal)
 {
+    // Lreal <= L: the layer-norm of iodine.py:376-395 (3-D case: mean and UNBIASED std over the latent axis) runs over the first Lreal
+    // entries - the reference's DIM_LATENT; entries Lreal .. L - 1 exist only when the host padded the latent axis to a multiple of 4
+    // (zero weights, zero posterior: their gradients are exactly 0) and are written as 0
     // blockDim = NS * Lp (Lp = L rounded up to 64, NS = 8 slices for L <= 64): the 9C-long contraction is cut into NS slices (one per group of
     // Lp threads), eight independent partial sums each (eight L2 loads in flight per thread: the kernel is a chain of load latencies), combined
     // in fixed order; slice 0 finishes the row.  (One thread per latent walked all 9C terms as a single dependent load + fma chain: 64 us per
@@ -601,13 +604,14 @@ __global__ void dz_latent_kernel(const float* __restrict__ Rc, const float* __re
     }
     float nm = gm, nl = gl;
     if (use_ln) {
-        const float m1 = block_sum_f(act ? gm : 0.f, s_buf, tid, nth) / L;
-        const float m2 = block_sum_f(act ? gl : 0.f, s_buf, tid, nth) / L;
-        const float d1 = act ? gm - m1 : 0.f, d2 = act ? gl - m2 : 0.f;
-        const float v1 = block_sum_f(d1 * d1, s_buf, tid, nth) / (L - 1);      // torch.std: unbiased
-        const float v2 = block_sum_f(d2 * d2, s_buf, tid, nth) / (L - 1);
-        nm = d1 / (sqrtf(v1) + 1e-5f);
-        nl = d2 / (sqrtf(v2) + 1e-5f);
+        const bool real = act && l < Lreal;
+        const float m1 = block_sum_f(real ? gm : 0.f, s_buf, tid, nth) / Lreal;
+        const float m2 = block_sum_f(real ? gl : 0.f, s_buf, tid, nth) / Lreal;
+        const float d1 = real ? gm - m1 : 0.f, d2 = real ? gl - m2 : 0.f;
+        const float v1 = block_sum_f(d1 * d1, s_buf, tid, nth) / (Lreal - 1);      // torch.std: unbiased
+        const float v2 = block_sum_f(d2 * d2, s_buf, tid, nth) / (Lreal - 1);
+        nm = real ? d1 / (sqrtf(v1) + 1e-5f) : 0.f;
+        nl = real ? d2 / (sqrtf(v2) + 1e-5f) : 0.f;
     }
     if (act) {
         float* o = latent + (size_t)n * 4 * L;
@@ -616,14 +620,15 @@ __global__ void dz_latent_kernel(const float* __restrict__ Rc, const float* __re
 }
 
 hipError_t launch_dz_latent(hipStream_t st, const float* Rc, const float* wclsT, const float* pm, const float* plv,
-                            const float* eps, int N, int L, int C, int use_ln, float* g_pm, float* g_plv, float* latent)
+                            const float* eps, int N, int L, int C, int use_ln, float* g_pm, float* g_plv, float* latent, int Lreal)
 {
+    if (Lreal <= 0 || Lreal > L) Lreal = L;
     IOD_XSKIP(32);
     const int Lp = (L + 63) / 64 * 64;
     if (Lp > 512) return hipErrorInvalidValue;                   // block_sum_f: at most 8 waves
     const int nth = (512 / Lp) * Lp;                             // 8 slices for L <= 64, 4 for L <= 128, ...
     hipLaunchKernelGGL(dz_latent_kernel, dim3(N), dim3(nth), (9 * C + nth) * sizeof(float), st, Rc, wclsT, pm, plv, eps, L, C,
-                       use_ln, g_pm, g_plv, latent);
+                       use_ln, g_pm, g_plv, latent, Lreal);
     return hipGetLastError();
 }
 

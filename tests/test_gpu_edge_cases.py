@@ -71,12 +71,7 @@ def test_unsupported_configurations_fail_loudly():
         IODINE(arch_namespace(8, 2, 3, 16, (48, 2, 32), (48, 2))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
     with pytest.raises((RuntimeError, ValueError)):                          # even kernel size
         IODINE(arch_namespace(8, 2, 3, 16, (32, 2, 32), (32, 2), kernels=(3, 4))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
-    # the refinement head reads weight rows as 16-byte vectors: DIM_LATENT / MLP_UNITS that are not multiples of 4 are refused WHEN
-    # THE HANDLE IS CREATED, with a readable message (round 4; they used to surface as a bare HIP error at the first call)
-    with pytest.raises((RuntimeError, ValueError), match='DIM_LATENT must be a multiple of 4'):
-        IODINE(arch_namespace(6, 2, 3, 16, (32, 2, 32), (32, 2))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
-    with pytest.raises((RuntimeError, ValueError), match='MLP_UNITS must be a multiple of 4'):
-        IODINE(arch_namespace(8, 2, 3, 16, (32, 2, 30), (32, 2))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
+    # (round 6: DIM_LATENT / MLP_UNITS that are not multiples of 4 run - test_latent_and_mlp_widths_that_are_not_multiples_of_4)
     m = IODINE(ok).to(DEV)
     with pytest.raises((RuntimeError, ValueError)):                          # wrong image size for this ARCH
         m.reconstruct(torch.rand(1, 3, 32, 32, device=DEV))
@@ -88,6 +83,47 @@ def test_unsupported_configurations_fail_loudly():
     big.max_batch = lambda training=False: 10 ** 9
     with pytest.raises(RuntimeError, match='batch too large'):
         big.reconstruct(torch.empty(300, 3, 128, 128, device=DEV))
+
+
+@pytest.mark.parametrize('L,H,prec', [(10, 30, 1), (10, 30, 0), (6, 32, 1), (8, 30, 1), (13, 33, 1)])
+def test_latent_and_mlp_widths_that_are_not_multiples_of_4(L, H, prec):
+    """iodine.py:8-32,446-464 take any DIM_LATENT / REF.MLP_UNITS; the library's refinement head moves weight rows as 16-byte vectors and
+    refused other widths until round 6.  Now such a model runs on a zero-padded inner handle (iodine_api.cpp PadShim;
+    the layer-norm over the latent axis keeps the real width) with the reference's shapes at the boundary: a whole training step, reconstruct,
+    elbo() from the posterior the call left, and decode against the oracle; every parameter gradient in its reference shape."""
+    arch = dataclasses.replace(O.tiny_arch(slots=3, iters=2, img_size=16), dim_latent=L, ref_mlp=H)
+    params, x, eps = _case(arch, 2, seed=41)
+    m = make_hip_model(arch, params, options={'conv_precision': prec})
+    assert m.get_input_size() == (17, 4 * L) and tuple(m.refine.lstm.weight_ih.shape) == (4 * H, H + 4 * L)
+    xd, ed = x.to(DEV), eps.to(DEV)
+    m.zero_grad(set_to_none=True)
+    loss = m(xd, ed)
+    loss.backward()
+    out, rg = O.train_step_grads(x, eps, params, arch)
+    assert abs(loss.item() - float(out['loss'])) <= 1e-4 * abs(float(out['loss']))
+    assert rel_err(m.elbo_terms[:, 0].cpu(), out['elbos']) < 1e-4
+    for n, p in m.named_parameters():
+        assert tuple(p.grad.shape) == tuple(params[n].shape), n
+    bad = [(n, rel_l2(*grad_views(n, p.grad.cpu().numpy(), rg[n].numpy()))) for n, p in m.named_parameters()
+           if not rel_l2(*grad_views(n, p.grad.cpu().numpy(), rg[n].numpy())) < 2e-3]
+    assert not bad, bad
+    assert rel_err(m.posterior.mean.cpu(), out['post_mean']) < 2e-4 and tuple(m.posterior.mean.shape) == (2, 3, L)
+    # a second backward accumulates into .grad like autograd (the scatter of the padded gradient honours `accumulate`)
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m(xd, ed).backward()
+    for n, p in m.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), 2 * g1[n].cpu().numpy()) < 1e-5, n
+    ref = O.reconstruct(x, eps, params, arch)
+    pred, mask, mean = m.reconstruct(xd, ed)
+    assert rel_err(m.elbo_terms[:, 0].cpu(), ref['elbos']) < 1e-4
+    assert rel_err(pred.cpu(), ref['pred']) < 2e-4 and rel_err(mask.cpu(), ref['mask']) < 2e-4
+    assert tuple(m.z.shape) == (2, 3, L)
+    z = m.encode(xd, ed)
+    assert tuple(z.shape) == (2, 3, L) and rel_err(z.cpu(), ref['z']) < 2e-4
+    p2, k2, m2 = m.decode(z)
+    assert rel_err(p2.cpu(), ref['pred']) < 2e-4
+    e1 = m.elbo(xd, ed[0])                                                   # samples from lambda_T the call above left (iodine.py:636-645)
+    assert torch.isfinite(e1)
 
 
 # ---- ARCH.ENCODING subsets (round 3): the reference's DEFAULT list has no 'coordinate' (lib/config/defaults.py:57-80) -----------
