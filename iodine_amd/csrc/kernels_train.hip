@@ -2053,6 +2053,46 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
     // launch to what the block left there in the previous pass; alpha = the pass's loss weight -w_i / B), so that the fixed-order
     // reduction over the blocks runs once per layer and step instead of once per launch (18 -> 3 reduce launches per cfg3 step).
     const float inv = alpha / acc_prod;
+    if constexpr (KS > 1) {
+        // Round 6 (C = 32: the four consumer waves each own one ROW of the tile and a full set of the nine 32 x 32 tap accumulators): the four
+        // K-split accumulator sets are summed through LDS - fixed order wave 0 .. 3 - before ONE partial tile per block is written, instead of
+        // four (37.7 -> 9.4 MB of partial tiles per cfg2 launch, and the fixed-order reduction behind it reads a quarter).  Three rounds of three
+        // taps (4 waves x 3 x 16 x 64 floats = 48 KB per round, behind the 4 KB the producers' bias sums use); the producer waves have left after F2,
+        // terminated waves do not take part in s_barrier.
+        __builtin_amdgcn_s_barrier();                                       // F1
+        __builtin_amdgcn_s_barrier();                                       // F2: producers' bias sums are in LDS
+        if (tid < D4) {
+            const float4* s_red = reinterpret_cast<const float4*>(smem_ws);
+            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = tid; j < 256; j += D4) { const float4 v = s_red[j]; t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w; }
+            float4* pb = reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * NCO + tid * 4);
+            float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (accum) o4 = *pb;
+            *pb = make_float4(o4.x + alpha * t4.x, o4.y + alpha * t4.y, o4.z + alpha * t4.z, o4.w + alpha * t4.w);
+        }
+        static_assert(KS == 4 && MT == 1 && NTT == 1, "K-split reduction is written for the 32 x 32 instance");
+        float* s_sum = reinterpret_cast<float*>(smem_ws) + 1024;            // [wave][3 taps x 16 regs][64 lanes]
+        float* pwb = part + ((size_t)blockIdx.x * 9) * CI * NCOP;
+#pragma unroll
+        for (int rd = 0; rd < 3; ++rd) {
+#pragma unroll
+            for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_sum[(ks * 48 + tl * 16 + r) * 64 + lane] = nq > 0 ? acc[rd * 3 + tl][r] * inv : 0.f;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const int ent = ks * 12 + e, tl = ent >> 4, r = ent & 15;
+                const float v = ((s_sum[(0 * 48 + ent) * 64 + lane] + s_sum[(1 * 48 + ent) * 64 + lane]) + s_sum[(2 * 48 + ent) * 64 + lane]) + s_sum[(3 * 48 + ent) * 64 + lane];
+                const int cr = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                float* dst = pwb + ((size_t)(rd * 3 + tl) * CI + cr) * NCOP + li;
+                *dst = accum ? *dst + v : v;
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
     float* pw = part + ((size_t)(blockIdx.x * KS + ks) * 9) * CI * NCOP;
     if (accum) {
 #pragma unroll
@@ -2113,7 +2153,7 @@ static hipError_t launch_wgrad_f16_ws_inst(hipStream_t st, const float* a, const
         fprintf(stderr, "\n");
     }
 #endif
-    *nparts = blocks * KS;
+    *nparts = blocks;                                                       // (round 6: the KS K-split sets of a block are summed before the write)
     *ncop = NTT * 32;
     *nbias = blocks;
     return hipGetLastError();
