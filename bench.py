@@ -162,19 +162,22 @@ def cpu_baseline(args, arch, params, mode):
     return cb, (x, eps, ref_elbos, ref_grads)
 
 
-def pmc_file(strict=False):
-    """The newest tracked PMC record (profiles/rNN_pmc.json; strict: rNN_pmc_strict.json = the same passes over --conv-precision 0)."""
+def pmc_file(strict=False, config='clevr6'):
+    """The newest tracked PMC record (profiles/rNN_pmc.json; strict: rNN_pmc_strict.json = the same passes over --conv-precision 0;
+    config dsprites: rNN_pmc_dsprites.json = the passes over --config dsprites, BASELINE configs[1])."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_strict.json' if strict else 'r[0-9][0-9]_pmc.json')))
+    pat = 'r[0-9][0-9]_pmc_dsprites.json' if config == 'dsprites' else 'r[0-9][0-9]_pmc_strict.json' if strict else 'r[0-9][0-9]_pmc.json'
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pat)))
     return files[-1] if files else None
 
 
-def pmc_record(args, B, K, strict=None):
+def pmc_record(args, B, K, strict=None, config=None):
     """HBM bytes per launch (every profiled category) and matrix-pipe utilisation / shader clock of the dominant kernels from the
     tracked PMC file (tools/pmc_to_json.py writes it from rocprofv3 --pmc passes: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).
     Quoted only while the file describes THIS tree (source digest) and THIS shape; otherwise (None, None, reason)."""
     strict = (args.conv_precision == 0) if strict is None else strict
-    path = pmc_file(strict)
+    config = config or args.config
+    path = pmc_file(strict, config)
     if not path:
         return None, None, 'no profiles/rNN_pmc_strict.json' if strict else 'no profiles/rNN_pmc.json'
     name = os.path.relpath(path, ROOT)
@@ -184,7 +187,7 @@ def pmc_record(args, B, K, strict=None):
         if rec.get('csrc_sha256') != source_digest():
             return None, None, f'{name} was measured on other kernel sources (digest mismatch)'
         shape = rec.get('shape', {})
-        if (shape.get('config'), shape.get('batch'), shape.get('slots')) != (args.config, B, K) or bool(rec.get('conv_precision', 1) == 0) != bool(strict):
+        if (shape.get('config'), shape.get('batch'), shape.get('slots')) != (config, B, K) or bool(rec.get('conv_precision', 1) == 0) != bool(strict):
             return None, None, f'{name} was measured on another shape'
         per = {k: v['hbm_bytes_per_launch'] for k, v in rec['kernels'].items() if 'hbm_bytes_per_launch' in v}
         pipe = {k: {f: v[f] for f in ('mfma_util', 'clock_ghz', 'mfma_rate_of_2p4ghz_peak') if f in v}
@@ -439,6 +442,8 @@ def main():
                     algorithmic_hbm_bytes_per_launch=2.0 * B * K * S * S * C_ * 4,
                     hbm_gbps_algorithmic=round(2.0 * B * K * S * S * C_ * 4 / (avg_ms * 1e-3) / 1e9, 1) if dom_n else None)
 
+    cfg_of = {}                                              # id(arch) -> bench config name of a side model ('dsprites' has its own PMC record)
+
     def side_roofline(m, a, bsz, step_fn, step_ms, mode):
         """`roofline` block of a side configuration (cfg2, cfg5 shard): the dominant decoder 3x3 conv C -> C of THAT shape, launches bracketed
         with HIP events (every PROFILE_STRIDE-th) in an extra pass of 3 steps behind the timed one - the brackets cost ~12 us of idle GPU
@@ -474,12 +479,18 @@ def main():
                     for c in DOMINANT if c in pr}
         f_m, f_h = tf / pk, gbps / PEAK_HBM_GBPS
         hb = f_h > f_m
+        # HBM bytes per launch from the PMC record of THIS shape (cfg2: profiles/rNN_pmc_dsprites.json), launch-weighted like `achieved`
+        s_per, s_pipe, s_src = pmc_record(args, bsz, Kk, strict=False, config=cfg_of.get(id(a), 'no-record'))
+        s_traffic = None
+        if s_per and all(c in s_per for c in w):
+            s_traffic = sum(s_per[c] * k for c, k in w.items()) / sum(w.values())
         return dict(bound='hbm' if hb else 'mfma',
                     kernel=f'conv3x3_ws_f16x3_kernel<{Cc},EPI>' + (f' + conv3x3_wgrad_f16x3_ws_kernel<{Cc},{Cc}>' if mode == 'train' else '')
                            + f' (decoder 3x3 conv {Cc}->{Cc}: ' + ('fwd, dgrad, wgrad' if mode == 'train' else 'fwd, dgrad') + ' launches)',
                     achieved=round(gbps if hb else tf, 2), peak=PEAK_HBM_GBPS if hb else round(pk, 1), unit='GB/s' if hb else 'TFLOP/s',
-                    frac=round(max(f_m, f_h), 4), frac_mfma=round(f_m, 4), frac_hbm=round(f_h, 4), traffic=None,
-                    traffic_source='no PMC record at this shape', flops_per_launch=fl, algorithmic_hbm_bytes_per_launch=by,
+                    frac=round(max(f_m, f_h), 4), frac_mfma=round(f_m, 4), frac_hbm=round(f_h, 4), traffic=s_traffic,
+                    traffic_source=s_src, traffic_per_kernel=({c: s_per[c] for c in w if c in s_per} if s_per else None),
+                    matrix_pipe_pmc=s_pipe, flops_per_launch=fl, algorithmic_hbm_bytes_per_launch=by,
                     avg_launch_ms=round(avg, 4), launches_per_step=round(dom_all / n, 1), launches_timed=dom_n, events_in_timed_region=False,
                     kernel_time_share=round(avg * (dom_all / n) / step_ms, 4), per_form=per_form)
 
@@ -658,6 +669,7 @@ def main():
         side = {}
         for tag, (cfgname, slots, iters, bsz) in dict(cfg2=('dsprites', 6, 5, 32), cfg5_shard=('clevr6', 11, 7, 8)).items():
             m2, a2, _ = build_model(cfgname, slots, iters, device)
+            cfg_of[id(a2)] = cfgname if (cfgname, slots) == ('dsprites', 6) else 'no-record'
             m2.manual_seed(99)
             x2 = torch.from_numpy(synth.make_images(bsz, a2.IMG_SIZE, seed=0)).to(device)
             rec = dict(workload=f'{"multi-dSprites 64x64" if cfgname == "dsprites" else "CLEVR 128x128"}, K={slots}, T={iters}, '

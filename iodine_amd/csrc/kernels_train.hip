@@ -1700,7 +1700,18 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
     const int tid = threadIdx.x;
     const int lane = tid & 63, kh = lane >> 5, li = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    // Round 6: XCD-aware tile order (block b runs on XCD b % 8 - observed, speed only): every XCD walks one contiguous eighth of the tile
+    // list and its blocks take neighbouring tiles at about the same time, so that the halo rows / columns two tiles share are L2 hits.  With
+    // the plain order (tile = block + q * blocks) neighbouring tiles sat on different XCDs and every halo was fetched from memory again:
+    // PMC at the cfg2 shapes 286 MB per launch against 210 MB of operands + partial tiles (profiles/r06_pmc_dsprites.json).  Needs a grid
+    // that is a multiple of 8; the tile -> block map only changes WHICH partial tile a product lands in (fixed: results stay deterministic).
+    const bool xcd_order = (gridDim.x & 7) == 0;
+    const int bpx = xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;              // tile stride of a block
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int t_begin = xcd_order ? (int)(blockIdx.x & 7) * per_xcd : 0;
+    const int t_end = xcd_order ? min(ntiles, t_begin + per_xcd) : ntiles;
+    const int t_first = t_begin + (xcd_order ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+    const int my_tiles = t_first < t_end ? (t_end - 1 - t_first) / bpx + 1 : 0;
     const int nq = my_tiles;
 
     if (wv >= 4) {
@@ -1756,13 +1767,13 @@ void conv3x3_wgrad_f16x3_ws_kernel(const float* __restrict__ a, const float* __r
         // divisions per tile (those were ~1 k ticks of a 6 k-tick step)
         int ltx, lty, ln, lq = 0;
         {
-            int t = blockIdx.x;
+            int t = min(t_first, ntiles - 1);                   // (a block without tiles still issues its first loads: keep them inside the tensor)
             ltx = t % tiles_x; t /= tiles_x;
             lty = t % tiles_y; ln = t / tiles_y;
         }
         int gsx, gsy, gsn;
         {
-            int t = gridDim.x;
+            int t = bpx;
             gsx = t % tiles_x; t /= tiles_x;
             gsy = t % tiles_y; gsn = t / tiles_y;
         }

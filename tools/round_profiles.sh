@@ -16,6 +16,14 @@ cp $OUT/${TAG}_pmc.json $REPO/profiles/${TAG}_pmc.json
 # ... and of the exact-fp32 path (the exact_fp32 sub-line / --conv-precision 0 quote their traffic from it)
 bash tools/pmc_traffic.sh $TAG --conv-precision 0 > $OUT/${TAG}_pmc_strict.log 2>&1
 cp $OUT/${TAG}_pmc_strict.json $REPO/profiles/${TAG}_pmc_strict.json
+# ... and of BASELINE configs[1] (cfg2: multi-dSprites 64 x 64, 32 channels): configs.cfg2.roofline.traffic of the default line and the
+# --config dsprites lines quote it; plus one SQ pass that splits the wave cycles of its kernels (parked / issue-stalled / issuing)
+bash tools/pmc_traffic.sh ${TAG}ds --config dsprites > $OUT/${TAG}_pmc_ds.log 2>&1
+cp $OUT/${TAG}ds_pmc.json $REPO/profiles/${TAG}_pmc_dsprites.json
+cp $OUT/${TAG}ds_kernel_traffic.md $OUT/${TAG}_kernel_traffic_dsprites.md
+(cd /tmp && export TMPDIR=/tmp && rm -rf $OUT/${TAG}_sq_ds && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/${TAG}_sq_ds -o p -- python $REPO/bench.py --config dsprites --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 --no-extra-configs --no-sustain > $OUT/${TAG}_sq_ds.log 2>&1)
+python tools/sq_split.py $OUT/${TAG}_sq_ds > $OUT/${TAG}_dsprites_wave_cycle_split.md 2>&1
+rm -rf $OUT/${TAG}_sq_ds
 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
 python bench.py --mode infer --no-exact-fp32 --no-sustain > $OUT/${TAG}_bench_infer.json 2> /dev/null
 for g in 0 1; do
