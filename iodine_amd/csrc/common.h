@@ -252,6 +252,7 @@ hipError_t launch_sgemm_tn_mfma(hipStream_t st, int M, int N, int K, float alpha
                                 float beta, float* C, int ldc, int mode, int mode_c, int a_rowmajor = 0);
 hipError_t launch_l0_tap_sums(hipStream_t st, const float* Rc, float* RT, int N, int C);
 hipError_t launch_l0_scatter_z(hipStream_t st, const float* tmp, int L, int C, float alpha, float* gw);
+hipError_t launch_l0_latent_wgrad(hipStream_t st, const float* Rc, const float* z, int N, int L, int C, float alpha, float* gw);
 hipError_t launch_l0_coord_grads(hipStream_t st, const float* D, const float* lin, int S, int C, int L, float alpha,
                                  float* gw, float* gb, float* scratch);
 hipError_t launch_loss(hipStream_t st, const float* scal, int n, float* loss);

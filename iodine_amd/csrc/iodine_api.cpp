@@ -707,13 +707,11 @@ int decoder_backward_data(iodine_handle* h, hipStream_t st, int N, float** dpre0
         // layer 0 (spatial broadcast): latent-channel weights from z and the per-tap sums, coordinate channels
         // and bias from the slot-summed gradient map
         const int wi = param_index(h, "decoder.mlc.layers.0.weight"), bi = param_index(h, "decoder.mlc.layers.0.bias");
-        HIPCHK(h, launch_l0_tap_sums(st, b.Rc, b.RT, N, Cd));
-        if (sgemm_tn_mfma_ok(h->L, 9 * Cd, N))              // z^T . RT on fp32 MFMA, accumulated straight into gw[co][ci][tap]
+        if (sgemm_tn_mfma_ok(h->L, 9 * Cd, N)) {            // z^T . RT on fp32 MFMA, accumulated straight into gw[co][ci][tap]
+            HIPCHK(h, launch_l0_tap_sums(st, b.Rc, b.RT, N, Cd));
             HIPCHK(h, launch_sgemm_tn_mfma(st, h->L, 9 * Cd, N, train_alpha, b.z[it], h->L, b.RT, 9 * Cd, 1.f, h->gacc[wi], h->L + 2, 1, Cd));
-        else {
-            HIPCHK(h, launch_sgemm(st, 1, 0, h->L, 9 * Cd, N, 1.f, b.z[it], h->L, b.RT, 9 * Cd, 0.f, b.tmp_lz, 9 * Cd));
-            HIPCHK(h, launch_l0_scatter_z(st, b.tmp_lz, h->L, Cd, train_alpha, h->gacc[wi]));
-        }
+        } else                                              // (round 6) tap sums + product + scatter in one launch
+            HIPCHK(h, launch_l0_latent_wgrad(st, b.Rc, b.z[it], N, h->L, Cd, train_alpha, h->gacc[wi]));
         if (it == h->T) {
             if (fused_l0) HIPCHK(h, launch_l0_coord_grads_rows(st, b.Rsum, h->lin, h->S, Cd, h->L, 1.f, h->gacc[wi], h->gacc[bi]));
             else HIPCHK(h, launch_l0_coord_grads(st, b.Dsum, h->lin, h->S, Cd, h->L, 1.f, h->gacc[wi], h->gacc[bi], b.wg_part));

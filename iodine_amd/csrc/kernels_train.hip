@@ -660,6 +660,52 @@ hipError_t launch_l0_tap_sums(hipStream_t st, const float* Rc, float* RT, int N,
     return hipGetLastError();
 }
 
+// Round 6: the latent-channel weight gradient of the broadcast layer in ONE launch where the fp32-MFMA GEMM does not apply (DIM_LATENT not a
+// multiple of 32: the dSprites architectures) - tap sums, z^T . RT and the scatter into gw[co][ci][tap] were three launches of 5 - 7 us each,
+// six times per training step.  One thread per (ci, tap, co); the sum over the slot-images runs in four interleaved partial sums (fixed order).
+__global__ __launch_bounds__(256)
+void l0_latent_wgrad_kernel(const float* __restrict__ Rc, const float* __restrict__ z, int N, int L, int C, float alpha,
+                            float* __restrict__ gw)
+{
+    // block = 32 outputs (consecutive co of one (ci, tap) when C >= 32) x 8 slices of the slot-images; slice s takes n = s, s + 8, ...
+    __shared__ float s_part[8][32];
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;
+    const bool live = i < L * 9 * C;
+    const int ii = live ? i : 0;
+    const int co = ii % C, tap = (ii / C) % 9, ci = ii / (9 * C);
+    const int dy = tap / 3, dx = tap % 3;
+    // border classes (row class rc, column class cc) in which the tap stays inside the image: rc in [r0, r1], cc in [c0, c1]
+    const int r0 = dy == 0 ? 1 : 0, r1 = dy == 2 ? 1 : 2, c0 = dx == 0 ? 1 : 0, c1 = dx == 2 ? 1 : 2;
+    float acc = 0.f;
+    for (int n = sl; n < N; n += 8) {
+        const float* r = Rc + (size_t)n * 9 * C + co;
+        float t = 0.f;
+#pragma unroll
+        for (int rc = 0; rc < 3; ++rc)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const float v = r[(rc * 3 + cc) * C];                   // (all nine classes are loaded: no divergent addressing, 36 bytes per (n, co))
+                t += (rc >= r0 && rc <= r1 && cc >= c0 && cc <= c1) ? v : 0.f;
+            }
+        acc = fmaf(z[(size_t)n * L + ci], t, acc);
+    }
+    s_part[sl][o] = acc;
+    __syncthreads();
+    if (sl == 0 && live) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += s_part[q][o];
+        gw[((size_t)co * (L + 2) + ci) * 9 + tap] += alpha * t;
+    }
+}
+
+hipError_t launch_l0_latent_wgrad(hipStream_t st, const float* Rc, const float* z, int N, int L, int C, float alpha, float* gw)
+{
+    hipLaunchKernelGGL(l0_latent_wgrad_kernel, dim3((L * 9 * C + 31) / 32), dim3(256), 0, st, Rc, z, N, L, C, alpha, gw);
+    return hipGetLastError();
+}
+
 // gw[co][ci][tap] += alpha * tmp[ci][tap*C + co]  for the latent channels (tmp = z^T . RT)
 __global__ void l0_scatter_z_kernel(const float* __restrict__ tmp, int L, int C, float alpha, float* __restrict__ gw)
 {
