@@ -490,7 +490,7 @@ def main():
                     achieved=round(gbps if hb else tf, 2), peak=PEAK_HBM_GBPS if hb else round(pk, 1), unit='GB/s' if hb else 'TFLOP/s',
                     frac=round(max(f_m, f_h), 4), frac_mfma=round(f_m, 4), frac_hbm=round(f_h, 4), traffic=s_traffic,
                     traffic_source=s_src, traffic_per_kernel=({c: s_per[c] for c in w if c in s_per} if s_per else None),
-                    matrix_pipe_pmc=s_pipe, flops_per_launch=fl, algorithmic_hbm_bytes_per_launch=by,
+                    matrix_pipe_pmc=({c: v for c, v in s_pipe.items() if c in w} if s_pipe else None), flops_per_launch=fl, algorithmic_hbm_bytes_per_launch=by,
                     avg_launch_ms=round(avg, 4), launches_per_step=round(dom_all / n, 1), launches_timed=dom_n, events_in_timed_region=False,
                     kernel_time_share=round(avg * (dom_all / n) / step_ms, 4), per_form=per_form)
 

@@ -678,7 +678,8 @@ void l0_latent_wgrad_kernel(const float* __restrict__ Rc, const float* __restric
     // border classes (row class rc, column class cc) in which the tap stays inside the image: rc in [r0, r1], cc in [c0, c1]
     const int r0 = dy == 0 ? 1 : 0, r1 = dy == 2 ? 1 : 2, c0 = dx == 0 ? 1 : 0, c1 = dx == 2 ? 1 : 2;
     float acc = 0.f;
-    for (int n = sl; n < N; n += 8) {
+#pragma unroll 4
+    for (int n = sl; n < N; n += 8) {                                   // (unrolled: 36 independent loads in flight instead of 9)
         const float* r = Rc + (size_t)n * 9 * C + co;
         float t = 0.f;
 #pragma unroll
