@@ -124,6 +124,18 @@ def test_latent_and_mlp_widths_that_are_not_multiples_of_4(L, H, prec, graph):
     assert rel_err(p2.cpu(), ref['pred']) < 2e-4
     e1 = m.elbo(xd, ed[0])                                                   # samples from lambda_T the call above left (iodine.py:636-645)
     assert torch.isfinite(e1)
+    # the chunked training path (batches beyond one library call): the library ADDS the second chunk's padded gradient into the flat
+    # reference-shaped buffer (iodine_train_backward_flat, accumulate = 1 -> pad_scatter with accumulate)
+    if graph == 0:
+        whole = {n: g.clone() for n, g in g1.items()}
+        m.set_option('batch_cap', 1)
+        m.zero_grad(set_to_none=True)
+        lc = m(xd, ed)
+        lc.backward()
+        m.set_option('batch_cap', 0)
+        assert abs(lc.item() - loss.item()) <= 1e-6 * abs(loss.item())
+        for n, p in m.named_parameters():
+            assert rel_l2(p.grad.cpu().numpy(), whole[n].cpu().numpy()) < 1e-5, n
 
 
 # ---- ARCH.ENCODING subsets (round 3): the reference's DEFAULT list has no 'coordinate' (lib/config/defaults.py:57-80) -----------
