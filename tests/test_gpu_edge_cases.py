@@ -85,13 +85,14 @@ def test_unsupported_configurations_fail_loudly():
         big.reconstruct(torch.empty(300, 3, 128, 128, device=DEV))
 
 
-@pytest.mark.parametrize('L,H,prec,graph', [(10, 30, 1, 0), (10, 30, 0, 0), (6, 32, 1, 0), (8, 30, 1, 0), (13, 33, 1, 0), (10, 30, 1, 1)])
-def test_latent_and_mlp_widths_that_are_not_multiples_of_4(L, H, prec, graph):
+@pytest.mark.parametrize('L,H,prec,graph,dk', [(10, 30, 1, 0, 3), (10, 30, 0, 0, 3), (6, 32, 1, 0, 3), (8, 30, 1, 0, 3), (13, 33, 1, 0, 3), (10, 30, 1, 1, 3),
+                                               (10, 30, 1, 0, 5)])       # dk 5: the generic decoder (its broadcast layer takes any latent width) behind the padded handle
+def test_latent_and_mlp_widths_that_are_not_multiples_of_4(L, H, prec, graph, dk):
     """iodine.py:8-32,446-464 take any DIM_LATENT / REF.MLP_UNITS; the library's refinement head moves weight rows as 16-byte vectors and
     refused other widths until round 6.  Now such a model runs on a zero-padded inner handle (iodine_api.cpp PadShim;
     the layer-norm over the latent axis keeps the real width) with the reference's shapes at the boundary: a whole training step, reconstruct,
     elbo() from the posterior the call left, and decode against the oracle; every parameter gradient in its reference shape."""
-    arch = dataclasses.replace(O.tiny_arch(slots=3, iters=2, img_size=16), dim_latent=L, ref_mlp=H)
+    arch = dataclasses.replace(O.tiny_arch(slots=3, iters=2, img_size=16), dim_latent=L, ref_mlp=H, dec_kernel=dk)
     params, x, eps = _case(arch, 2, seed=41)
     m = make_hip_model(arch, params, options={'conv_precision': prec, 'graph': graph})      # graph 1: the inner handle replays, the pad / unpad launches stay eager
     assert m.get_input_size() == (17, 4 * L) and tuple(m.refine.lstm.weight_ih.shape) == (4 * H, H + 4 * L)
