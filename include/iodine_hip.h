@@ -55,7 +55,7 @@ extern "C" {
 typedef struct iodine_config {
     int dim_latent;        /* ARCH.DIM_LATENT  (2..256; widths that are not multiples of 4 run zero-padded inside, same shapes at this boundary) */
     int iters;             /* ARCH.ITERS       */
-    int slots;             /* ARCH.SLOTS       */
+    int slots;             /* ARCH.SLOTS       (1..16) */
     int img_size;          /* ARCH.IMG_SIZE    (multiples of 16: tuned kernels; other sizes >= 8: generic fallback path) */
     int img_channels;      /* ARCH.IMG_CHANNELS (3) */
     double sigma;          /* ARCH.SIGMA       */

@@ -311,7 +311,7 @@ std::string validate(const iodine_config& c)
     if (9 * c.dec_conv_chan < c.dim_latent) return "DIM_LATENT must not exceed 9 * DEC.CONV_CHAN";
     if (c.dec_conv_layers < 2) return "DEC.CONV_LAYERS must be >= 2";
     if (c.ref_conv_layers < 1 || (c.img_size >> c.ref_conv_layers) < 1) return "REF.CONV_LAYERS out of range for IMG_SIZE";
-    if (c.slots < 1 || c.slots > 12) return "ARCH.SLOTS must be in 1..12";
+    if (c.slots < 1 || c.slots > 16) return "ARCH.SLOTS must be in 1..16 (the per-pixel kernels keep every slot of a pixel in registers: instantiated for K <= 16)";
     if (c.iters < 1) return "ARCH.ITERS must be >= 1";
     // (the refinement head reads its weight rows as 16-byte vectors: widths that are not multiples of 4 run on a zero-padded inner handle,
     // PadShim - round 6)

@@ -374,7 +374,7 @@ void final_out_kernel(const float4* __restrict__ dec, float* __restrict__ pred, 
 }
 
 // ---- launchers --------------------------------------------------------------------------------
-#define FOR_EACH_K(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+#define FOR_EACH_K(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)      // (round 6: 13 .. 16; 6 K + 3 <= 99 statistics)
 
 int pixel_blocks_per_image(int P) { return (P + 2 * PIX_BLOCK - 1) / (2 * PIX_BLOCK); }   // 2 pixels / thread
 

