@@ -143,6 +143,7 @@ struct iodine_handle {
     bool gen_ref = false;                                  // the REFINEMENT conv stack runs on the generic path (round 5: decided separately -
                                                            // the reference's default ARCH has REF.KERNEL_SIZE 3 / 32 channels beside DEC.KERNEL_SIZE 5)
     int kd = 3, kr = 3;                                    // DEC / REF kernel sizes
+    int rs = 2;                                            // REF.STRIDE (round 6: other strides run on the generic path's kernels)
     std::vector<float*> gen_wdec, gen_wref;                // [layer]: packed weights
     float *gen_wout = nullptr, *gen_cterm = nullptr, *gen_ident = nullptr;   // output conv pack, [P][Cd] bias + coordinate term of decoder layer 0, [9 Cd][L] identity
     std::vector<float*> gacc;                   // one per parameter, reference shapes (slices of gacc_arena)
@@ -304,13 +305,13 @@ std::string validate(const iodine_config& c)
     // fallback path (kernels_generic.hip)
     for (int k : {c.dec_kernel_size, c.ref_kernel_size})
         if (k != 3 && k != 5 && k != 7) return "KERNEL_SIZE must be 3, 5 or 7 (odd: the reference pads with KERNEL_SIZE // 2, iodine.py:419,580)";
-    if (c.ref_stride != 2) return "only REF.STRIDE 2 is implemented";
+    if (c.ref_stride < 1 || c.ref_stride > 8) return "REF.STRIDE must be in 1..8 (2: tuned kernels; other strides: generic path)";
     if (c.img_size < 8 || c.img_size > 1024) return "ARCH.IMG_SIZE must be in 8..1024 (multiples of 16 run on the tuned kernels, other sizes on the generic path)";
     if (c.dec_conv_chan < 8 || c.dec_conv_chan > 256 || c.dec_conv_chan % 4 != 0) return "DEC.CONV_CHAN must be a multiple of 4 in 8..256";
     if (c.ref_conv_chan < 4 || c.ref_conv_chan > 256 || 256 % c.ref_conv_chan != 0) return "REF.CONV_CHAN must divide 256 (4 ... 256)";
     if (9 * c.dec_conv_chan < c.dim_latent) return "DIM_LATENT must not exceed 9 * DEC.CONV_CHAN";
     if (c.dec_conv_layers < 2) return "DEC.CONV_LAYERS must be >= 2";
-    if (c.ref_conv_layers < 1 || (c.img_size >> c.ref_conv_layers) < 1) return "REF.CONV_LAYERS out of range for IMG_SIZE";
+    if (c.ref_conv_layers < 1 || c.ref_conv_layers > 16 || (c.ref_stride == 2 && (c.img_size >> c.ref_conv_layers) < 1)) return "REF.CONV_LAYERS out of range for IMG_SIZE";
     if (c.slots < 1 || c.slots > 16) return "ARCH.SLOTS must be in 1..16 (the per-pixel kernels keep every slot of a pixel in registers: instantiated for K <= 16)";
     if (c.iters < 1) return "ARCH.ITERS must be >= 1";
     // (the refinement head reads its weight rows as 16-byte vectors: widths that are not multiples of 4 run on a zero-padded inner handle,
@@ -321,8 +322,9 @@ std::string validate(const iodine_config& c)
     return "";
 }
 
-// spatial size of refinement layer l's OUTPUT (3x3, pad 1, stride 2): floor((s + 2 - 3)/2) + 1
-int ref_out_size(int s) { return (s - 1) / 2 + 1; }
+// spatial size of refinement layer l's OUTPUT
+// (k x k, pad k // 2, stride rs: floor((s + 2 (k // 2) - k) / rs) + 1 = (s - 1) / rs + 1 for odd k)
+int ref_out_size(const iodine_handle* h, int s) { return (s - 1) / h->rs + 1; }
 // the split-fp16 stride-2 kernels cover the shipped refinement stacks: 32 or 64 channels, even sizes at every layer
 bool refine_f16_ok(const iodine_handle* h);
 
@@ -408,7 +410,7 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
     {
         int s = h->S;
         for (int l = 0; l < h->Dr; ++l) {
-            s = ref_out_size(s);
+            s = ref_out_size(h, s);
             const size_t n_l = (size_t)N * s * s * Cr;
             float* base = a.take<float>(n_l * (mode == 1 ? T : 1));         // [T][N][s][s][Cr] in training (see enc)
             for (int i = 0; i <= T; ++i) b.ract[i][l] = (mode == 1 && i < T) ? (base ? base + (size_t)i * n_l : nullptr) : base;
@@ -444,7 +446,7 @@ void plan(const iodine_handle* h, int B, int mode, Arena& a, Buffers& b)
         for (int j = 0; j < 2; ++j) { b.carry_h[j] = a.take<float>((size_t)N * H); b.carry_c[j] = a.take<float>((size_t)N * H); }
         b.rdpre.resize(h->Dr);
         int s = h->S;
-        for (int l = 0; l < h->Dr; ++l) { s = ref_out_size(s); b.rdpre[l] = a.take<float>((size_t)T * N * s * s * Cr); }
+        for (int l = 0; l < h->Dr; ++l) { s = ref_out_size(h, s); b.rdpre[l] = a.take<float>((size_t)T * N * s * s * Cr); }
     }
     if (h->generic) {
         b.gen_l0 = a.take<float>(gen_l0_scratch_floats(N, h->S, Cd, h->kd));   // row / tap sums, prefix table of the broadcast layer
@@ -784,7 +786,7 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
     for (int l = 0; l < h->Dr; ++l) {
         if (h->gen_ref) {
             PROF(h, st, "gen_conv", launch_gen_conv_fwd(st, in, h->gen_wref[l], h->ref_b[l], b.ract[i][l], N, s, l == 0 ? 17 : h->Cr,
-                                                        l == 0 ? 20 : h->Cr, h->Cr, h->kr, 2, 1, l == 0 ? h->enc_chmask : 0xffffffffu));
+                                                        l == 0 ? 20 : h->Cr, h->Cr, h->kr, h->rs, 1, l == 0 ? h->enc_chmask : 0xffffffffu));
         } else if (l == 0 && l0f) {
         } else if (l == 0 && split) {
             PROF(h, st, "refine_l0", launch_conv3x3_s2_f16x3(st, b.encs[i], h->ref_wsh16, h->ref_wshmeta, nullptr, b.rmap, B, s, 8,
@@ -800,7 +802,7 @@ int refine_step(iodine_handle* h, hipStream_t st, int B, int i, bool save)
             PROF(h, st, l == 0 ? "refine_l0" : "refine_conv", launch_conv3x3_gather(st, in, h->ref_w[l], h->ref_b[l], b.ract[i][l], N, s, s,
                                                              l == 0 ? 20 : h->Cr, h->Cr, 2));
         in = b.ract[i][l];
-        s = ref_out_size(s);
+        s = ref_out_size(h, s);
     }
     PROF(h, st, "refine_head", launch_refine_head(st, in, N, s * s, h->Cr, h->H, h->L, h->mlp_wT, h->mlp_b, h->wihT, h->whhT, h->lstm_b,
                                  h->wmT, h->bm, h->wvT, h->bv, b.latent[i], b.h[i], b.c[i], b.h[i + 1], b.c[i + 1], b.pm,
@@ -1016,7 +1018,7 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
         // boundary handle of a zero-padded inner handle (PadShim above): owns the reference-shaped parameter table and the maps only
         h->L = cfg->dim_latent; h->T = cfg->iters; h->K = cfg->slots; h->S = cfg->img_size; h->P = h->S * h->S; h->H = cfg->ref_mlp_units;
         h->Cd = cfg->dec_conv_chan; h->Dd = cfg->dec_conv_layers; h->Cr = cfg->ref_conv_chan; h->Dr = cfg->ref_conv_layers;
-        h->kd = cfg->dec_kernel_size; h->kr = cfg->ref_kernel_size;
+        h->kd = cfg->dec_kernel_size; h->kr = cfg->ref_kernel_size; h->rs = cfg->ref_stride;
         h->n_in = 0;
         for (unsigned bit = 0; bit < 12; ++bit) {
             static const int cnt[12] = {0, 0, 3, 3, 1, 1, 1, 3, 1, 1, 1, 2};      // channels per ENCODING entry, order of the IODINE_ENC_* bits
@@ -1039,9 +1041,9 @@ int iodine_create(const iodine_config* cfg, iodine_handle** out)
     h->L = cfg->dim_latent; h->T = cfg->iters; h->K = cfg->slots; h->S = cfg->img_size; h->P = h->S * h->S;
     h->Cd = cfg->dec_conv_chan; h->Dd = cfg->dec_conv_layers; h->Cr = cfg->ref_conv_chan; h->Dr = cfg->ref_conv_layers;
     h->H = cfg->ref_mlp_units;
-    h->kd = cfg->dec_kernel_size; h->kr = cfg->ref_kernel_size;
+    h->kd = cfg->dec_kernel_size; h->kr = cfg->ref_kernel_size; h->rs = cfg->ref_stride;
     h->generic = h->kd != 3 || (h->Cd != 32 && h->Cd != 64) || h->S % 16 != 0;
-    h->gen_ref = h->kr != 3 || (h->Cr != 32 && h->Cr != 64) || h->S % 16 != 0;
+    h->gen_ref = h->kr != 3 || (h->Cr != 32 && h->Cr != 64) || h->S % 16 != 0 || h->rs != 2;
     {
         // image-shaped entries in CODE order (iodine.py:277-340) with their channel counts
         static const struct { unsigned bit; int first, count; } ent[10] = {
@@ -1644,7 +1646,7 @@ int iodine_train_forward(iodine_handle* h, void* stream, int batch, const float*
     if (rc) return rc;
     if (!x || !eps || !loss) return h->fail(IODINE_ERR_INVALID, "iodine_train_forward: x, eps and loss are required");
     // the backward pass runs the refinement conv stack over all T iterations as one batch of T * N slot-images
-    if ((size_t)batch * h->K * h->T * h->P * 20 >= ((size_t)1 << 31) || (size_t)batch * h->K * h->T * (h->P / 4) * h->Cr >= ((size_t)1 << 31))
+    if ((size_t)batch * h->K * h->T * h->P * 20 >= ((size_t)1 << 31) || (size_t)batch * h->K * h->T * (size_t)ref_out_size(h, h->S) * ref_out_size(h, h->S) * h->Cr >= ((size_t)1 << 31))
         return h->fail(IODINE_ERR_INVALID, "batch too large for one device in training: batch * slots * iters * pixels * 20 must stay below "
                                            "2^31 (shard the images over ranks, iodine_amd.parallel)");
     rc = ensure_workspace(h, batch, 1);
@@ -1773,7 +1775,7 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
         const int NT = T * N;
         std::vector<int> sz(h->Dr + 1);
         sz[0] = h->S;
-        for (int l = 0; l < h->Dr; ++l) sz[l + 1] = ref_out_size(sz[l]);
+        for (int l = 0; l < h->Dr; ++l) sz[l + 1] = ref_out_size(h, sz[l]);
         const int sl = sz[h->Dr];
         HIPCHK(h, launch_pool_bwd(st, b.dpooled, b.ract[0][h->Dr - 1], b.rdpre[h->Dr - 1], NT, sl * sl, Cr));
         // round 4: the data gradient of layer 1 and the weight / bias gradient of layer 0 in ONE launch - d(pre-activation 0), the
@@ -1791,7 +1793,7 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
             float* gw_dst = gather0 ? h->ref_g17 : G(base + ".weight");
             if (gather0) HIPCHK(h, hipMemsetAsync(h->ref_g17, 0, (size_t)Cr * 17 * h->kr * h->kr * sizeof(float), st));
             if (h->gen_ref) {
-                PROF(h, st, "gen_conv", launch_gen_conv_wgrad(st, in, b.rdpre[l], b.gen_scr, NT, sz[l], ireal, cip, ireal, Cr, h->kr, 2, 1.f,
+                PROF(h, st, "gen_conv", launch_gen_conv_wgrad(st, in, b.rdpre[l], b.gen_scr, NT, sz[l], ireal, cip, ireal, Cr, h->kr, h->rs, 1.f,
                                                               gw_dst, G(base + ".bias"), l == 0 ? h->enc_chmask : 0xffffffffu));
             } else if (l == 0 && fuse01) {
                 int nb = 0;
@@ -1828,7 +1830,7 @@ static int train_backward_impl(iodine_handle* h, void* stream, float grad_scale,
             if (l > 0 && !(l == 1 && fuse01)) {
                 if (h->gen_ref)
                     PROF(h, st, "gen_conv", launch_gen_conv_dgrad(st, b.rdpre[l], h->gen_wref[l], b.ract[0][l - 1], b.rdpre[l - 1], NT, sz[l],
-                                                                  Cr, Cr, Cr, h->kr, 2));
+                                                                  Cr, Cr, Cr, h->kr, h->rs));
                 else if (refine_f16_ok(h))
                     PROF(h, st, "refine_dgrad", launch_conv3x3_s2_dgrad_f16x3(st, b.rdpre[l], h->ref_wb16[l], h->ref_wmeta[l] + 2,
                                                                               b.ract[0][l - 1], b.rdpre[l - 1], NT, sz[l], Cr, h->precision == 0));
@@ -1929,7 +1931,7 @@ int iodine_debug_copy(iodine_handle* h, void* stream, const char* name, int iter
     } else if (s.rfind("ract", 0) == 0) {
         const int l = atoi(s.c_str() + 4);
         if (l < 0 || l >= h->Dr) return h->fail(IODINE_ERR_INVALID, "bad refinement layer");
-        int sz = h->S; for (int j = 0; j <= l; ++j) sz = ref_out_size(sz);
+        int sz = h->S; for (int j = 0; j <= l; ++j) sz = ref_out_size(h, sz);
         src = b.ract[iter][l]; n = N * sz * sz * h->Cr;
     } else return h->fail(IODINE_ERR_INVALID, "iodine_debug_copy: unknown buffer " + s);
     if (n_floats) *n_floats = n;

@@ -386,7 +386,7 @@ class IODINE(nn.Module):
         cd, cr = int(self._cfg.dec_conv_chan), int(self._cfg.ref_conv_chan)
         lim = ((1 << 31) - 1) // (K * P * max(cd, cr, 20))
         if training:
-            lim = min(lim, ((1 << 31) - 1) // (K * T * P * 20), ((1 << 31) - 1) // (K * T * max(P // 4, 1) * cr))
+            lim = min(lim, ((1 << 31) - 1) // (K * T * P * 20), ((1 << 31) - 1) // (K * T * max(((self.img_size - 1) // max(int(self._cfg.ref_stride), 1) + 1) ** 2, 1) * cr))
         cap = int(self._options.get('batch_cap', 0))
         return max(1, min(lim, cap) if cap > 0 else lim)
 
@@ -637,13 +637,13 @@ class IODINE(nn.Module):
 
 
 def arch_namespace(dim_latent, iters, slots, img_size, ref, dec, sigma=0.10, layernorm=True,
-                   encoding=_lib.ENC_ORDER, kernels=(3, 3)):
+                   encoding=_lib.ENC_ORDER, kernels=(3, 3), ref_stride=2):
     """Build an ``ARCH``-shaped namespace (the yacs node of lib/config/defaults.py:35-100) from plain
     values; ref = (CONV_CHAN, CONV_LAYERS, MLP_UNITS), dec = (CONV_CHAN, CONV_LAYERS), kernels = (REF, DEC) KERNEL_SIZE."""
     from types import SimpleNamespace as NS
     return NS(DIM_LATENT=dim_latent, ITERS=iters, SLOTS=slots, ENCODING=list(encoding), IMG_CHANNELS=3,
               IMG_SIZE=img_size, SIGMA=sigma, LAYERNORM=layernorm, STOP_GRADIENT=False,
-              REF=NS(CONV_CHAN=ref[0], CONV_LAYERS=ref[1], MLP_UNITS=ref[2], KERNEL_SIZE=kernels[0], STRIDE=2),
+              REF=NS(CONV_CHAN=ref[0], CONV_LAYERS=ref[1], MLP_UNITS=ref[2], KERNEL_SIZE=kernels[0], STRIDE=ref_stride),
               DEC=NS(CONV_CHAN=dec[0], CONV_LAYERS=dec[1], KERNEL_SIZE=kernels[1]))
 
 

@@ -236,7 +236,8 @@ def test_kernel_size_5_matches_the_reference_golden():
     assert rel_err(pred.cpu(), g['f32.recon.pred']) < 2e-4 and rel_err(mean.cpu(), g['f32.recon.mean']) < 2e-4
 
 
-@pytest.mark.parametrize('what', ['dec5_ref3', 'ref5_dec3', 'k7', 'k7_size8', 'chan16', 'chan20_dec5', 'chan24_dec', 'chan48_dec', 'chan128', 'size24', 'size40'])
+@pytest.mark.parametrize('what', ['dec5_ref3', 'ref5_dec3', 'k7', 'k7_size8', 'chan16', 'chan20_dec5', 'chan24_dec', 'chan48_dec', 'chan128', 'size24', 'size40',
+                                  'ref_stride1', 'ref_stride3', 'ref_stride4_k5'])
 def test_generic_path_configurations(what):
     """the reference's default kernel sizes (REF 3, DEC 5), KERNEL_SIZE 7, channel counts the tuned kernels are not built for, and image
     sizes that are not a multiple of 16 (the reference only asks for a multiple of 8, lib/config/defaults.py:45); k7_size8: the smallest image with
@@ -244,7 +245,9 @@ def test_generic_path_configurations(what):
     channel counts that leave the last 16-channel chunk of the MFMA conv partly empty and the last 32-channel plane of the weight gradients ragged"""
     # (round 5: the two stacks fall back separately - dec5_ref3 = generic decoder + tuned refinement kernels, ref5_dec3 the other way round)
     kw = dict(dec5_ref3=dict(ref_kernel=3, dec_kernel=5), ref5_dec3=dict(ref_kernel=5, dec_kernel=3), k7=dict(ref_kernel=7, dec_kernel=7), k7_size8=dict(ref_kernel=3, dec_kernel=7, img_size=8), chan16=dict(ref_chan=16, dec_chan=16),
-              chan20_dec5=dict(dec_chan=20, dec_kernel=5), chan24_dec=dict(dec_chan=24), chan48_dec=dict(dec_chan=48), chan128=dict(ref_chan=128, dec_chan=128), size24=dict(img_size=24), size40=dict(img_size=40))[what]
+              chan20_dec5=dict(dec_chan=20, dec_kernel=5), chan24_dec=dict(dec_chan=24), chan48_dec=dict(dec_chan=48), chan128=dict(ref_chan=128, dec_chan=128), size24=dict(img_size=24), size40=dict(img_size=40),
+              # round 6: REF.STRIDE other than 2 (RefinementNetwork takes any, iodine.py:446-459; every shipped config uses 2): the refinement stack on the generic kernels
+              ref_stride1=dict(ref_stride=1), ref_stride3=dict(ref_stride=3), ref_stride4_k5=dict(ref_stride=4, ref_kernel=5, img_size=24))[what]
     arch = dataclasses.replace(O.tiny_arch(slots=3, iters=2, img_size=32 if what in ('dec5_ref3', 'ref5_dec3') else 16), **kw)
     params, x, eps = _case(arch, 2, seed=11)
     _step_vs_oracle(arch, params, x, eps)

@@ -68,7 +68,7 @@ def hip_arch(arch):
     return arch_namespace(arch.dim_latent, arch.iters, arch.slots, arch.img_size,
                           (arch.ref_chan, arch.ref_layers, arch.ref_mlp), (arch.dec_chan, arch.dec_layers),
                           sigma=arch.sigma, layernorm=arch.layernorm, encoding=arch.encoding,
-                          kernels=(arch.ref_kernel, arch.dec_kernel))
+                          kernels=(arch.ref_kernel, arch.dec_kernel), ref_stride=arch.ref_stride)
 
 
 def make_hip_model(arch, params, device='cuda:0', options=None):
