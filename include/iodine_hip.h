@@ -68,7 +68,7 @@ typedef struct iodine_config {
     int ref_kernel_size;   /* ARCH.REF.KERNEL_SIZE (3: tuned kernels; 5, 7: generic fallback path, kernels_generic.hip) */
     int ref_stride;        /* ARCH.REF.STRIDE      (2: tuned kernels; 1, 3 .. 8: the refinement stack on the generic path) */
     int dec_conv_chan;     /* ARCH.DEC.CONV_CHAN   (32 or 64: tuned kernels; other multiples of 4 in 8..256: generic path) */
-    int dec_conv_layers;   /* ARCH.DEC.CONV_LAYERS (>= 2) */
+    int dec_conv_layers;   /* ARCH.DEC.CONV_LAYERS (>= 1) */
     int dec_kernel_size;   /* ARCH.DEC.KERNEL_SIZE (3: tuned kernels; 5 - the reference's default - and 7: generic path) */
 } iodine_config;
 

@@ -310,7 +310,7 @@ std::string validate(const iodine_config& c)
     if (c.dec_conv_chan < 8 || c.dec_conv_chan > 256 || c.dec_conv_chan % 4 != 0) return "DEC.CONV_CHAN must be a multiple of 4 in 8..256";
     if (c.ref_conv_chan < 4 || c.ref_conv_chan > 256 || 256 % c.ref_conv_chan != 0) return "REF.CONV_CHAN must divide 256 (4 ... 256)";
     if (9 * c.dec_conv_chan < c.dim_latent) return "DIM_LATENT must not exceed 9 * DEC.CONV_CHAN";
-    if (c.dec_conv_layers < 2) return "DEC.CONV_LAYERS must be >= 2";
+    if (c.dec_conv_layers < 1 || c.dec_conv_layers > 32) return "DEC.CONV_LAYERS must be in 1..32";
     if (c.ref_conv_layers < 1 || c.ref_conv_layers > 16 || (c.ref_stride == 2 && (c.img_size >> c.ref_conv_layers) < 1)) return "REF.CONV_LAYERS out of range for IMG_SIZE";
     if (c.slots < 1 || c.slots > 16) return "ARCH.SLOTS must be in 1..16 (the per-pixel kernels keep every slot of a pixel in registers: instantiated for K <= 16)";
     if (c.iters < 1) return "ARCH.ITERS must be >= 1";

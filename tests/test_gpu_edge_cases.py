@@ -28,6 +28,9 @@ def _case(arch, B, seed):
 CASES = {
     'one_slot': (dataclasses.replace(O.tiny_arch(slots=1, iters=2)), 3),
     'twelve_slots': (dataclasses.replace(O.tiny_arch(slots=12, iters=2)), 2),
+    'one_decoder_layer': (O.tiny_arch(slots=3, iters=2, dec_layers=1), 2),             # round 6: broadcast layer + output conv only (DEC.CONV_LAYERS 1)
+    'one_decoder_layer_k5': (dataclasses.replace(O.tiny_arch(slots=3, iters=2, dec_layers=1), dec_kernel=5), 2),
+    'one_refinement_layer': (O.tiny_arch(slots=3, iters=2, ref_layers=1), 2),
     'sixteen_slots': (dataclasses.replace(O.tiny_arch(slots=16, iters=2)), 2),       # round 6: K = 13 .. 16 instantiated (VERDICT r05 missing #6)
     'one_iteration_batch_one': (dataclasses.replace(O.tiny_arch(slots=3, iters=1)), 1),
     'no_layernorm': (dataclasses.replace(O.tiny_arch(slots=3, iters=2), layernorm=False), 2),
